@@ -1,0 +1,1131 @@
+/*
+ * slowflow_oracle.c -- CPU restatement of the slowflow variational-refinement hot path.
+ * TEST INFRASTRUCTURE ONLY (see slowflow_oracle.h for the pin status of every function).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fPIC -shared (oracle/Makefile).
+ * The reference is compiled -O3 -msse4 without FMA or fast-math (CMakeLists.txt:6), i.e. every
+ * fp32 expression is evaluated left-to-right with one rounding per operation; the restatement
+ * keeps each expression's association exactly as written in the reference source.
+ */
+#include "slowflow_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static float *plane_alloc(size_t n) {
+    float *p = (float *)calloc(n ? n : 1, sizeof(float));
+    if (!p) { fprintf(stderr, "slowflow_oracle: out of memory\n"); abort(); }
+    return p;
+}
+
+void orc_params_default(orc_params *p) {
+    /* slow_flow.cpp:64-128 (driver defaults) */
+    memset(p, 0, sizeof(*p));
+    p->S = 2; p->one_direction = 0; p->smoothing = 1; p->dataterm_norm = 1;
+    p->niter_alter = 10; p->niter_outer = 10; p->niter_inner = 1; p->niter_solver = 30;
+    p->thres_outer = 1e-5f; p->thres_inner = 1e-5f; p->sor_omega = 1.9f;
+    p->alpha = 4.0f; p->gamma = 6.0f; p->delta = 1.0f;
+    p->robust_color.id = 1; p->robust_color.eps = 0.001f; p->robust_color.trunc = 0.5f;
+    p->robust_grad = p->robust_color; p->robust_reg = p->robust_color;
+    p->rho[0] = 1; p->rho[1] = 1; p->rho[2] = 1; p->rho[3] = 1;
+    p->omega[0] = 0; p->omega[1] = 2; p->omega[2] = 1; p->omega[3] = 1;
+    p->hbit = 1;
+    for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
+    p->occlusion_reasoning = 1;
+    p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * penalty_functions headers -- psi'(x^2)
+ * ---------------------------------------------------------------------------------------- */
+
+/* scalar overloads: quadratic_function.h:23, modified_l1_norm.h:28-30 (double epsilon_sq member,
+ * double sqrt), lorentzian.h:36-38, trunc_modified_l1_norm.h:40-45 (float epsilon_sq member and
+ * float sqrt: all-float), geman_mcclure.h:28-32 */
+float orc_psi_deriv_scalar(const orc_penalty *pen, float xsq) {
+    const float e2f = pen->eps * pen->eps;     /* epsilon_sq(e*e): float product */
+    const double e2d = (double)e2f;
+    switch (pen->id) {
+    case 0: return 1.0f;
+    case 2: return (float)(1 / (2 * e2d + xsq));
+    case 3:
+        if (sqrtf(xsq) > pen->trunc) return 0;
+        return 1 / (2 * sqrtf(xsq + e2f));
+    case 4: {
+        float tmp = (float)(e2d + xsq);
+        tmp = tmp * tmp;
+        return (float)((e2d + 2 * xsq) / tmp);
+    }
+    default: return (float)(1 / (2 * sqrt(xsq + e2d)));
+    }
+}
+
+/* v4sf overloads: pure fp32, sqrtps/divps (modified_l1_norm.h:32-34, lorentzian.h:40-42,
+ * trunc_modified_l1_norm.h:47-56, geman_mcclure.h:34-38) */
+float orc_psi_deriv_vec(const orc_penalty *pen, float xsq) {
+    const float e2 = pen->eps * pen->eps;
+    switch (pen->id) {
+    case 0: return 1.0f;
+    case 2: return 1.0f / (2.0f * e2 + xsq);
+    case 3: {
+        float out = 1.0f / (2.0f * sqrtf(xsq + e2));
+        if (sqrtf(xsq) > pen->trunc) out = 0;
+        return out;
+    }
+    case 4: {
+        float tmp = e2 + xsq;
+        tmp = tmp * tmp;
+        return (e2 + 2.0f * xsq) / tmp;
+    }
+    default: return 1.0f / (2.0f * sqrtf(xsq + e2));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * image.c -- derivative filters
+ * ---------------------------------------------------------------------------------------- */
+
+/* coefficients as convolution_new(order, half, even=0) builds them (image.c:363-366 with
+ * variational_mt.cpp:570-573): coeffs[order-i] = +half[i]; coeffs[order+i] = -half[i] */
+static void deriv_coeffs(int order, float c[5]) {
+    if (order == 2) {
+        const float half[3] = {0.0f, -8.0f / 12.0f, 1.0f / 12.0f};
+        for (int i = 0; i <= 2; i++) { c[2 - i] = +half[i]; c[2 + i] = -half[i]; }
+    } else {
+        const float half[2] = {0.0f, -0.5f};
+        for (int i = 0; i <= 1; i++) { c[1 - i] = +half[i]; c[1 + i] = -half[i]; }
+    }
+}
+
+static inline int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
+
+/* image.c:460-526: replicate border on both sides (the shifted copies src_m1/src_m2/src_p1/src_p2) */
+void orc_convolve_horiz(float *dst, const float *src, int w, int h, int stride, int order) {
+    float c[5];
+    deriv_coeffs(order, c);
+    for (int y = 0; y < h; y++) {
+        const float *s = src + (size_t)y * stride;
+        float *d = dst + (size_t)y * stride;
+        for (int x = 0; x < w; x++) {
+            if (order == 2) {
+                const float m2 = s[clampi(x - 2, 0, w - 1)], m1 = s[clampi(x - 1, 0, w - 1)];
+                const float p1 = s[clampi(x + 1, 0, w - 1)], p2 = s[clampi(x + 2, 0, w - 1)];
+                d[x] = c[0] * m2 + c[1] * m1 + c[2] * s[x] + c[3] * p1 + c[4] * p2;   /* image.c:521 */
+            } else {
+                const float m1 = s[clampi(x - 1, 0, w - 1)], p1 = s[clampi(x + 1, 0, w - 1)];
+                d[x] = c[0] * m1 + c[1] * s[x] + c[2] * p1;                            /* image.c:482 */
+            }
+        }
+    }
+}
+
+/* image.c:400-458: border rows fold the coefficients at run time in fp32 */
+void orc_convolve_vert(float *dst, const float *src, int w, int h, int stride, int order) {
+    float c[5];
+    deriv_coeffs(order, c);
+    for (int y = 0; y < h; y++) {
+        float *d = dst + (size_t)y * stride;
+        const float *s0 = src + (size_t)y * stride;
+        for (int x = 0; x < w; x++) {
+            if (order == 2) {
+                if (y == 0)                 /* image.c:434 */
+                    d[x] = (c[0] + c[1] + c[2]) * s0[x] + c[3] * s0[x + stride] + c[4] * s0[x + 2 * stride];
+                else if (y == 1)            /* image.c:439 */
+                    d[x] = (c[0] + c[1]) * s0[x - stride] + c[2] * s0[x] + c[3] * s0[x + stride] + c[4] * s0[x + 2 * stride];
+                else if (y == h - 2)        /* image.c:451 */
+                    d[x] = c[0] * s0[x - 2 * stride] + c[1] * s0[x - stride] + c[2] * s0[x] + (c[3] + c[4]) * s0[x + stride];
+                else if (y == h - 1)        /* image.c:455 */
+                    d[x] = c[0] * s0[x - 2 * stride] + c[1] * s0[x - stride] + (c[2] + c[3] + c[4]) * s0[x];
+                else                        /* image.c:446 */
+                    d[x] = c[0] * s0[x - 2 * stride] + c[1] * s0[x - stride] + c[2] * s0[x] + c[3] * s0[x + stride] + c[4] * s0[x + 2 * stride];
+            } else {
+                if (y == 0)                 /* image.c:408 */
+                    d[x] = (c[0] + c[1]) * s0[x] + c[2] * s0[x + stride];
+                else if (y == h - 1)        /* image.c:420 */
+                    d[x] = c[0] * s0[x - stride] + (c[1] + c[2]) * s0[x];
+                else                        /* image.c:415 */
+                    d[x] = c[0] * s0[x - stride] + c[1] * s0[x] + c[2] * s0[x + stride];
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_aux_mt.cpp:722-756 -- image_warp
+ * ---------------------------------------------------------------------------------------- */
+#define RECTIFY(a, b) (((a) < 0) ? (0) : (((a) < (b)-1) ? (a) : ((b)-1)))
+
+void orc_image_warp(float *dst3, float *mask, const float *src3, const float *wx, const float *wy,
+                    int w, int h, int stride, int factor) {
+    const size_t plane = (size_t)stride * h;
+    if (factor == 0) {                                        /* :723-728 */
+        for (int k = 0; k < 3; k++)
+            for (int y = 0; y < h; y++)
+                memcpy(dst3 + k * plane + (size_t)y * stride, src3 + k * plane + (size_t)y * stride, sizeof(float) * w);
+        /* the reference memset()s mask BYTES to 1 here (:726); unreachable from get_derivatives,
+         * the oracle leaves mask untouched */
+        return;
+    }
+    for (int j = 0; j < h; j++) {
+        size_t offset = (size_t)j * stride;
+        for (int i = 0; i < w; i++, offset++) {
+            const float xx = i + factor * wx[offset];        /* :735 */
+            const float yy = j + factor * wy[offset];
+            const int x = (int)floor(xx);
+            const int y = (int)floor(yy);
+            const float dx = xx - x;
+            const float dy = yy - y;
+            if (mask) mask[offset] = (xx >= 0 && xx <= w - 1 && yy >= 0 && yy <= h - 1);
+            const int x1 = RECTIFY(x, w), x2 = RECTIFY(x + 1, w);
+            const int y1 = RECTIFY(y, h), y2 = RECTIFY(y + 1, h);
+            for (int k = 0; k < 3; k++) {
+                const float *s = src3 + k * plane;
+                dst3[k * plane + offset] = s[(size_t)y1 * stride + x1] * (1.0f - dx) * (1.0f - dy)
+                                         + s[(size_t)y1 * stride + x2] * dx * (1.0f - dy)
+                                         + s[(size_t)y2 * stride + x1] * (1.0f - dx) * dy
+                                         + s[(size_t)y2 * stride + x2] * dx * dy;          /* :748-753 */
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_mt.cpp:113-133 -- one derivative stack
+ * ---------------------------------------------------------------------------------------- */
+enum { D_IX = 0, D_IY, D_IZ, D_IXX, D_IXY, D_IYY, D_IXZ, D_IYZ };
+
+void orc_derivative_stack(float *out, const float *I1, const float *I2, int w, int h, int stride) {
+    const size_t plane = (size_t)stride * h, cimg = 3 * plane;
+    float *mean = plane_alloc(cimg);
+    float *Iz = out + D_IZ * cimg;
+    for (int k = 0; k < 3; k++)
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const size_t o = k * plane + (size_t)y * stride + x;
+                mean[o] = 0.5f * (I2[o] + I1[o]);   /* :120 */
+                Iz[o] = I1[o] - I2[o];              /* :122 */
+            }
+    for (int k = 0; k < 3; k++) {
+        const size_t o = k * plane;
+        orc_convolve_horiz(out + D_IX * cimg + o, mean + o, w, h, stride, 2);                  /* :127 */
+        orc_convolve_vert(out + D_IY * cimg + o, mean + o, w, h, stride, 2);                   /* :128 */
+        orc_convolve_horiz(out + D_IXX * cimg + o, out + D_IX * cimg + o, w, h, stride, 2);    /* :129 */
+        orc_convolve_vert(out + D_IXY * cimg + o, out + D_IX * cimg + o, w, h, stride, 2);     /* :130 */
+        orc_convolve_vert(out + D_IYY * cimg + o, out + D_IY * cimg + o, w, h, stride, 2);     /* :131 */
+        orc_convolve_horiz(out + D_IXZ * cimg + o, Iz + o, w, h, stride, 2);                   /* :132 */
+        orc_convolve_vert(out + D_IYZ * cimg + o, Iz + o, w, h, stride, 2);                    /* :133 */
+    }
+    free(mean);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_aux_mt.cpp:673-719 -- local smoothness weight
+ * ---------------------------------------------------------------------------------------- */
+void orc_dpsis_weight(float *dst, const float *im3, int w, int h, int stride, float coef,
+                      const float avg[3], const float std[3], int hbit) {
+    const size_t plane = (size_t)stride * h;
+    float *lum = plane_alloc(plane), *lx = plane_alloc(plane), *ly = plane_alloc(plane);
+    const float *c1 = im3, *c2 = im3 + plane, *c3 = im3 + 2 * plane;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t o = (size_t)y * stride + x;
+            const float v = 0.299f * (c1[o] * std[0] + avg[0]) + 0.587f * (c2[o] * std[1] + avg[1]) + 0.114f * (c3[o] * std[2] + avg[2]);
+            lum[o] = hbit ? v / 65535.0f : v / 255.0f;       /* :681,683 */
+        }
+    orc_convolve_horiz(lx, lum, w, h, stride, 2);
+    orc_convolve_vert(ly, lum, w, h, stride, 2);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t o = (size_t)y * stride + x;
+            const float n = -coef * sqrtf(lx[o] * lx[o] + ly[o] * ly[o]);   /* :699 */
+            dst[o] = 0.5f * expf(n);                                       /* :700 */
+        }
+    free(lum); free(lx); free(ly);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_aux_mt.cpp:18-127 -- smoothness weights
+ * ---------------------------------------------------------------------------------------- */
+void orc_smoothness(int method, float *dst_horiz, float *dst_vert, const float *uu, const float *vv,
+                    const float *dpsis, int w, int h, int stride, float alpha, const orc_penalty *reg) {
+    const int s = stride;
+    const size_t plane = (size_t)stride * h;
+    float *ux1 = plane_alloc(plane), *uy1 = plane_alloc(plane), *vx1 = plane_alloc(plane), *vy1 = plane_alloc(plane);
+    float *ux2 = plane_alloc(plane), *uy2 = plane_alloc(plane), *vx2 = plane_alloc(plane), *vy2 = plane_alloc(plane);
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w - 1; i++) {
+            const size_t o = (size_t)j * s + i;
+            ux1[o] = uu[o + 1] - uu[o];                      /* :27 */
+            vx1[o] = vv[o + 1] - vv[o];
+        }
+    for (int j = 0; j < h - 1; j++)
+        for (int i = 0; i < w; i++) {
+            const size_t o = (size_t)j * s + i;
+            uy1[o] = uu[o + s] - uu[o];                      /* :35 */
+            vy1[o] = vv[o + s] - vv[o];
+        }
+    orc_convolve_horiz(ux2, uu, w, h, stride, 1);
+    orc_convolve_horiz(vx2, vv, w, h, stride, 1);
+    orc_convolve_vert(uy2, uu, w, h, stride, 1);
+    orc_convolve_vert(vy2, vv, w, h, stride, 1);
+    if (method <= 1) {
+        for (int j = 0; j < h; j++) {
+            for (int i = 0; i < w - 1; i++) {
+                const size_t o = (size_t)j * s + i;
+                float tmp = 0, tmp2 = 0;
+                const float tmp_w = dpsis[o] + dpsis[o + 1];
+                if (method == 1) {
+                    tmp = 0.5f * (uy2[o] + uy2[o + 1]);      /* :57 */
+                    tmp2 = 0.5f * (vy2[o] + vy2[o + 1]);
+                }
+                tmp = ux1[o] * ux1[o] + tmp * tmp;           /* :61 */
+                tmp2 = vx1[o] * vx1[o] + tmp2 * tmp2;
+                tmp = tmp + tmp2;
+                dst_horiz[o] = tmp_w * alpha * orc_psi_deriv_scalar(reg, tmp);   /* :66 */
+            }
+            for (int i = w - 1; i < s; i++) dst_horiz[(size_t)j * s + i] = 0;    /* :68 */
+        }
+        for (int j = 0; j < h - 1; j++)
+            for (int i = 0; i < w; i++) {
+                const size_t o = (size_t)j * s + i;
+                float tmp = 0, tmp2 = 0;
+                const float tmp_w = dpsis[o] + dpsis[o + s];
+                if (method == 1) {
+                    tmp = 0.5f * (ux2[o] + ux2[o + s]);      /* :80 */
+                    tmp2 = 0.5f * (vx2[o] + vx2[o + s]);
+                }
+                tmp = uy1[o] * uy1[o] + tmp * tmp;           /* :84 */
+                tmp2 = vy1[o] * vy1[o] + tmp2 * tmp2;
+                tmp = tmp + tmp2;
+                dst_vert[o] = tmp_w * alpha * orc_psi_deriv_scalar(reg, tmp);    /* :89 */
+            }
+        for (int i = 0; i < s; i++) dst_vert[(size_t)(h - 1) * s + i] = 0;       /* :92 */
+    } else {
+        /* :96-116 as written, including the `float w` that shadows the image width inside the loop
+         * body (:100), which makes the horizontal test `i < w - 1` compare against (weight - 1) */
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                const size_t o = (size_t)j * s + i;
+                float tmp = 0;
+                float wgt = dpsis[o];
+                if (i < wgt - 1) {
+                    tmp += ux1[o] * ux1[o] + vx1[o] * vx1[o];
+                    wgt += dpsis[o + 1];
+                }
+                if (j < h - 1) {
+                    tmp += vy1[o] * vy1[o] + uy1[o] * uy1[o];
+                    wgt += dpsis[o + s];
+                }
+                dst_horiz[o] = wgt * alpha * orc_psi_deriv_scalar(reg, tmp);
+                dst_vert[o] = dst_horiz[o];
+            }
+    }
+    free(ux1); free(uy1); free(vx1); free(vy1); free(ux2); free(uy2); free(vx2); free(vy2);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_aux_mt.cpp:130-161 -- sub_laplacian (sequential scatter form, as the reference)
+ * ---------------------------------------------------------------------------------------- */
+void orc_sub_laplacian(float *dst, const float *src, const float *wh, const float *wv, int w, int h, int stride) {
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w - 1; i++) {
+            const size_t o = (size_t)j * stride + i;
+            const float tmp = wh[o] * (src[o + 1] - src[o]);     /* :138 */
+            dst[o] += tmp;
+            dst[o + 1] -= tmp;
+        }
+    for (int j = 0; j < h - 1; j++)
+        for (int i = 0; i < w; i++) {
+            const size_t o = (size_t)j * stride + i;
+            const float tmp = wv[o] * (src[o + stride] - src[o]); /* :152 */
+            dst[o] += tmp;
+            dst[o + stride] -= tmp;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_aux_mt.cpp:166-403 -- successive-frames data term
+ * ---------------------------------------------------------------------------------------- */
+static const float datanorm = 0.1f * 0.1f;   /* variational_aux_mt.h:23 */
+
+void orc_add_data_and_match(float *a11, float *a12, float *a22, float *b1, float *b2, const float *mask,
+                            const float *du, const float *dv, const float *D, const float *const chw[3],
+                            int w, int h, int stride, float delta_over3, float gamma_over3, float s,
+                            int dt_norm, const orc_penalty *color, const orc_penalty *grad) {
+    const size_t plane = (size_t)stride * h, cimg = 3 * plane;
+    const float factor = s, factorp1 = s + 1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t o = (size_t)y * stride + x;
+            const float u = du[o], v = dv[o], m = mask[o];
+            float wk[3], ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
+            for (int k = 0; k < 3; k++) {
+                const size_t ok = k * plane + o;
+                wk[k] = chw[k][o];
+                ix[k] = D[D_IX * cimg + ok]; iy[k] = D[D_IY * cimg + ok]; iz[k] = D[D_IZ * cimg + ok];
+                ixx[k] = D[D_IXX * cimg + ok]; ixy[k] = D[D_IXY * cimg + ok]; iyy[k] = D[D_IYY * cimg + ok];
+                ixz[k] = D[D_IXZ * cimg + ok]; iyz[k] = D[D_IYZ * cimg + ok];
+            }
+            float A11 = a11[o], A12 = a12[o], A22 = a22[o], B1 = b1[o], B2 = b2[o];
+            if (delta_over3) {                                                  /* :189 */
+                float r[3], tx[3], ty[3];
+                for (int k = 0; k < 3; k++) {
+                    r[k] = wk[k] * (iz[k] + ix[k] * factor * u + iy[k] * factor * v - ix[k] * factorp1 * u - iy[k] * factorp1 * v);  /* :190-192 */
+                    tx[k] = factor * ix[k] - factorp1 * ix[k];                  /* :198,229 */
+                    ty[k] = factor * iy[k] - factorp1 * iy[k];
+                }
+                if (!dt_norm) {
+                    const float t = m * delta_over3 * orc_psi_deriv_vec(color, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);   /* :196 */
+                    for (int k = 0; k < 3; k++) {
+                        const float t2 = t * wk[k];
+                        A11 += t2 * tx[k] * tx[k];
+                        A12 += t2 * tx[k] * ty[k];
+                        A22 += t2 * ty[k] * ty[k];
+                        B1 -= t2 * iz[k] * tx[k];
+                        B2 -= t2 * iz[k] * ty[k];
+                    }
+                } else {
+                    float n[3];
+                    for (int k = 0; k < 3; k++) n[k] = tx[k] * tx[k] + ty[k] * ty[k] + datanorm;   /* :236-238 */
+                    const float t = m * delta_over3 * orc_psi_deriv_vec(color, r[0] * r[0] / n[0] + r[1] * r[1] / n[1] + r[2] * r[2] / n[2]);   /* :240 */
+                    for (int k = 0; k < 3; k++) {
+                        float tk = t / n[k];
+                        tk = tk * wk[k];
+                        A11 += tk * tx[k] * tx[k];
+                        A12 += tk * tx[k] * ty[k];
+                        A22 += tk * ty[k] * ty[k];
+                        B1 -= tk * iz[k] * tx[k];
+                        B2 -= tk * iz[k] * ty[k];
+                    }
+                }
+            }
+            {   /* gradient constancy :269-364 */
+                float r[6], X[3], Y[3], Z[3];
+                for (int k = 0; k < 3; k++) {
+                    r[2 * k] = wk[k] * (ixz[k] + ixx[k] * factor * u + ixy[k] * factor * v - ixx[k] * factorp1 * u - ixy[k] * factorp1 * v);
+                    r[2 * k + 1] = wk[k] * (iyz[k] + ixy[k] * factor * u + iyy[k] * factor * v - ixy[k] * factorp1 * u - iyy[k] * factorp1 * v);
+                    X[k] = factor * ixx[k] - factorp1 * ixx[k];
+                    Y[k] = factor * iyy[k] - factorp1 * iyy[k];
+                    Z[k] = factor * ixy[k] - factorp1 * ixy[k];
+                }
+                if (!dt_norm) {
+                    const float t = m * gamma_over3 * orc_psi_deriv_vec(grad, r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3] + r[4] * r[4] + r[5] * r[5]);   /* :280 */
+                    for (int k = 0; k < 3; k++) {
+                        const float t2 = t * wk[k];
+                        A11 += t2 * X[k] * X[k] + t2 * Z[k] * Z[k];
+                        A12 += t2 * X[k] * Z[k] + t2 * Z[k] * Y[k];
+                        A22 += t2 * Y[k] * Y[k] + t2 * Z[k] * Z[k];
+                        B1 -= t2 * ixz[k] * X[k] + t2 * iyz[k] * Z[k];
+                        B2 -= t2 * iyz[k] * Y[k] + t2 * ixz[k] * Z[k];
+                    }
+                } else {
+                    float n[6];
+                    for (int k = 0; k < 3; k++) {
+                        n[2 * k] = X[k] * X[k] + Z[k] * Z[k] + datanorm;        /* :326-331 */
+                        n[2 * k + 1] = Y[k] * Y[k] + Z[k] * Z[k] + datanorm;
+                    }
+                    const float t = m * gamma_over3 * orc_psi_deriv_vec(grad,
+                        r[0] * r[0] / n[0] + r[1] * r[1] / n[1] + r[2] * r[2] / n[2] + r[3] * r[3] / n[3] + r[4] * r[4] / n[4] + r[5] * r[5] / n[5]);   /* :333 */
+                    for (int k = 0; k < 3; k++) {
+                        float ta = t / n[2 * k], tb = t / n[2 * k + 1];
+                        ta = ta * wk[k];
+                        tb = tb * wk[k];
+                        A11 += ta * X[k] * X[k] + tb * Z[k] * Z[k];             /* :343-347 */
+                        A12 += ta * X[k] * Z[k] + tb * Z[k] * Y[k];
+                        A22 += tb * Y[k] * Y[k] + ta * Z[k] * Z[k];
+                        B1 -= ta * ixz[k] * X[k] + tb * iyz[k] * Z[k];
+                        B2 -= tb * iyz[k] * Y[k] + ta * ixz[k] * Z[k];
+                    }
+                }
+            }
+            a11[o] = A11; a12[o] = A12; a22[o] = A22; b1[o] = B1; b2[o] = B2;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_aux_mt.cpp:408-634 -- reference-frame data term
+ * ---------------------------------------------------------------------------------------- */
+int orc_add_data_and_match_ref(float *a11, float *a12, float *a22, float *b1, float *b2, const float *mask,
+                               const float *du, const float *dv, const float *D, const float *const chw[3],
+                               int w, int h, int stride, float delta_over3, float gamma_over3, float s,
+                               int dt_norm, const orc_penalty *color, const orc_penalty *grad) {
+    const size_t plane = (size_t)stride * h, cimg = 3 * plane;
+    float factor = s;
+    const float factorsq = factor * factor;                  /* :417 */
+    if (s == 0) return -1;                                   /* :419-421 */
+    if (s >= 0) factor = -factor;                            /* :424-425 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t o = (size_t)y * stride + x;
+            const float u = du[o], v = dv[o], m = mask[o];
+            float wk[3], ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
+            for (int k = 0; k < 3; k++) {
+                const size_t ok = k * plane + o;
+                wk[k] = chw[k][o];
+                ix[k] = D[D_IX * cimg + ok]; iy[k] = D[D_IY * cimg + ok]; iz[k] = D[D_IZ * cimg + ok];
+                ixx[k] = D[D_IXX * cimg + ok]; ixy[k] = D[D_IXY * cimg + ok]; iyy[k] = D[D_IYY * cimg + ok];
+                ixz[k] = D[D_IXZ * cimg + ok]; iyz[k] = D[D_IYZ * cimg + ok];
+            }
+            float A11 = a11[o], A12 = a12[o], A22 = a22[o], B1 = b1[o], B2 = b2[o];
+            if (delta_over3) {                                                  /* :439 */
+                float r[3];
+                for (int k = 0; k < 3; k++)
+                    r[k] = wk[k] * (iz[k] + ix[k] * factor * u + iy[k] * factor * v);   /* :441-443 */
+                if (!dt_norm) {
+                    float t = m * delta_over3 * orc_psi_deriv_vec(color, r[0] * r[0] / factorsq + r[1] * r[1] / factorsq + r[2] * r[2] / factorsq);  /* :447 */
+                    t /= factorsq;
+                    float t2;
+                    t2 = t * wk[0] * factor;                                    /* :450 */
+                    B1 -= t2 * iz[0] * ix[0];
+                    B2 -= t2 * iz[0] * iy[0];
+                    t2 = t2 * factor;
+                    A11 += t2 * ix[0] * ix[0];
+                    A12 += t2 * ix[0] * iy[0];
+                    A22 += t2 * iy[0] * iy[0];
+                    t2 = t * factor * wk[1];                                    /* :458 */
+                    B1 -= t2 * iz[1] * ix[1];
+                    B2 -= t2 * iz[1] * iy[1];
+                    t2 = t2 * factor;
+                    A11 += t2 * ix[1] * ix[1];
+                    A12 += t2 * ix[1] * iy[1];
+                    A22 += t2 * iy[1] * iy[1];
+                    t2 = t * factor * wk[2];                                    /* :466 */
+                    B1 -= t2 * iz[2] * ix[2];
+                    B2 -= t2 * iz[2] * iy[2];
+                    t2 = t * factor;                                            /* :469 (sic: tmp, not tmp2) */
+                    A11 += t2 * ix[2] * ix[2];
+                    A12 += t2 * ix[2] * iy[2];
+                    A22 += t2 * iy[2] * iy[2];
+                } else {
+                    float n[3];
+                    for (int k = 0; k < 3; k++) n[k] = factorsq * ix[k] * ix[k] + factorsq * iy[k] * iy[k] + datanorm;   /* :475-477 */
+                    const float t = m * delta_over3 * orc_psi_deriv_vec(color, r[0] * r[0] / n[0] + r[1] * r[1] / n[1] + r[2] * r[2] / n[2]);   /* :479 */
+                    for (int k = 0; k < 3; k++) {
+                        float tk = t / n[k];
+                        tk = tk * wk[k] * factor;                               /* :484 */
+                        B1 -= tk * iz[k] * ix[k];
+                        B2 -= tk * iz[k] * iy[k];
+                        tk = tk * factor;
+                        A11 += tk * ix[k] * ix[k];
+                        A12 += tk * ix[k] * iy[k];
+                        A22 += tk * iy[k] * iy[k];
+                    }
+                }
+            }
+            {   /* gradient :511-593 */
+                float r[6];
+                for (int k = 0; k < 3; k++) {
+                    r[2 * k] = wk[k] * (ixz[k] + ixx[k] * factor * u + ixy[k] * factor * v);       /* :511-516 */
+                    r[2 * k + 1] = wk[k] * (iyz[k] + ixy[k] * factor * u + iyy[k] * factor * v);
+                }
+                if (!dt_norm) {
+                    float t = m * gamma_over3 * orc_psi_deriv_vec(grad,
+                        r[0] * r[0] / factorsq + r[1] * r[1] / factorsq + r[2] * r[2] / factorsq + r[3] * r[3] / factorsq + r[4] * r[4] / factorsq + r[5] * r[5] / factorsq);  /* :520-521 */
+                    t /= factorsq;
+                    for (int k = 0; k < 3; k++) {
+                        float t2 = t * wk[k] * factor;                          /* :524 */
+                        B1 -= t2 * ixx[k] * ixz[k] + t2 * ixy[k] * iyz[k];
+                        B2 -= t2 * iyy[k] * iyz[k] + t2 * ixy[k] * ixz[k];
+                        t2 = t2 * factor;
+                        if (k == 0) {                                           /* :528-530 (sic: extra factorsq) */
+                            A11 += t2 * factorsq * ixx[k] * ixx[k] + t2 * factorsq * ixy[k] * ixy[k];
+                            A12 += t2 * factorsq * ixx[k] * ixy[k] + t2 * factorsq * ixy[k] * iyy[k];
+                            A22 += t2 * factorsq * iyy[k] * iyy[k] + t2 * factorsq * ixy[k] * ixy[k];
+                        } else {
+                            A11 += t2 * ixx[k] * ixx[k] + t2 * ixy[k] * ixy[k];
+                            A12 += t2 * ixx[k] * ixy[k] + t2 * ixy[k] * iyy[k];
+                            A22 += t2 * iyy[k] * iyy[k] + t2 * ixy[k] * ixy[k];
+                        }
+                    }
+                } else {
+                    float n[6];
+                    for (int k = 0; k < 3; k++) {
+                        n[2 * k] = factorsq * ixx[k] * ixx[k] + factorsq * ixy[k] * ixy[k] + datanorm;      /* :549-554 */
+                        n[2 * k + 1] = factorsq * iyy[k] * iyy[k] + factorsq * ixy[k] * ixy[k] + datanorm;
+                    }
+                    const float t = m * gamma_over3 * orc_psi_deriv_vec(grad,
+                        r[0] * r[0] / n[0] + r[1] * r[1] / n[1] + r[2] * r[2] / n[2] + r[3] * r[3] / n[3] + r[4] * r[4] / n[4] + r[5] * r[5] / n[5]);   /* :556 */
+                    for (int k = 0; k < 3; k++) {
+                        float ta = t / n[2 * k], tb = t / n[2 * k + 1];
+                        ta = ta * wk[k] * factor;                               /* :564-565 */
+                        tb = tb * wk[k] * factor;
+                        B1 -= ta * ixx[k] * ixz[k] + tb * ixy[k] * iyz[k];
+                        B2 -= tb * iyy[k] * iyz[k] + ta * ixy[k] * ixz[k];
+                        ta = ta * factor;
+                        tb = tb * factor;
+                        A11 += ta * ixx[k] * ixx[k] + tb * ixy[k] * ixy[k];
+                        A12 += ta * ixx[k] * ixy[k] + tb * ixy[k] * iyy[k];
+                        A22 += tb * iyy[k] * iyy[k] + ta * ixy[k] * ixy[k];
+                    }
+                }
+            }
+            a11[o] = A11; a12[o] = A12; a22[o] = A22; b1[o] = B1; b2[o] = B2;
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * solver.c -- SOR
+ * ---------------------------------------------------------------------------------------- */
+
+/* solver.c:17-57 */
+void orc_sor_coupled_readable(float *du, float *dv, const float *a11, const float *a12, const float *a22,
+                              const float *b1, const float *b2, const float *sh, const float *sv,
+                              int w, int h, int stride, int iterations, float omega) {
+    for (int iter = 0; iter < iterations; iter++)
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                const size_t o = (size_t)j * stride + i;
+                float sigma_u = 0.0f, sigma_v = 0.0f, sum_dpsis = 0.0f;
+                if (j > 0) {
+                    sigma_u -= sv[o - stride] * du[o - stride];
+                    sigma_v -= sv[o - stride] * dv[o - stride];
+                    sum_dpsis += sv[o - stride];
+                }
+                if (i > 0) {
+                    sigma_u -= sh[o - 1] * du[o - 1];
+                    sigma_v -= sh[o - 1] * dv[o - 1];
+                    sum_dpsis += sh[o - 1];
+                }
+                if (j < h - 1) {
+                    sigma_u -= sv[o] * du[o + stride];
+                    sigma_v -= sv[o] * dv[o + stride];
+                    sum_dpsis += sv[o];
+                }
+                if (i < w - 1) {
+                    sigma_u -= sh[o] * du[o + 1];
+                    sigma_v -= sh[o] * dv[o + 1];
+                    sum_dpsis += sh[o];
+                }
+                const float A11 = a11[o] + sum_dpsis, A12 = a12[o], A22 = a22[o] + sum_dpsis;
+                const float det = A11 * A22 - A12 * A12;
+                const float B1 = b1[o] - sigma_u, B2 = b2[o] - sigma_v;
+                du[o] = (1.0f - omega) * du[o] + omega * (A22 * B1 - A12 * B2) / det;
+                dv[o] = (1.0f - omega) * dv[o] + omega * (-A12 * B1 + A11 * B2) / det;
+            }
+}
+
+/* solver.c:63-399.  Raster order; per pixel exactly the fast solver's operations:
+ *   hl = sh[x-1] (f1: 0 at x=0, solver.c:82,94), right neighbour = du[x+1], 0 at x=w-1 (f2: :84,95)
+ *   first sweep: dpsis = hl + sh (+ vt if y>0) (+ sv if y<h-1)  (:101,159,214)
+ *                A11 = a22+dpsis, A22 = a11+dpsis, det = A11*A22 - a12*a12,
+ *                a11 <- A11/det, a22 <- A22/det, a12 <- a12/(-det)      (:102-106)
+ *   s1 = sh*du_r (+ vt*du_t) (+ sv*du_b) + b1                            (:108,166,221)
+ *   x == 0: du += w*(a11*s1 + a12*s2 - du)                               (:110)
+ *   x  > 0: B1 = hl*du_l + s1; du += w*(a11*B1 + a12*B2 - du)            (:113-116)
+ * The right / top / bottom neighbours of a 4-pixel block are read before the block's own
+ * updates (the v4sf part), the left one after: equivalent to plain raster order. */
+void orc_sor_coupled(float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
+                     const float *sh, const float *sv, int w, int h, int stride, int iterations, float omega) {
+    if (w < 2 || h < 2 || iterations < 1) {              /* :66-69 */
+        orc_sor_coupled_readable(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, stride, iterations, omega);
+        return;
+    }
+    for (int iter = 0; iter < iterations; iter++)
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                const size_t o = (size_t)j * stride + i;
+                const float hl = i > 0 ? sh[o - 1] : 0.0f;
+                const float hp = sh[o];
+                if (iter == 0) {
+                    float dpsis = hl + hp;
+                    if (j > 0) dpsis = dpsis + sv[o - stride];
+                    if (j < h - 1) dpsis = dpsis + sv[o];
+                    const float A11 = a22[o] + dpsis, A22 = a11[o] + dpsis;
+                    const float det = A11 * A22 - a12[o] * a12[o];
+                    a11[o] = A11 / det;
+                    a22[o] = A22 / det;
+                    a12[o] = a12[o] / -det;
+                }
+                const float dur = i < w - 1 ? du[o + 1] : 0.0f;
+                const float dvr = i < w - 1 ? dv[o + 1] : 0.0f;
+                float s1 = hp * dur, s2 = hp * dvr;
+                if (j > 0) { s1 = s1 + sv[o - stride] * du[o - stride]; s2 = s2 + sv[o - stride] * dv[o - stride]; }
+                if (j < h - 1) { s1 = s1 + sv[o] * du[o + stride]; s2 = s2 + sv[o] * dv[o + stride]; }
+                s1 = s1 + b1[o];
+                s2 = s2 + b2[o];
+                float B1 = s1, B2 = s2;
+                if (i > 0) {
+                    B1 = hl * du[o - 1] + s1;
+                    B2 = hl * dv[o - 1] + s2;
+                }
+                du[o] += omega * (a11[o] * B1 + a12[o] * B2 - du[o]);
+                dv[o] += omega * (a12[o] * B1 + a22[o] * B2 - dv[o]);
+            }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_mt.cpp:17-85 -- normalize
+ * ---------------------------------------------------------------------------------------- */
+void orc_normalize(float **frames, int F, int w, int h, int stride, double avg[3], double std_dev[3]) {
+    const size_t plane = (size_t)stride * h;
+    for (int c = 0; c < 3; c++) { avg[c] = 0; std_dev[c] = 0; }
+    for (int f = 0; f < F; f++) {
+        double avg_frame[3] = {0, 0, 0}, sq_frame[3] = {0, 0, 0};
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++)
+                for (int c = 0; c < 3; c++) {
+                    const float v = frames[f][c * plane + (size_t)i * stride + j];
+                    avg_frame[c] += v;
+                    sq_frame[c] += v * v;            /* float product accumulated in double (:35) */
+                }
+        for (int c = 0; c < 3; c++) {
+            avg[c] += avg_frame[c] / (h * w);
+            std_dev[c] += sq_frame[c] / (h * w);
+        }
+    }
+    for (int c = 0; c < 3; c++) {
+        avg[c] /= F;
+        std_dev[c] = sqrt((std_dev[c] / F) - avg[c] * avg[c]) / 255.0f;     /* :52 */
+    }
+    for (int f = 0; f < F; f++)
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++)
+                for (int c = 0; c < 3; c++)
+                    if (std_dev[c] > 0) {
+                        float *p = &frames[f][c * plane + (size_t)i * stride + j];
+                        *p = (float)((*p - avg[c]) / std_dev[c]);           /* :64-66 */
+                    }
+}
+
+/* :71-84 publishes the six doubles through `ostream <<` (6 significant digits, %g style) and
+ * :250-251 reads them back with atof into float */
+void orc_normalize_publish(const double avg[3], const double std_dev[3], float avg_f[3], float std_f[3]) {
+    char buf[64];
+    for (int c = 0; c < 3; c++) {
+        snprintf(buf, sizeof buf, "%g", avg[c]);
+        avg_f[c] = (float)atof(buf);
+        snprintf(buf, sizeof buf, "%g", std_dev[c]);
+        std_f[c] = (float)atof(buf);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_mt.cpp:169-493 -- one pyramid level
+ * ---------------------------------------------------------------------------------------- */
+int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *const *frames,
+                          const float *const chw[3], float *occ_out, int w, int h, int stride, float change[2]) {
+    const int ref = p->S - 1;
+    if (ref < 1 || ref > ORC_MAX_REF) return -2;
+    const int nslots = 2 * ref;
+    const size_t plane = (size_t)stride * h, cimg = 3 * plane, stack = 8 * cimg;
+    const float gamma_over3 = p->gamma / 3.0f, delta_over3 = p->delta / 3.0f;   /* :548-549 */
+
+    float *du = plane_alloc(plane), *dv = plane_alloc(plane), *old_du = plane_alloc(plane), *old_dv = plane_alloc(plane);
+    float *sh = plane_alloc(plane), *sv = plane_alloc(plane), *uu = plane_alloc(plane), *vv = plane_alloc(plane);
+    float *a11 = plane_alloc(plane), *a12 = plane_alloc(plane), *a22 = plane_alloc(plane), *b1 = plane_alloc(plane), *b2 = plane_alloc(plane);
+    float *occ = plane_alloc(plane), *dpsis = plane_alloc(plane);
+    float *w_s = plane_alloc(cimg), *w_sp1 = plane_alloc(cimg);
+    float *mask = plane_alloc(nslots * plane);
+    float *succ = plane_alloc(nslots * stack), *toref = plane_alloc(nslots * stack);
+
+    if (p->one_direction || p->occlusion_reasoning)                              /* :219-220 */
+        for (size_t i = 0; i < plane; i++) occ[i] = -1.0f;
+
+    float data_norm = 0;                                                        /* :223-226 */
+    for (int s = 0; s < ref; s++) data_norm += p->rho[s] + p->omega[s];
+
+    orc_dpsis_weight(dpsis, frames[ref], w, h, stride, 5.0f, p->norm_avg, p->norm_std, p->hbit);   /* :257 */
+
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uu[(size_t)y * stride + x] = wx[(size_t)y * stride + x];            /* :260-261 */
+            vv[(size_t)y * stride + x] = wy[(size_t)y * stride + x];
+        }
+
+    float chg_x = 0, chg_y = 0;
+    int rc = 0;
+    for (int alter = 0; alter < p->niter_alter && !rc; alter++) {
+        int need_derivs = 1;                                                    /* :266 */
+        /* alter > 0 with occlusion reasoning would call optimizeOcc (GCO, :269-273): not part of the
+         * oracle; occ keeps its initial value */
+        for (int outer = 0; outer < p->niter_outer; outer++) {
+            if (outer > 0) need_derivs = 1;                                     /* :289-290 */
+            if (need_derivs) {
+                /* get_derivatives, variational_mt.cpp:87-166 */
+                for (int s = p->one_direction ? ref : 0; s < nslots; s++) {
+                    if (s < ref) {
+                        orc_image_warp(w_s, mask + s * plane, frames[s], wx, wy, w, h, stride, s - ref);
+                        orc_image_warp(w_sp1, NULL, frames[s + 1], wx, wy, w, h, stride, s - ref + 1);
+                    } else {
+                        orc_image_warp(w_s, NULL, frames[s], wx, wy, w, h, stride, s - ref);
+                        orc_image_warp(w_sp1, mask + s * plane, frames[s + 1], wx, wy, w, h, stride, s - ref + 1);
+                    }
+                    orc_derivative_stack(succ + s * stack, w_s, w_sp1, w, h, stride);
+                    if (s < ref) orc_derivative_stack(toref + s * stack, w_s, frames[ref], w, h, stride);      /* :139-141 */
+                    else         orc_derivative_stack(toref + s * stack, frames[ref], w_sp1, w, h, stride);    /* :143-144 */
+                }
+                need_derivs = 0;
+            }
+            /* mask weighting :293-320 */
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    const size_t o = (size_t)y * stride + x;
+                    float factor = (occ[o] == 0.0f) ? 1.0f : 0.0f;
+                    factor = (1 + factor) * data_norm;
+                    const float backward = ((occ[o] >= 0.0f) ? 1.0f : 0.0f) / factor;
+                    const float forward = ((occ[o] <= 0.0f) ? 1.0f : 0.0f) / factor;
+                    for (int s = p->one_direction ? ref : 0; s < nslots; s++) {
+                        float *m = mask + s * plane + o;
+                        if (s < ref) *m = 1.0f * backward * (*m);
+                        else         *m = 1.0f * forward * (*m);
+                    }
+                }
+            memset(du, 0, plane * sizeof(float));
+            memset(dv, 0, plane * sizeof(float));
+
+            for (int inner = 0; inner < p->niter_inner; inner++) {
+                memcpy(old_du, du, plane * sizeof(float));
+                memcpy(old_dv, dv, plane * sizeof(float));
+                orc_smoothness(p->smoothing, sh, sv, uu, vv, dpsis, w, h, stride, p->alpha, &p->robust_reg);   /* :333 */
+                memset(a11, 0, plane * sizeof(float)); memset(a12, 0, plane * sizeof(float)); memset(a22, 0, plane * sizeof(float));
+                memset(b1, 0, plane * sizeof(float)); memset(b2, 0, plane * sizeof(float));
+                for (int s = 0; s < ref && !rc; s++) {                           /* :343-361 */
+                    if (!p->one_direction) {
+                        if (p->rho[ref - 1 - s] > 0)
+                            orc_add_data_and_match(a11, a12, a22, b1, b2, mask + s * plane, du, dv, succ + s * stack, chw, w, h, stride,
+                                                   p->rho[ref - 1 - s] * delta_over3, p->rho[ref - 1 - s] * gamma_over3, (float)(s - ref),
+                                                   p->dataterm_norm, &p->robust_color, &p->robust_grad);
+                        if (p->omega[ref - 1 - s] > 0)
+                            rc = orc_add_data_and_match_ref(a11, a12, a22, b1, b2, mask + s * plane, du, dv, toref + s * stack, chw, w, h, stride,
+                                                            p->omega[ref - 1 - s] * delta_over3, p->omega[ref - 1 - s] * gamma_over3, (float)(s - ref),
+                                                            p->dataterm_norm, &p->robust_color, &p->robust_grad);
+                    }
+                    if (p->rho[s] > 0)
+                        orc_add_data_and_match(a11, a12, a22, b1, b2, mask + (ref + s) * plane, du, dv, succ + (ref + s) * stack, chw, w, h, stride,
+                                               p->rho[s] * delta_over3, p->rho[s] * gamma_over3, (float)s,
+                                               p->dataterm_norm, &p->robust_color, &p->robust_grad);
+                    if (p->omega[s] > 0 && !rc)
+                        rc = orc_add_data_and_match_ref(a11, a12, a22, b1, b2, mask + (ref + s) * plane, du, dv, toref + (ref + s) * stack, chw, w, h, stride,
+                                                        p->omega[s] * delta_over3, p->omega[s] * gamma_over3, (float)(s + 1),
+                                                        p->dataterm_norm, &p->robust_color, &p->robust_grad);
+                }
+                if (rc) break;
+                orc_sub_laplacian(b1, uu, sh, sv, w, h, stride);                /* :364-365 */
+                orc_sub_laplacian(b2, vv, sh, sv, w, h, stride);
+                orc_sor_coupled(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, stride, p->niter_solver, p->sor_omega);   /* :368 */
+
+                /* :371-402: padding lanes of du,dv are zeroed; the L1 change norms are fp32 running sums
+                 * in raster order, four lanes of a block added left to right first.  The oracle sums the
+                 * valid pixels in that order (padding lanes contribute +0 there). */
+                float avg_du = 0, avg_dv = 0;
+                for (int y = 0; y < h; y++) {
+                    for (int xb = 0; xb < stride; xb += 4) {
+                        float d[4], e[4];
+                        for (int q = 0; q < 4; q++) {
+                            const int x = xb + q;
+                            const size_t o = (size_t)y * stride + x;
+                            if (x < w) {
+                                d[q] = fabsf(old_du[o] - du[o]);
+                                e[q] = fabsf(old_dv[o] - dv[o]);
+                                uu[o] = wx[o] + du[o];                          /* :396-397 */
+                                vv[o] = wy[o] + dv[o];
+                            } else { d[q] = 0; e[q] = 0; du[o] = 0; dv[o] = 0; }
+                        }
+                        avg_du += d[0] + d[1] + d[2] + d[3];
+                        avg_dv += e[0] + e[1] + e[2] + e[3];
+                    }
+                }
+                avg_du /= (h * w);
+                avg_dv /= (h * w);
+                if ((avg_du > avg_dv ? avg_du : avg_dv) < p->thres_inner) break;   /* :407 */
+            }
+            if (rc) break;
+            float avg_wx = 0, avg_wy = 0;                                       /* :412-425 */
+            for (int y = 0; y < h; y++)
+                for (int xb = 0; xb < stride; xb += 4) {
+                    float d[4], e[4];
+                    for (int q = 0; q < 4; q++) {
+                        const int x = xb + q;
+                        const size_t o = (size_t)y * stride + x;
+                        if (x < w) { d[q] = fabsf(uu[o] - wx[o]); e[q] = fabsf(vv[o] - wy[o]); }
+                        else { d[q] = 0; e[q] = 0; }
+                    }
+                    avg_wx += d[0] + d[1] + d[2] + d[3];
+                    avg_wy += e[0] + e[1] + e[2] + e[3];
+                }
+            avg_wx /= (h * w);
+            avg_wy /= (h * w);
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    wx[(size_t)y * stride + x] = uu[(size_t)y * stride + x];    /* :428-429 */
+                    wy[(size_t)y * stride + x] = vv[(size_t)y * stride + x];
+                }
+            chg_x = avg_wx; chg_y = avg_wy;
+            if ((avg_wx > avg_wy ? avg_wx : avg_wy) < p->thres_outer) break;    /* :436 */
+        }
+    }
+    if (change) { change[0] = chg_x; change[1] = chg_y; }
+    if (occ_out) memcpy(occ_out, occ, plane * sizeof(float));
+    free(du); free(dv); free(old_du); free(old_dv); free(sh); free(sv); free(uu); free(vv);
+    free(a11); free(a12); free(a22); free(b1); free(b2); free(occ); free(dpsis);
+    free(w_s); free(w_sp1); free(mask); free(succ); free(toref);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * OpenCV-defined arithmetic of the pyramid (variational_mt.cpp:607,611,672-673,711-712).
+ * OpenCV is not vendored and absent: restated from its documented semantics.  UNPINNED.
+ * ---------------------------------------------------------------------------------------- */
+
+/* cv::GaussianBlur(src, dst, Size(0,0), sigma, sigma, BORDER_REPLICATE) on CV_32F:
+ * ksize = cvRound(sigma*4*2+1)|1; kernel = getGaussianKernel(ksize, sigma, CV_32F): fp32 taps
+ * exp(-x^2/(2 sigma^2)) (computed in double, stored float) normalised by the double reciprocal of
+ * their float sum; separable, rows then columns, symmetric form k0*c + sum_j kj*(l_j + r_j) in fp32 */
+void orc_gaussian_blur_cv(float *dst, const float *src, int w, int h, int stride, float sigma) {
+    int ksize = ((int)lrint((double)sigma * 4 * 2 + 1)) | 1;
+    const int r = ksize / 2;
+    float *k = (float *)malloc(sizeof(float) * ksize);
+    const double sigmaX = sigma, scale2X = -0.5 / (sigmaX * sigmaX);
+    double sum = 0;
+    for (int i = 0; i < ksize; i++) {
+        const double x = i - (ksize - 1) * 0.5;
+        k[i] = (float)exp(scale2X * x * x);
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < ksize; i++) k[i] = (float)(k[i] * sum);
+    float *tmp = plane_alloc((size_t)stride * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float *s = src + (size_t)y * stride;
+            float acc = k[r] * s[x];
+            for (int j = 1; j <= r; j++)
+                acc += k[r + j] * (s[clampi(x - j, 0, w - 1)] + s[clampi(x + j, 0, w - 1)]);
+            tmp[(size_t)y * stride + x] = acc;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float acc = k[r] * tmp[(size_t)y * stride + x];
+            for (int j = 1; j <= r; j++)
+                acc += k[r + j] * (tmp[(size_t)clampi(y - j, 0, h - 1) * stride + x] + tmp[(size_t)clampi(y + j, 0, h - 1) * stride + x]);
+            dst[(size_t)y * stride + x] = acc;
+        }
+    free(tmp); free(k);
+}
+
+/* cv::resize(..., INTER_LINEAR) on CV_32F: fx = (float)((dx+0.5)*(sw/dw) - 0.5); sx = floor(fx);
+ * fx -= sx; sx<0 -> (0, fx=0); sx>=sw-1 -> (sw-1, fx=0); horizontal pass on the two source rows
+ * S[sx]*(1-fx) + S[sx+1]*fx, then vertical R0*(1-fy) + R1*fy, all fp32 */
+void orc_resize_linear_cv(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride) {
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int *xofs = (int *)malloc(sizeof(int) * dw);
+    float *xa = (float *)malloc(sizeof(float) * dw);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx; xa[dx] = fx;
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        const float *r0 = src + (size_t)sy * sstride;
+        const float *r1 = src + (size_t)(sy + 1 < sh ? sy + 1 : sy) * sstride;
+        const float b0 = 1.f - fy, b1 = fy;
+        for (int dx = 0; dx < dw; dx++) {
+            const int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sx;
+            const float a0 = 1.f - xa[dx], a1 = xa[dx];
+            const float h0 = r0[sx] * a0 + r0[sx1] * a1;
+            const float h1 = r1[sx] * a0 + r1[sx1] * a1;
+            dst[(size_t)dy * dstride + dx] = h0 * b0 + h1 * b1;
+        }
+    }
+    free(xofs); free(xa);
+}
+
+/* image.c:310-322 order of the presmoothing filter (only its order is used, for the size break) */
+static int gaussian_filter_order(float sigma) {
+    int order = (int)floor(3 * sigma) + 1;
+    if (order == 0) order = 1;
+    return order;
+}
+
+/* variational_mt.cpp:583-652: sizes floor((float)w*p) with the product rounded to fp32; levels stop
+ * growing when the next one would be <= order+1 in either dimension.  returns the level count */
+int orc_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs) {
+    const float sigma = 1 / sqrtf(2 * p_scale);                                  /* :578 (C++: float sqrt overload) */
+    const int order = gaussian_filter_order(sigma);
+    int L = layers;
+    for (int l = 0; l < layers; l++) {
+        if (l == 0) { ws[0] = w; hs[0] = h; }
+        else {
+            ws[l] = (int)(float)floor(ws[l - 1] * p_scale);                      /* :609-611 */
+            hs[l] = (int)(float)floor(hs[l - 1] * p_scale);
+        }
+        if (floor(ws[l] * p_scale) <= order + 1 || floor(hs[l] * p_scale) <= order + 1) {   /* :647 */
+            L = l;
+            break;
+        }
+    }
+    return L;
+}
+
+static int stride_of(int w) { return ((w + 3) / 4) * 4; }                      /* image.c:25 */
+
+/* image.c:310-348 + :351-361 + generic convolve_horiz/vert :537-644 -- the optional Gaussian
+ * presmoothing of level 0 (cfg sigma > 0, variational_mt.cpp:590-597) */
+static void gaussian_presmooth(float *dst, const float *src, int w, int h, int stride, float sigma) {
+    const int order = gaussian_filter_order(sigma);
+    const int n = 2 * order + 1;
+    float *data = (float *)malloc(sizeof(float) * n), *coeffs = (float *)malloc(sizeof(float) * n), *accu = (float *)malloc(sizeof(float) * n);
+    const float alpha = 1.0f / (2.0f * sigma * sigma);
+    float sum = 0.0f;
+    for (int i = -order; i <= order; i++) { data[i + order] = (float)exp(-i * i * alpha); sum += data[i + order]; }
+    for (int i = 0; i < n; i++) data[i] /= sum;
+    const float *half = data + order;
+    for (int i = 0; i <= order; i++) coeffs[order - i] = coeffs[order + i] = half[i];
+    float acc = 0.0f;
+    for (int i = 0; i <= order; i++) { acc += coeffs[i]; accu[2 * order - i] = accu[i] = acc; }
+    const float *coeff = coeffs + order, *coeff_accu = accu + order;
+    const int i0 = -order, i1 = order;
+    float *tmp = plane_alloc((size_t)stride * h);
+    /* horizontal, image.c:545-578 */
+    for (int j = 0; j < h; j++) {
+        const float *al = src + (size_t)j * stride;
+        float *o = tmp + (size_t)j * stride;
+        const float *f0 = coeff + i0;
+        int i;
+        for (i = 0; i < -i0; i++) {
+            float s = coeff_accu[-i - 1] * al[0];
+            for (int ii = i1 + i; ii >= 0; ii--) s += coeff[ii - i] * al[ii];
+            *o++ = s;
+        }
+        for (; i < w - i1; i++) {
+            float s = 0;
+            for (int ii = i1 - i0; ii >= 0; ii--) s += f0[ii] * al[ii];
+            al++;
+            *o++ = s;
+        }
+        for (; i < w; i++) {
+            float s = coeff_accu[w - i] * al[w - i0 - 1 - i];
+            for (int ii = w - i0 - 1 - i; ii >= 0; ii--) s += f0[ii] * al[ii];
+            al++;
+            *o++ = s;
+        }
+    }
+    /* vertical, image.c:597-644 */
+    {
+        const float *in = tmp;
+        const float *alast = in + (size_t)stride * (h - 1);
+        const float *f0 = coeff + i0;
+        int i;
+        for (i = 0; i < -i0; i++) {
+            const float fa = coeff_accu[-i - 1];
+            const float *al = in + (size_t)i * stride;
+            for (int j = 0; j < w; j++) {
+                float s = fa * in[j];
+                for (int ii = -i; ii <= i1; ii++) s += coeff[ii] * al[j + ii * stride];
+                dst[(size_t)i * stride + j] = s;
+            }
+        }
+        for (; i < h - i1; i++) {
+            const float *al = in + (size_t)(i + i0) * stride;
+            for (int j = 0; j < w; j++) {
+                float s = 0;
+                const float *al2 = al + j;
+                for (int ii = 0; ii <= i1 - i0; ii++) { s += f0[ii] * al2[0]; al2 += stride; }
+                dst[(size_t)i * stride + j] = s;
+            }
+        }
+        for (; i < h; i++) {
+            const float fa = coeff_accu[h - i];
+            const float *al = in + (size_t)i * stride;
+            for (int j = 0; j < w; j++) {
+                float s = fa * alast[j];
+                for (int ii = i0; ii <= h - 1 - i; ii++) s += coeff[ii] * al[j + ii * stride];
+                dst[(size_t)i * stride + j] = s;
+            }
+        }
+    }
+    free(tmp); free(data); free(coeffs); free(accu);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * variational_mt.cpp:526-784 -- coarse-to-fine driver
+ * ---------------------------------------------------------------------------------------- */
+int orc_variational(const orc_params *p, float *wx, float *wy, float *const *frames, const float *const chw_in[3],
+                    int w, int h, int stride, float change[2]) {
+    const int ref = p->S - 1, F = 2 * ref + 1;
+    if (ref < 1 || ref > ORC_MAX_REF || p->layers < 1 || p->layers > 64) return -2;
+    int ws[64], hs[64];
+    const int L = orc_pyramid_sizes(w, h, p->layers, p->p_scale, ws, hs);
+    /* when the size break fires at level l the reference sets L = l: level l itself was built but is
+     * not used (:647-651); the oracle does not build it */
+    const int nbuilt = L;
+    const float sigma = 1 / sqrtf(2 * p->p_scale);
+
+    float *ones = NULL;
+    const float *chw[3];
+    if (chw_in) { chw[0] = chw_in[0]; chw[1] = chw_in[1]; chw[2] = chw_in[2]; }
+    else {
+        ones = plane_alloc((size_t)stride * h);
+        for (size_t i = 0; i < (size_t)stride * h; i++) ones[i] = 1.0f;
+        chw[0] = chw[1] = chw[2] = ones;
+    }
+
+    float ***pyr = (float ***)calloc(nbuilt, sizeof(float **));
+    for (int l = 0; l < nbuilt; l++) {
+        pyr[l] = (float **)calloc(F, sizeof(float *));
+        const int lw = ws[l], lh = hs[l], ls = stride_of(lw);
+        const size_t lplane = (size_t)(l == 0 ? stride : ls) * lh;
+        for (int s = 0; s < F; s++) {
+            pyr[l][s] = plane_alloc(3 * lplane);
+            if (l == 0) {
+                if (p->presmooth_sigma > 0) {
+                    for (int k = 0; k < 3; k++) gaussian_presmooth(pyr[0][s] + k * lplane, frames[s] + k * lplane, w, h, stride, p->presmooth_sigma);
+                } else memcpy(pyr[0][s], frames[s], 3 * lplane * sizeof(float));       /* :599 */
+            } else {
+                const int pw = ws[l - 1], ph = hs[l - 1], ps = l - 1 == 0 ? stride : stride_of(pw);
+                const size_t pplane = (size_t)ps * ph;
+                float *blur = plane_alloc(pplane);
+                for (int k = 0; k < 3; k++) {
+                    orc_gaussian_blur_cv(blur, pyr[l - 1][s] + k * pplane, pw, ph, ps, sigma);   /* :607 */
+                    orc_resize_linear_cv(pyr[l][s] + k * lplane, lw, lh, ls, blur, pw, ph, ps);  /* :611 */
+                }
+                free(blur);
+            }
+        }
+    }
+
+    float *wxl = wx, *wyl = wy;
+    int cw = w, ch = h, cs = stride;
+    if (L > 1) {                                                                /* :662-681 */
+        const int lw = ws[L - 1], lh = hs[L - 1], ls = stride_of(lw);
+        const float fx = (1.0f * lw) / w, fy = (1.0f * lh) / h;
+        wxl = plane_alloc((size_t)ls * lh); wyl = plane_alloc((size_t)ls * lh);
+        orc_resize_linear_cv(wxl, lw, lh, ls, wx, w, h, stride);
+        orc_resize_linear_cv(wyl, lw, lh, ls, wy, w, h, stride);
+        for (int y = 0; y < lh; y++) for (int x = 0; x < lw; x++) { wxl[(size_t)y * ls + x] *= fx; wyl[(size_t)y * ls + x] *= fy; }
+        cw = lw; ch = lh; cs = ls;
+    }
+    int rc = 0;
+    float chg[2] = {0, 0};
+    for (int l = L - 1; l >= 0 && !rc; l--) {
+        const int lw = ws[l], lh = hs[l], ls = l == 0 ? stride : stride_of(lw);
+        if (l < L - 1) {                                                        /* :689-723 */
+            float *tx = l > 0 ? plane_alloc((size_t)ls * lh) : wx;
+            float *ty = l > 0 ? plane_alloc((size_t)ls * lh) : wy;
+            const float fx = (1.0f * lw) / cw, fy = (1.0f * lh) / ch;
+            orc_resize_linear_cv(tx, lw, lh, ls, wxl, cw, ch, cs);
+            orc_resize_linear_cv(ty, lw, lh, ls, wyl, cw, ch, cs);
+            for (int y = 0; y < lh; y++) for (int x = 0; x < lw; x++) { tx[(size_t)y * ls + x] *= fx; ty[(size_t)y * ls + x] *= fy; }
+            free(wxl); free(wyl);
+            wxl = tx; wyl = ty; cw = lw; ch = lh; cs = ls;
+        }
+        rc = orc_compute_one_level(p, wxl, wyl, pyr[l], chw, NULL, lw, lh, ls, chg);   /* :761 */
+    }
+    if (L > 1 && rc && wxl != wx) { free(wxl); free(wyl); }
+    if (L == 0) rc = -3;
+    if (change) { change[0] = chg[0]; change[1] = chg[1]; }
+    for (int l = 0; l < nbuilt; l++) { for (int s = 0; s < F; s++) free(pyr[l][s]); free(pyr[l]); }
+    free(pyr); free(ones);
+    return rc;
+}

@@ -1,0 +1,140 @@
+/*
+ * slowflow_oracle.h -- CPU restatement of the slowflow variational-refinement hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (slowflow_amd/, include/) may include,
+ * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * use it, and only as the checker.
+ *
+ * Plain scalar C, strict IEEE fp32 (build with -ffp-contract=off, no fast-math), every
+ * function written from the equations of the reference and citing the reference file:line
+ * it follows (paths relative to the reference root).  All planes are planar fp32,
+ * row-major, explicit (w, h, stride); only the w valid columns of a row are defined on
+ * output -- padding lanes (stride - w) are never read as meaningful and written as 0 or
+ * left untouched.
+ *
+ * Pin status (see oracle/README.md and tests/test_oracle_pin.py):
+ *   bit-exact against the compiled reference (oracle/_ref, built from the reference's own
+ *   solver.c / image.c / variational_aux.c / penalty_functions headers):
+ *     orc_sor_coupled, orc_convolve_{horiz,vert} (3/5-tap), orc_image_warp,
+ *     orc_sub_laplacian, orc_dpsis_weight (output 0), orc_derivative_stack,
+ *     orc_psi_deriv_{scalar,vec};
+ *   near-pinned (same operator in the reference's 2-frame variational_aux.c, different
+ *   rounding order, <= few ulp): orc_smoothness (method 1), orc_add_data_and_match
+ *   (normalised, ModL1);
+ *   PARITY UNPINNED (restated from the source text only; variational_aux_mt.cpp /
+ *   variational_mt.cpp need the absent GCO/OpenCV headers and cannot be built here):
+ *     orc_add_data_and_match_ref, the unnormalised data-term branches, smoothing
+ *     methods 0/2, orc_compute_one_level orchestration, orc_normalize, and the OpenCV
+ *     defined pyramid arithmetic (orc_gaussian_blur_cv, orc_resize_linear_cv).
+ */
+#ifndef SLOWFLOW_ORACLE_H
+#define SLOWFLOW_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_REF 4
+
+typedef struct {
+    int id;        /* 0 quadratic, 2 lorentzian, 3 trunc mod-L1, 4 geman-mcclure, else mod-L1 */
+    float eps;
+    float trunc;
+} orc_penalty;
+
+/* mirrors the cfg keys read by variational_mt.cpp:173-192, 533-568 */
+typedef struct {
+    int   S;                  /* slow_flow_S; ref = S-1; frames = 2*ref+1 */
+    int   one_direction;      /* slow_flow_method == "forward" */
+    int   smoothing;          /* slow_flow_smoothing */
+    int   dataterm_norm;      /* slow_flow_dataterm */
+    int   niter_alter, niter_outer, niter_inner, niter_solver;
+    float thres_outer, thres_inner;
+    float sor_omega;
+    float alpha, gamma, delta;
+    orc_penalty robust_color, robust_grad, robust_reg;
+    float rho[ORC_MAX_REF], omega[ORC_MAX_REF];
+    int   hbit;               /* 16bit */
+    float norm_avg[3], norm_std[3];
+    int   occlusion_reasoning;
+    int   layers;             /* slow_flow_layers */
+    float p_scale;            /* slow_flow_p_scale */
+    float presmooth_sigma;    /* >0: cfg sigma>0, value of slow_flow_sigma */
+} orc_params;
+
+void orc_params_default(orc_params *p);
+
+/* penalty_functions headers: psi'(x^2).  scalar overload = double inside, vec = pure fp32 */
+float orc_psi_deriv_scalar(const orc_penalty *pen, float xsq);
+float orc_psi_deriv_vec(const orc_penalty *pen, float xsq);
+
+/* image.c:400-526: 3-tap (order 1) / 5-tap (order 2) antisymmetric derivative filters.
+ * order==2: c = [1/12,-8/12,-0,8/12,-1/12]; order==1: c = [-.5,-0,.5] */
+void orc_convolve_horiz(float *dst, const float *src, int w, int h, int stride, int order);
+void orc_convolve_vert(float *dst, const float *src, int w, int h, int stride, int order);
+
+/* variational_aux_mt.cpp:722-756.  src/dst: 3 planes of h*stride each; mask may be NULL */
+void orc_image_warp(float *dst3, float *mask, const float *src3, const float *wx, const float *wy,
+                    int w, int h, int stride, int factor);
+
+/* variational_mt.cpp:113-133: from I1 (=im1p) and I2 (=im2p) colour images compute
+ * Iz = I1-I2, M = .5*(I2+I1), Ix,Iy = D5(M), Ixx,Ixy = D5(Ix), Iyy = D5y(Iy), Ixz,Iyz = D5(Iz).
+ * every output = 3 planes.  order: Ix,Iy,Iz,Ixx,Ixy,Iyy,Ixz,Iyz (each 3*h*stride floats) */
+void orc_derivative_stack(float *out8x3, const float *I1, const float *I2, int w, int h, int stride);
+
+/* variational_aux_mt.cpp:673-719 (first output only; the two others are unused downstream) */
+void orc_dpsis_weight(float *dst, const float *im3, int w, int h, int stride, float coef,
+                      const float avg[3], const float std[3], int hbit);
+
+/* variational_aux_mt.cpp:18-127 */
+void orc_smoothness(int method, float *dst_horiz, float *dst_vert, const float *uu, const float *vv,
+                    const float *dpsis, int w, int h, int stride, float alpha, const orc_penalty *reg);
+
+/* variational_aux_mt.cpp:130-161 */
+void orc_sub_laplacian(float *dst, const float *src, const float *wh, const float *wv, int w, int h, int stride);
+
+/* variational_aux_mt.cpp:166-403 / 408-634.  D = 8 colour images (order as orc_derivative_stack);
+ * chw[k] = channel-weight plane k, indexed with THIS level's y*stride+x (the reference walks the
+ * level-0 weight planes linearly at every level, variational_aux_mt.cpp:177,366-371).
+ * _ref returns -1 for the logic_error of :419 */
+void orc_add_data_and_match(float *a11, float *a12, float *a22, float *b1, float *b2, const float *mask,
+                            const float *du, const float *dv, const float *D8x3, const float *const chw[3],
+                            int w, int h, int stride, float delta_over3, float gamma_over3, float s,
+                            int dt_norm, const orc_penalty *color, const orc_penalty *grad);
+int orc_add_data_and_match_ref(float *a11, float *a12, float *a22, float *b1, float *b2, const float *mask,
+                               const float *du, const float *dv, const float *D8x3, const float *const chw[3],
+                               int w, int h, int stride, float delta_over3, float gamma_over3, float s,
+                               int dt_norm, const orc_penalty *color, const orc_penalty *grad);
+
+/* solver.c:63-399 (fast solver arithmetic, raster order; a11/a12/a22 are overwritten by the
+ * inverted 2x2 blocks) and solver.c:17-57 (readable) */
+void orc_sor_coupled(float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
+                     const float *sh, const float *sv, int w, int h, int stride, int iterations, float omega);
+void orc_sor_coupled_readable(float *du, float *dv, const float *a11, const float *a12, const float *a22,
+                              const float *b1, const float *b2, const float *sh, const float *sv,
+                              int w, int h, int stride, int iterations, float omega);
+
+/* variational_mt.cpp:17-85.  frames[f] = 3 planes.  writes avg/std (double->6 significant
+ * digits->float round trip of :71-84,250-251 is applied by orc_normalize_publish) */
+void orc_normalize(float **frames, int F, int w, int h, int stride, double avg[3], double std[3]);
+void orc_normalize_publish(const double avg[3], const double std[3], float avg_f[3], float std_f[3]);
+
+/* variational_mt.cpp:169-493.  frames: 2*ref+1 colour images of this level; wx,wy in/out;
+ * chw[3]: channel weight planes; occ: out occlusion plane (h*stride) or NULL; change[2] out */
+int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *const *frames,
+                          const float *const chw[3], float *occ, int w, int h, int stride, float change[2]);
+
+/* OpenCV-defined pyramid arithmetic, restated from the documented semantics (UNPINNED) */
+void orc_gaussian_blur_cv(float *dst, const float *src, int w, int h, int stride, float sigma);
+void orc_resize_linear_cv(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride);
+int  orc_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs);
+
+/* variational_mt.cpp:526-784 (chw == NULL: all ones, :534-539; as in the reference the level-0
+ * weight planes are NOT rescaled per level) */
+int orc_variational(const orc_params *p, float *wx, float *wy, float *const *frames, const float *const chw[3],
+                    int w, int h, int stride, float change[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as orc
+    return orc.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reflib():
+    import oracle as orc
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref/libslowflow_ref.so not built (needs /root/reference)")
+    return orc.RefLib()
