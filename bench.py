@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the variational-refinement hot path on MI355X.
+
+Metric (BASELINE.json): Mpix*solver-iters/s at 1024x436, with the SOR kernel's achieved algorithmic GB/s against
+the HBM peak.  A *step* = one complete coarse-to-fine refinement (sfa_job_run: pyramid, per-level warps, derivative
+stacks, data-term assembly, SOR solves, flow updates) of one resident batch of synthetic frame windows -- BASELINE
+config 2: 1024x436, S=2 (3 frames), 5 pyramid levels, 5 outer x 1 inner x 30 SOR sweeps per level.  Inputs are
+uploaded to HBM before the timed region.  value = (sum over all ranks and SOR solves of w*h*K) / wall time / 1e6.
+
+  python bench.py --gpus N --steps K --warmup W [--batch B]
+N > 1 is launched by torch.distributed.run (one rank per GPU over RCCL); frame windows shard across ranks with no
+data-path collective (weak scaling); the only exchange is a gather of per-rank timings.
+
+The JSON line also carries `roofline` (SOR solve kernel: algorithmic bytes / HIP-event duration over the timed
+region) and, on rank 0 at N=1, `cpu_baseline` (the reference's own sor_coupled from oracle/_ref, or the oracle port,
+timed on one host core over a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import slowflow_amd as sfa  # noqa: E402
+
+W, H, LAYERS, OUTER, INNER, SWEEPS, S = 1024, 436, 5, 5, 1, 30, 2
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def synth_window(seed, w=W, h=H, n=3):
+    """Config-2 stand-in: seeded band-limited noise texture moved by a smooth flow field of at most
+    3 px per frame, 8-bit quantised; returns n (3,h,stride) fp32 frames."""
+    rng = np.random.default_rng(seed)
+    stride = sfa.stride_of(w)
+    pad = 16
+    base = rng.uniform(0, 1, size=(3, h + 2 * pad, w + 2 * pad))
+    k = np.exp(-0.5 * (np.arange(-6, 7) / 2.0) ** 2)
+    k /= k.sum()
+    for ax in (1, 2):
+        base = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, base)
+    base = (base - base.min()) / (base.max() - base.min()) * 255.0
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    fu = 2.0 + 1.0 * np.sin(2 * np.pi * yy / h)          # |flow| <= 3 px
+    fv = 1.0 * np.cos(2 * np.pi * xx / w)
+    frames = []
+    for t in range(n):
+        sx, sy = xx - t * fu + pad, yy - t * fv + pad
+        x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+        ax, ay = sx - x0, sy - y0
+        f = np.zeros((3, h, stride), np.float32)
+        for c in range(3):
+            b = base[c]
+            v = (b[y0, x0] * (1 - ax) * (1 - ay) + b[y0, x0 + 1] * ax * (1 - ay) + b[y0 + 1, x0] * (1 - ax) * ay + b[y0 + 1, x0 + 1] * ax * ay)
+            f[c, :, :w] = np.round(v).astype(np.float32)
+        frames.append(f)
+    return frames
+
+
+def bench_params():
+    p = sfa.default_params()
+    p.S = S; p.layers = LAYERS; p.niter_alter = 1; p.niter_outer = OUTER; p.niter_inner = INNER; p.niter_solver = SWEEPS
+    p.thres_outer = 0; p.thres_inner = 0            # fixed work: exactly OUTER x SWEEPS per level
+    p.occlusion_reasoning = 0; p.hbit = 0
+    p.rho[0] = 1; p.omega[0] = 0
+    return p
+
+
+def cpu_baseline(budget_s=12.0):
+    """The reference's own sor_coupled (solver.c:63, compiled by oracle/Makefile into oracle/_ref) on ONE host core,
+    30 sweeps at 1024x436, repeated for about `budget_s` seconds.  Falls back to the oracle port."""
+    import oracle as orc
+    from synth import copy_sys, sor_system
+    rng = np.random.default_rng(0)
+    s0 = sor_system(rng, W, H)
+    if orc.ref_available():
+        lib, kind = orc.RefLib(), "reference"
+    else:
+        lib, kind = orc.Oracle(), "port"
+    n, t_total = 0, 0.0
+    while t_total < budget_s and n < 400:
+        s = copy_sys(s0)
+        t0 = time.perf_counter()
+        lib.sor(s["du"], s["dv"], s["a11"], s["a12"], s["a22"], s["b1"], s["b2"], s["sh"], s["sv"], W, SWEEPS, 1.9)
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {"value": round(n * W * H * SWEEPS / 1e6 / t_total, 2), "unit": "Mpix*solver-iters/s", "cores": 1, "kind": kind,
+            "sample": f"{n} sor_coupled calls, {SWEEPS} sweeps each, {W}x{H}, one thread ({t_total:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="frame windows per GPU solved in lockstep (fwd/bwd of several jets)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    ctx = sfa.Context(local_rank if world > 1 else 0)
+    p = bench_params()
+    B = args.batch
+    # one normalisation for the whole sequence, as the driver does (slow_flow.cpp:673)
+    windows = [synth_window(1000 * rank + b) for b in range(B)]
+    allf = [f for wdw in windows for f in wdw]
+    avg, std = ctx.normalize(allf, W)
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])     # 6-digit publish, variational_mt.cpp:71-84
+    job = sfa.Job(ctx, p, W, H, B)
+    for b in range(B):
+        job.upload(b, windows[b])
+    mpix_iters = job.mpix_iters()
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        job.run()
+    barrier()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.run()
+    ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_sor, sor_ms, sor_bytes = ctx.profile_read()
+    ctx.profile_enable(False)
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)                       # the per-rank timings: the only exchange of the path
+        elapsed_max = max(float(x.item()) for x in gathered)
+    else:
+        elapsed_max = elapsed
+
+    # SOR-only: the metric's own kernel at 1024x436, same batch, HIP events on the launch stream
+    from synth import sor_system
+    sb = sfa.SorBatch(ctx, W, H, B)
+    rng = np.random.default_rng(7 + rank)
+    for b in range(B):
+        s = sor_system(rng, W, H)
+        sb.upload(b, *[np.ascontiguousarray(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb.run(SWEEPS, 1.9); ctx.sync()
+    ctx.profile_enable(True)
+    reps = 20
+    for _ in range(reps):
+        sb.run(SWEEPS, 1.9)
+    n1, ms1, by1 = ctx.profile_read()
+    ctx.profile_enable(False)
+    # single-solve latency (batch of one)
+    sb1 = sfa.SorBatch(ctx, W, H, 1)
+    s = sor_system(rng, W, H)
+    sb1.upload(0, *[np.ascontiguousarray(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb1.run(SWEEPS, 1.9); ctx.sync()
+    ctx.profile_enable(True)
+    for _ in range(reps):
+        sb1.run(SWEEPS, 1.9)
+    n2, ms2, by2 = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    if rank == 0:
+        total = mpix_iters * args.steps * world
+        value = total / elapsed_max
+        achieved = sor_bytes / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
+        out = {
+            "metric": "Mpix*solver-iters/s at 1024x436 (whole coarse-to-fine path)", "value": round(value, 1), "unit": "Mpix*solver-iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 1024x436, S=2 (3 frames), 5 pyramid levels, 5 outer x 1 inner x 30 SOR sweeps, "
+                                   "symmetric window, modified-L1 penalties, thresholds off",
+                       "frame_windows_per_gpu": B, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
+                       "parallelism": f"frame-window data parallel x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_sor_solve", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
+                         "algorithmic_bytes_per_launch": round(sor_bytes / max(n_sor, 1)),
+                         "note": "over the timed region: sum of (44*K+12)*w*h*batch bytes of every SOR launch (all 5 levels) / sum of HIP-event durations",
+                         "sor_1024x436_batch": {"batch": B, "avg_launch_ms": round(ms1 / max(n1, 1), 4), "achieved": round(by1 / (ms1 * 1e-3) / 1e9, 1),
+                                                "frac": round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                "mpix_iters_per_s": round(W * H * SWEEPS * B * n1 / 1e6 / (ms1 * 1e-3), 1)},
+                         "sor_1024x436_single": {"batch": 1, "avg_launch_ms": round(ms2 / max(n2, 1), 4), "achieved": round(by2 / (ms2 * 1e-3) / 1e9, 1),
+                                                 "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}},
+            "sor_share_of_step": round(sor_ms / (elapsed * 1e3), 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    sb.close(); sb1.close(); job.close(); ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * slowflow_amd.h -- C-ABI of the MI355X-native (gfx950 HIP) implementation of slowflow's variational
+ * optical-flow refinement hot path.  Plain pointers and sizes only; every entry point names the
+ * reference interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions (identical to the reference, epic_flow_extended/image.h:17-43):
+ *   - planes are fp32, row-major, `stride` floats per row (stride >= width); a colour image is 3 planes
+ *     of height*stride floats each; only the `width` valid columns of a row are read or written,
+ *   - all pointers below are HOST pointers unless a function says "device-resident"; the library owns
+ *     every device buffer (through the context),
+ *   - functions return 0 (SFA_OK) or a negative sfa_status; they never exit() (the reference does:
+ *     image.c:19-30, solver.c:75-78); sfa_last_error() gives the message,
+ *   - a context is bound to one GPU and one HIP stream; it is thread-compatible, not thread-safe: use one
+ *     context per host thread (the reference runs one Variational_MT per OpenMP thread, slow_flow.cpp:706).
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with SFA_ERR_NO_DEVICE.
+ */
+#ifndef SLOWFLOW_AMD_H
+#define SLOWFLOW_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFA_VERSION 1
+#define SFA_MAX_REF 4          /* slow_flow_S - 1 <= 4 */
+
+typedef enum {
+    SFA_OK = 0,
+    SFA_ERR_ARG = -1,          /* bad argument (null pointer, size, unsupported S) */
+    SFA_ERR_HIP = -2,          /* a HIP runtime call failed */
+    SFA_ERR_NO_DEVICE = -3,    /* no usable GPU */
+    SFA_ERR_REF_FRAME = -4,    /* "Frame compared to reference frame is the reference frame itself" (variational_aux_mt.cpp:419) */
+    SFA_ERR_TIMEOUT = -5,      /* a bounded in-kernel wait gave up (solver pipeline) */
+    SFA_ERR_UNSUPPORTED = -6   /* a path that needs the absent third-party hook (occlusion graph cut) */
+} sfa_status;
+
+/* layout-compatible with image_t / color_image_t (epic_flow_extended/image.h:17-33) */
+typedef struct sfa_image { int width, height, stride; float *data; } sfa_image;
+typedef struct sfa_color_image { int width, height, stride; float *c1, *c2, *c3; } sfa_color_image;
+
+/* penalty ids as Variational_AUX_MT::select_robust_function (variational_aux_mt.cpp:909-925):
+ * 0 quadratic, 2 lorentzian, 3 truncated modified L1, 4 geman-mcclure, anything else modified L1 */
+typedef struct sfa_penalty { int id; float eps; float trunc; } sfa_penalty;
+
+/* the cfg keys Variational_MT reads (variational_mt.cpp:173-192, 533-568), already parsed */
+typedef struct sfa_params {
+    int   S;                    /* slow_flow_S */
+    int   one_direction;        /* slow_flow_method == "forward" */
+    int   smoothing;            /* slow_flow_smoothing */
+    int   dataterm_norm;        /* slow_flow_dataterm */
+    int   niter_alter, niter_outer, niter_inner, niter_solver;
+    float thres_outer, thres_inner;
+    float sor_omega;
+    float alpha, gamma, delta;
+    sfa_penalty robust_color, robust_grad, robust_reg;
+    float rho[SFA_MAX_REF], omega[SFA_MAX_REF];      /* slow_flow_rho_<a>, slow_flow_omega_<a> */
+    int   hbit;                 /* 16bit */
+    float norm_avg[3], norm_std[3];                  /* slow_flow_img_norm_{avg,std}_{1,2,3} */
+    int   occlusion_reasoning;  /* slow_flow_occlusion_reasoning */
+    int   layers;               /* slow_flow_layers */
+    float p_scale;              /* slow_flow_p_scale */
+    float presmooth_sigma;      /* > 0 when cfg `sigma` > 0: value of slow_flow_sigma */
+} sfa_params;
+
+typedef struct sfa_ctx sfa_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int  sfa_device_count(void);
+int  sfa_ctx_create(int device, sfa_ctx **out);
+void sfa_ctx_destroy(sfa_ctx *ctx);
+const char *sfa_last_error(const sfa_ctx *ctx);     /* ctx may be NULL: last error of the calling thread */
+int  sfa_ctx_sync(sfa_ctx *ctx);
+void sfa_params_default(sfa_params *p);             /* driver defaults, slow_flow.cpp:64-128 */
+
+/* ---- the path itself ---------------------------------------------------------------------------- */
+
+/* Replaces Variational_MT::variational (variational_mt.cpp:526-784): coarse-to-fine refinement of (wx,wy),
+ * in place.  frames[f] = first plane of colour frame f (3 consecutive planes), f = 0 .. 2*(S-1), reference
+ * frame in the middle; chw = channel weights (setChannelWeights, :521) or NULL for all ones;
+ * occlusions_out (h*stride floats) or NULL; change[2] = returned Point2f (mean |du|, mean |dv| of the last
+ * outer iteration of level 0). */
+int sfa_variational(sfa_ctx *ctx, const sfa_params *p, float *wx, float *wy, int w, int h, int stride,
+                    const float *const *frames, int n_frames, const float *const chw[3],
+                    float *occlusions_out, float change[2]);
+
+/* Replaces Variational_MT::compute_one_level (variational_mt.cpp:169-493): one pyramid level. */
+int sfa_compute_one_level(sfa_ctx *ctx, const sfa_params *p, float *wx, float *wy, int w, int h, int stride,
+                          const float *const *frames, int n_frames, const float *const chw[3],
+                          float *occlusions_out, float change[2]);
+
+/* Replaces normalize() (variational_mt.cpp:17-85): in-place (I-avg)/std over F colour frames; avg/std are the
+ * doubles the reference publishes as slow_flow_img_norm_* params. */
+int sfa_normalize(sfa_ctx *ctx, float *const *frames, int n_frames, int w, int h, int stride,
+                  double avg[3], double std_dev[3]);
+
+/* Replaces sor_coupled (solver.h:11, solver.c:63-399) on host planes: K lexicographic SOR sweeps, results
+ * numerically identical to the reference's raster order (hyperplane-pipelined on the GPU).  a11/a12/a22 are
+ * overwritten with the inverted 2x2 blocks exactly as the reference does. */
+int sfa_sor_coupled(sfa_ctx *ctx, sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, sfa_image *a22,
+                    sfa_image *b1, sfa_image *b2, sfa_image *dpsis_horiz, sfa_image *dpsis_vert,
+                    int iterations, float omega);
+/* the reference's own symbol and signature (solver.h:11); uses a process-wide default context on device 0 and
+ * aborts with a message if no GPU is usable (the reference's error style, solver.c:75-78) */
+void sor_coupled(sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, sfa_image *a22, sfa_image *b1,
+                 sfa_image *b2, sfa_image *dpsis_horiz, sfa_image *dpsis_vert, const int iterations, const float omega);
+
+/* ---- stage entry points (host planes; used by the parity tests and by partial integrations) ------ */
+
+/* Variational_AUX_MT::image_warp (variational_aux_mt.cpp:722-756); mask may be NULL */
+int sfa_image_warp(sfa_ctx *ctx, float *dst3, float *mask, const float *src3, const float *wx, const float *wy,
+                   int w, int h, int stride, int factor);
+/* one derivative stack of get_derivatives (variational_mt.cpp:113-133): out = Ix,Iy,Iz,Ixx,Ixy,Iyy,Ixz,Iyz,
+ * each a colour image (3*h*stride floats), from I1 (im1p) and I2 (im2p) */
+int sfa_derivative_stack(sfa_ctx *ctx, float *out8x3, const float *I1, const float *I2, int w, int h, int stride);
+/* convolve_horiz / convolve_vert with the path's derivative filters (image.c:400-526); order 1 or 2 */
+int sfa_convolve(sfa_ctx *ctx, float *dst, const float *src, int w, int h, int stride, int order, int horizontal);
+/* Variational_AUX_MT::compute_dpsis_weight, first output (variational_aux_mt.cpp:673-719) */
+int sfa_dpsis_weight(sfa_ctx *ctx, float *dst, const float *im3, int w, int h, int stride, float coef,
+                     const float avg[3], const float std_dev[3], int hbit);
+/* Variational_AUX_MT::compute_smoothness (variational_aux_mt.cpp:18-127) */
+int sfa_smoothness(sfa_ctx *ctx, int method, float *dst_horiz, float *dst_vert, const float *uu, const float *vv,
+                   const float *dpsis, int w, int h, int stride, float alpha, const sfa_penalty *reg);
+/* Variational_AUX_MT::sub_laplacian (variational_aux_mt.cpp:130-161): dst += div(w grad src) */
+int sfa_sub_laplacian(sfa_ctx *ctx, float *dst, const float *src, const float *wh, const float *wv, int w, int h, int stride);
+/* Variational_AUX_MT::add_data_and_match / add_data_and_match_ref (variational_aux_mt.cpp:166-403, 408-634):
+ * accumulate one data term into a11,a12,a22,b1,b2.  D8x3 as sfa_derivative_stack's output. */
+int sfa_add_data_and_match(sfa_ctx *ctx, float *a11, float *a12, float *a22, float *b1, float *b2, const float *mask,
+                           const float *du, const float *dv, const float *D8x3, const float *const chw[3],
+                           int w, int h, int stride, float delta_over3, float gamma_over3, float s, int ref_term,
+                           int dt_norm, const sfa_penalty *color, const sfa_penalty *grad);
+/* pyramid arithmetic (cv::GaussianBlur / cv::resize as used at variational_mt.cpp:607,611,672,711) */
+int sfa_gaussian_blur(sfa_ctx *ctx, float *dst, const float *src, int w, int h, int stride, float sigma);
+int sfa_resize_linear(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride);
+int sfa_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs);
+
+/* ---- device-resident batches (measurement and the multi-pair driver) ------------------------------
+ * A job = `batch` independent frame windows of identical size solved in lockstep by the same launches
+ * (forward + backward of a jet, several jets ...), all inputs resident in HBM. */
+typedef struct sfa_job sfa_job;
+int  sfa_job_create(sfa_ctx *ctx, const sfa_params *p, int w, int h, int batch, sfa_job **out);
+void sfa_job_destroy(sfa_job *job);
+/* frames / initial flow of batch element b (host -> HBM); chw NULL = ones */
+int  sfa_job_upload(sfa_job *job, int b, const float *const *frames, int n_frames, const float *wx, const float *wy,
+                    int stride, const float *const chw[3]);
+int  sfa_job_reset_flow(sfa_job *job);               /* re-arm every element with the uploaded initial flow */
+int  sfa_job_run(sfa_job *job);                      /* the whole coarse-to-fine path, asynchronous on the ctx stream */
+int  sfa_job_download(sfa_job *job, int b, float *wx, float *wy, int stride, float change[2]);
+double sfa_job_mpix_iters(const sfa_job *job);       /* sum over the job's SOR solves of w*h*K / 1e6, per run */
+
+/* SOR-only resident batch: `batch` independent systems of one size */
+typedef struct sfa_sor_batch sfa_sor_batch;
+int  sfa_sor_batch_create(sfa_ctx *ctx, int w, int h, int batch, sfa_sor_batch **out);
+void sfa_sor_batch_destroy(sfa_sor_batch *sb);
+int  sfa_sor_batch_upload(sfa_sor_batch *sb, int b, const float *du, const float *dv, const float *a11, const float *a12,
+                          const float *a22, const float *b1, const float *b2, const float *sh, const float *sv, int stride);
+int  sfa_sor_batch_run(sfa_sor_batch *sb, int iterations, float omega);   /* prepare + solve + finish, async */
+int  sfa_sor_batch_download(sfa_sor_batch *sb, int b, float *du, float *dv, int stride);
+
+/* ---- in-library kernel timing (HIP events on the context's stream) ---------------------------------
+ * While enabled every SOR solve kernel launch is bracketed by an event pair on the launch stream. */
+int  sfa_profile_enable(sfa_ctx *ctx, int on);
+int  sfa_profile_read(sfa_ctx *ctx, int *n_sor_launches, double *sor_ms_total, double *sor_bytes_total);
+/* wall bracket on the stream: start/stop an event pair around arbitrary enqueued work */
+int  sfa_timer_start(sfa_ctx *ctx);
+int  sfa_timer_stop(sfa_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,314 @@
+"""slowflow_amd -- Python binding (ctypes) of libslowflow_amd.so, the MI355X-native implementation of
+slowflow's variational optical-flow refinement path (include/slowflow_amd.h).
+
+This package is plumbing around the C-ABI for tests, bench.py and Python callers.  It contains no
+compute and no CPU fallback: if the HIP library is missing or no GPU is usable every call raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslowflow_amd.so")
+MAX_REF = 4
+
+_f = C.POINTER(C.c_float)
+
+
+class SlowflowError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise SlowflowError("building libslowflow_amd.so failed:\n" + out.stdout + out.stderr)
+    if verbose:
+        print(out.stdout)
+    return LIB_PATH
+
+
+class Penalty(C.Structure):
+    _fields_ = [("id", C.c_int), ("eps", C.c_float), ("trunc", C.c_float)]
+
+
+class Params(C.Structure):
+    """sfa_params: the cfg keys of the path (variational_mt.cpp:173-192, 533-568)."""
+    _fields_ = [
+        ("S", C.c_int), ("one_direction", C.c_int), ("smoothing", C.c_int), ("dataterm_norm", C.c_int),
+        ("niter_alter", C.c_int), ("niter_outer", C.c_int), ("niter_inner", C.c_int), ("niter_solver", C.c_int),
+        ("thres_outer", C.c_float), ("thres_inner", C.c_float), ("sor_omega", C.c_float),
+        ("alpha", C.c_float), ("gamma", C.c_float), ("delta", C.c_float),
+        ("robust_color", Penalty), ("robust_grad", Penalty), ("robust_reg", Penalty),
+        ("rho", C.c_float * MAX_REF), ("omega", C.c_float * MAX_REF),
+        ("hbit", C.c_int), ("norm_avg", C.c_float * 3), ("norm_std", C.c_float * 3),
+        ("occlusion_reasoning", C.c_int), ("layers", C.c_int), ("p_scale", C.c_float), ("presmooth_sigma", C.c_float),
+    ]
+
+
+class Image(C.Structure):
+    """sfa_image == image_t (epic_flow_extended/image.h:17-23)"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("stride", C.c_int), ("data", _f)]
+
+
+EXPORTS = [
+    "sfa_device_count", "sfa_ctx_create", "sfa_ctx_destroy", "sfa_last_error", "sfa_ctx_sync", "sfa_params_default",
+    "sfa_variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sor_coupled",
+    "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
+    "sfa_add_data_and_match", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_pyramid_sizes",
+    "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_mpix_iters",
+    "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
+    "sfa_profile_enable", "sfa_profile_read", "sfa_timer_start", "sfa_timer_stop",
+]
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlowflowError(f"{LIB_PATH} is missing: build it with slowflow_amd.build() / make -C slowflow_amd/csrc "
+                                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.sfa_last_error.restype = C.c_char_p
+        L.sfa_last_error.argtypes = [C.c_void_p]
+        L.sfa_job_mpix_iters.restype = C.c_double
+        L.sfa_job_mpix_iters.argtypes = [C.c_void_p]
+        for name in ("sfa_ctx_destroy", "sfa_job_destroy", "sfa_sor_batch_destroy"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], "fp32 C-contiguous planes only"
+    return a.ctypes.data_as(_f)
+
+
+def stride_of(w):
+    return ((w + 3) // 4) * 4
+
+
+def default_params():
+    p = Params()
+    lib().sfa_params_default(C.byref(p))
+    return p
+
+
+def device_count():
+    return lib().sfa_device_count()
+
+
+class Context:
+    """sfa_ctx: one GPU, one HIP stream."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib().sfa_ctx_create(int(device), C.byref(self.h))
+        if rc != 0:
+            raise SlowflowError(f"sfa_ctx_create({device}) -> {rc}: {lib().sfa_last_error(None).decode()}")
+
+    def close(self):
+        if self.h:
+            lib().sfa_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise SlowflowError(f"{what} -> {rc}: {lib().sfa_last_error(self.h).decode()}")
+
+    def sync(self):
+        self._ck(lib().sfa_ctx_sync(self.h), "sfa_ctx_sync")
+
+    # ---- stage entry points (host planes) -------------------------------------------------------
+    def image_warp(self, src3, wx, wy, w, factor, want_mask=True):
+        _, h, stride = src3.shape
+        dst = np.zeros_like(src3)
+        mask = np.zeros((h, stride), np.float32) if want_mask else None
+        self._ck(lib().sfa_image_warp(self.h, fptr(dst), fptr(mask) if want_mask else None, fptr(src3), fptr(wx), fptr(wy), w, h, stride, int(factor)), "sfa_image_warp")
+        return dst, mask
+
+    def derivative_stack(self, I1, I2, w):
+        _, h, stride = I1.shape
+        out = np.zeros((8, 3, h, stride), np.float32)
+        self._ck(lib().sfa_derivative_stack(self.h, fptr(out), fptr(I1), fptr(I2), w, h, stride), "sfa_derivative_stack")
+        return out
+
+    def convolve(self, src, w, order, horiz):
+        h, stride = src.shape
+        dst = np.zeros_like(src)
+        self._ck(lib().sfa_convolve(self.h, fptr(dst), fptr(src), w, h, stride, int(order), int(bool(horiz))), "sfa_convolve")
+        return dst
+
+    def dpsis_weight(self, im3, w, avg=(0, 0, 0), std=(1, 1, 1), hbit=0, coef=5.0):
+        _, h, stride = im3.shape
+        dst = np.zeros((h, stride), np.float32)
+        a, s = (C.c_float * 3)(*avg), (C.c_float * 3)(*std)
+        self._ck(lib().sfa_dpsis_weight(self.h, fptr(dst), fptr(im3), w, h, stride, C.c_float(coef), a, s, int(hbit)), "sfa_dpsis_weight")
+        return dst
+
+    def smoothness(self, method, uu, vv, dpsis, w, alpha, reg):
+        h, stride = uu.shape
+        sh, sv = np.zeros_like(uu), np.zeros_like(uu)
+        self._ck(lib().sfa_smoothness(self.h, int(method), fptr(sh), fptr(sv), fptr(uu), fptr(vv), fptr(dpsis), w, h, stride, C.c_float(alpha), C.byref(reg)), "sfa_smoothness")
+        return sh, sv
+
+    def sub_laplacian(self, dst, src, wh, wv, w):
+        h, stride = src.shape
+        self._ck(lib().sfa_sub_laplacian(self.h, fptr(dst), fptr(src), fptr(wh), fptr(wv), w, h, stride), "sfa_sub_laplacian")
+        return dst
+
+    def add_data(self, sysm, mask, du, dv, D, chw, w, hd, hg, s, dt_norm, color, grad, ref_term=False):
+        a11, a12, a22, b1, b2 = sysm
+        h, stride = du.shape
+        cw = (_f * 3)(fptr(chw[0]), fptr(chw[1]), fptr(chw[2])) if chw is not None else None
+        rc = lib().sfa_add_data_and_match(self.h, fptr(a11), fptr(a12), fptr(a22), fptr(b1), fptr(b2), fptr(mask), fptr(du), fptr(dv), fptr(D), cw,
+                                          w, h, stride, C.c_float(hd), C.c_float(hg), C.c_float(s), int(bool(ref_term)), int(dt_norm),
+                                          C.byref(color), C.byref(grad))
+        return rc
+
+    def sor_coupled(self, du, dv, a11, a12, a22, b1, b2, sh, sv, w, iterations, omega):
+        """drop-in for sor_coupled (solver.h:11) on host planes"""
+        h, stride = du.shape
+        imgs = [Image(w, h, stride, fptr(a)) for a in (du, dv, a11, a12, a22, b1, b2, sh, sv)]
+        self._ck(lib().sfa_sor_coupled(self.h, *[C.byref(i) for i in imgs], int(iterations), C.c_float(omega)), "sfa_sor_coupled")
+
+    def gaussian_blur(self, src, w, sigma):
+        h, stride = src.shape
+        dst = np.zeros_like(src)
+        self._ck(lib().sfa_gaussian_blur(self.h, fptr(dst), fptr(src), w, h, stride, C.c_float(sigma)), "sfa_gaussian_blur")
+        return dst
+
+    def resize_linear(self, src, sw, dw, dh):
+        sh, sstride = src.shape
+        dst = np.zeros((dh, stride_of(dw)), np.float32)
+        self._ck(lib().sfa_resize_linear(self.h, fptr(dst), dw, dh, stride_of(dw), fptr(src), sw, sh, sstride), "sfa_resize_linear")
+        return dst
+
+    def normalize(self, frames, w):
+        F = len(frames)
+        _, h, stride = frames[0].shape
+        arr = (_f * F)(*[fptr(f) for f in frames])
+        avg, std = (C.c_double * 3)(), (C.c_double * 3)()
+        self._ck(lib().sfa_normalize(self.h, arr, F, w, h, stride, avg, std), "sfa_normalize")
+        return list(avg), list(std)
+
+    # ---- the path --------------------------------------------------------------------------------
+    def _run(self, fn, name, p, wx, wy, frames, w, chw, want_occ):
+        h, stride = wx.shape
+        F = len(frames)
+        arr = (_f * F)(*[fptr(f) for f in frames])
+        cw = (_f * 3)(fptr(chw[0]), fptr(chw[1]), fptr(chw[2])) if chw is not None else None
+        occ = np.zeros((h, stride), np.float32) if want_occ else None
+        change = (C.c_float * 2)()
+        rc = fn(self.h, C.byref(p), fptr(wx), fptr(wy), w, h, stride, arr, F, cw, fptr(occ) if want_occ else None, change)
+        self._ck(rc, name)
+        return (change[0], change[1]), occ
+
+    def compute_one_level(self, p, wx, wy, frames, w, chw=None, want_occ=False):
+        return self._run(lib().sfa_compute_one_level, "sfa_compute_one_level", p, wx, wy, frames, w, chw, want_occ)
+
+    def variational(self, p, wx, wy, frames, w, chw=None, want_occ=False):
+        return self._run(lib().sfa_variational, "sfa_variational", p, wx, wy, frames, w, chw, want_occ)
+
+    # ---- profiling / timing ----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._ck(lib().sfa_profile_enable(self.h, int(on)), "sfa_profile_enable")
+
+    def profile_read(self):
+        n, ms, by = C.c_int(), C.c_double(), C.c_double()
+        self._ck(lib().sfa_profile_read(self.h, C.byref(n), C.byref(ms), C.byref(by)), "sfa_profile_read")
+        return n.value, ms.value, by.value
+
+    def timer_start(self):
+        self._ck(lib().sfa_timer_start(self.h), "sfa_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(lib().sfa_timer_stop(self.h, C.byref(ms)), "sfa_timer_stop")
+        return ms.value
+
+
+class Job:
+    """sfa_job: `batch` frame windows of one size, resident in HBM, refined in lockstep."""
+
+    def __init__(self, ctx, params, w, h, batch=1):
+        self.ctx, self.w, self.h, self.batch = ctx, w, h, batch
+        self.h_ = C.c_void_p()
+        ctx._ck(lib().sfa_job_create(ctx.h, C.byref(params), w, h, batch, C.byref(self.h_)), "sfa_job_create")
+
+    def upload(self, b, frames, wx=None, wy=None, chw=None):
+        F = len(frames)
+        _, h, stride = frames[0].shape
+        arr = (_f * F)(*[fptr(f) for f in frames])
+        cw = (_f * 3)(fptr(chw[0]), fptr(chw[1]), fptr(chw[2])) if chw is not None else None
+        self.ctx._ck(lib().sfa_job_upload(self.h_, b, arr, F, fptr(wx) if wx is not None else None, fptr(wy) if wy is not None else None, stride, cw), "sfa_job_upload")
+
+    def run(self):
+        self.ctx._ck(lib().sfa_job_run(self.h_), "sfa_job_run")
+
+    def download(self, b):
+        stride = stride_of(self.w)
+        wx, wy = np.zeros((self.h, stride), np.float32), np.zeros((self.h, stride), np.float32)
+        change = (C.c_float * 2)()
+        self.ctx._ck(lib().sfa_job_download(self.h_, b, fptr(wx), fptr(wy), stride, change), "sfa_job_download")
+        return wx, wy, (change[0], change[1])
+
+    def mpix_iters(self):
+        return lib().sfa_job_mpix_iters(self.h_)
+
+    def close(self):
+        if self.h_:
+            lib().sfa_job_destroy(self.h_)
+            self.h_ = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SorBatch:
+    """sfa_sor_batch: `batch` independent 2x2-block systems of one size, resident in HBM."""
+
+    def __init__(self, ctx, w, h, batch=1):
+        self.ctx, self.w, self.h, self.batch = ctx, w, h, batch
+        self.h_ = C.c_void_p()
+        ctx._ck(lib().sfa_sor_batch_create(ctx.h, w, h, batch, C.byref(self.h_)), "sfa_sor_batch_create")
+
+    def upload(self, b, du, dv, a11, a12, a22, b1, b2, sh, sv):
+        stride = du.shape[1]
+        self.ctx._ck(lib().sfa_sor_batch_upload(self.h_, b, *[fptr(a) for a in (du, dv, a11, a12, a22, b1, b2, sh, sv)], stride), "sfa_sor_batch_upload")
+
+    def run(self, iterations, omega):
+        self.ctx._ck(lib().sfa_sor_batch_run(self.h_, int(iterations), C.c_float(omega)), "sfa_sor_batch_run")
+
+    def download(self, b):
+        stride = stride_of(self.w)
+        du, dv = np.zeros((self.h, stride), np.float32), np.zeros((self.h, stride), np.float32)
+        self.ctx._ck(lib().sfa_sor_batch_download(self.h_, b, fptr(du), fptr(dv), stride), "sfa_sor_batch_download")
+        return du, dv
+
+    def close(self):
+        if self.h_:
+            lib().sfa_sor_batch_destroy(self.h_)
+            self.h_ = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,867 @@
+// api.hip -- the C-ABI of include/slowflow_amd.h: context, host<->HBM staging, the level / pyramid
+// orchestration (Variational_MT::variational and compute_one_level, variational_mt.cpp:169-493, 526-784)
+// and the resident batch objects.  All compute is in kernels.hip / sor.hip; there is no CPU path.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "sfa_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace sfa {
+
+thread_local std::string g_thread_err;
+
+int set_error(sfa_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_thread_err = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int DevMem::alloc(sfa_ctx *ctx, size_t n) {
+    if (n <= bytes && p) return SFA_OK;
+    release();
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) { p = nullptr; return set_error(ctx, SFA_ERR_HIP, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
+    bytes = n;
+    return SFA_OK;
+}
+void DevMem::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+int upload_plane(sfa_ctx *ctx, float *dev, int pitch, const float *host, int stride, int w, int h) {
+    SFA_HIP(ctx, hipMemcpy2DAsync(dev, (size_t)pitch * 4, host, (size_t)stride * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, ctx->stream));
+    return SFA_OK;
+}
+int download_plane(sfa_ctx *ctx, float *host, int stride, const float *dev, int pitch, int w, int h) {
+    SFA_HIP(ctx, hipMemcpy2DAsync(host, (size_t)stride * 4, dev, (size_t)pitch * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost, ctx->stream));
+    return SFA_OK;
+}
+
+static int check_device_error(sfa_ctx *c) {
+    unsigned e = 0;
+    SFA_HIP(c, hipMemcpyAsync(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost, c->stream));
+    SFA_HIP(c, hipStreamSynchronize(c->stream));
+    if (e) {
+        (void)hipMemsetAsync(c->d_err, 0, sizeof(unsigned), c->stream);
+        return set_error(c, SFA_ERR_TIMEOUT, "SOR pipeline: a bounded in-kernel wait gave up (code %u)", e);
+    }
+    return SFA_OK;
+}
+
+static PenaltyDev pen(const sfa_penalty &p) { return PenaltyDev{p.id, p.eps, p.trunc}; }
+
+// ---------------------------------------------------------------------------------------------------
+// Level: device-resident state of `nb` frame windows at one pyramid level.
+// Element arena layout (floats, per batch element), PL = pitch*h:
+//   planes : wx wy uu vv du dv odu odv sh sv a11 a12 a22 b1 b2 occ dpsis   (17 PL)
+//   masks  : 2*ref PL
+//   warped : w_s (3 PL), w_sp1 (3 PL)
+//   stacks : [slot][succ|toref][24 PL]
+//   frames : F x 3 PL
+// ---------------------------------------------------------------------------------------------------
+enum { P_WX = 0, P_WY, P_UU, P_VV, P_DU, P_DV, P_ODU, P_ODV, P_SH, P_SV, P_A11, P_A12, P_A22, P_B1, P_B2, P_OCC, P_DPSIS, P_COUNT };
+
+struct Level {
+    int w = 0, h = 0, pitch = 0, lstride = 0, ref = 0, F = 0, nb = 0;
+    long pl = 0, es = 0;
+    long off_masks = 0, off_ws = 0, off_wsp1 = 0, off_stacks = 0, off_frames = 0, off_tmp = 0;
+    float *base = nullptr;    // element 0
+    float *plane(int i) const { return base + (long)i * pl; }
+    float *mask(int s) const { return base + off_masks + (long)s * pl; }
+    float *stack(int s, int toref) const { return base + off_stacks + ((long)s * 2 + toref) * 24 * pl; }
+    float *frame(int f) const { return base + off_frames + (long)f * 3 * pl; }
+    Geo geo(unsigned long long active = ~0ull) const { return Geo{w, h, pitch, pl, es, nb, active}; }
+    static long elem_floats(int pitch, int h, int ref) {
+        const long pl = (long)pitch * h;
+        return pl * (P_COUNT + 2 * ref + 6 + 2L * ref * 2 * 24 + (2L * ref + 1) * 3 + 6 /* tmp colour images for the pyramid */);
+    }
+    void layout(float *b, int w_, int h_, int lstride_, int ref_, int nb_, long es_) {
+        base = b; w = w_; h = h_; pitch = dev_pitch(w_); lstride = lstride_; ref = ref_; F = 2 * ref_ + 1; nb = nb_; es = es_;
+        pl = (long)pitch * h;
+        off_masks = (long)P_COUNT * pl;
+        off_ws = off_masks + 2L * ref * pl;
+        off_wsp1 = off_ws + 3 * pl;
+        off_stacks = off_wsp1 + 3 * pl;
+        off_frames = off_stacks + 2L * ref * 2 * 24 * pl;
+        off_tmp = off_frames + (long)F * 3 * pl;
+    }
+};
+
+struct ChannelWeights { const float *dev = nullptr; long pl = 0, es = 0; int pitch = 0, stride0 = 0; };
+
+// get_derivatives (variational_mt.cpp:87-166)
+static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, unsigned long long active, const bool need_toref[2 * SFA_MAX_REF]) {
+    const Geo g = L.geo(active);
+    const int ref = L.ref;
+    float *w_s = L.base + L.off_ws, *w_sp1 = L.base + L.off_wsp1;
+    for (int s = p.one_direction ? ref : 0; s < 2 * ref; s++) {
+        if (s < ref) {
+            launch_warp(c, g, w_s, L.mask(s), L.frame(s), L.plane(P_WX), L.plane(P_WY), s - ref, L.es);           // :100
+            launch_warp(c, g, w_sp1, nullptr, L.frame(s + 1), L.plane(P_WX), L.plane(P_WY), s - ref + 1, L.es);  // :103
+        } else {
+            launch_warp(c, g, w_s, nullptr, L.frame(s), L.plane(P_WX), L.plane(P_WY), s - ref, L.es);            // :106
+            launch_warp(c, g, w_sp1, L.mask(s), L.frame(s + 1), L.plane(P_WX), L.plane(P_WY), s - ref + 1, L.es); // :109
+        }
+        launch_deriv_stack(c, g, L.stack(s, 0), w_s, w_sp1, L.es, L.es);                                        // :113-133
+        // the to-reference stack (:136-161) only feeds add_data_and_match_ref (omega > 0) and optimizeOcc
+        if (need_toref[s]) {
+            if (s < ref) launch_deriv_stack(c, g, L.stack(s, 1), w_s, L.frame(ref), L.es, L.es);                 // :139-141
+            else         launch_deriv_stack(c, g, L.stack(s, 1), L.frame(ref), w_sp1, L.es, L.es);               // :143-144
+        }
+    }
+}
+
+// compute_one_level (variational_mt.cpp:169-493) for all batch elements in lockstep.
+// change: nb x 2 floats (host).  Thresholds <= 0 never break, so no host round trip is needed.
+static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const ChannelWeights &cw, SorWorkspace &sorws, float *change) {
+    const int ref = L.ref;
+    const float gamma_over3 = p.gamma / 3.0f, delta_over3 = p.delta / 3.0f;                                   // :548-549
+    unsigned long long active = L.nb >= 64 ? ~0ull : ((1ull << L.nb) - 1);
+    const unsigned long long all = active;
+    Geo g = L.geo(active);
+
+    // occlusions: 0, or -1 with one_direction / occlusion reasoning (:216-220)
+    {
+        const float occ0 = (p.one_direction || p.occlusion_reasoning) ? -1.0f : 0.0f;
+        for (int b = 0; b < L.nb; b++) launch_fill(c, L.plane(P_OCC) + b * L.es, (size_t)L.pl, occ0);
+    }
+    float data_norm = 0;                                                                                     // :223-226
+    for (int s = 0; s < ref; s++) data_norm += p.rho[s] + p.omega[s];
+
+    launch_dpsis(c, g, L.plane(P_DPSIS), L.frame(ref), L.es, 5.0f, p.norm_avg, p.norm_std, p.hbit);           // :257
+    launch_copy_planes(c, g, L.plane(P_UU), L.plane(P_WX), 2, L.es, L.es);                                    // :260-261 (wx,wy and uu,vv adjacent)
+
+    // which terms are active (:343-361), in the reference's call order
+    AssembleArgs aa;
+    memset(&aa, 0, sizeof aa);
+    bool need_toref[2 * SFA_MAX_REF] = {false};
+    for (int s = 0; s < ref; s++) {
+        if (!p.one_direction) {
+            if (p.rho[ref - 1 - s] > 0)
+                aa.t[aa.n++] = Term{L.off_stacks + ((long)s * 2 + 0) * 24 * L.pl, L.off_masks + (long)s * L.pl, p.rho[ref - 1 - s] * delta_over3,
+                                    p.rho[ref - 1 - s] * gamma_over3, (float)(s - ref), 0};
+            if (p.omega[ref - 1 - s] > 0) {
+                aa.t[aa.n++] = Term{L.off_stacks + ((long)s * 2 + 1) * 24 * L.pl, L.off_masks + (long)s * L.pl, p.omega[ref - 1 - s] * delta_over3,
+                                    p.omega[ref - 1 - s] * gamma_over3, (float)(s - ref), 1};
+                need_toref[s] = true;
+            }
+        }
+        if (p.rho[s] > 0)
+            aa.t[aa.n++] = Term{L.off_stacks + ((long)(ref + s) * 2 + 0) * 24 * L.pl, L.off_masks + (long)(ref + s) * L.pl, p.rho[s] * delta_over3,
+                                p.rho[s] * gamma_over3, (float)s, 0};
+        if (p.omega[s] > 0) {
+            aa.t[aa.n++] = Term{L.off_stacks + ((long)(ref + s) * 2 + 1) * 24 * L.pl, L.off_masks + (long)(ref + s) * L.pl, p.omega[s] * delta_over3,
+                                p.omega[s] * gamma_over3, (float)(s + 1), 1};
+            need_toref[ref + s] = true;
+        }
+    }
+    for (int t = 0; t < aa.n; t++)
+        if (aa.t[t].is_ref && aa.t[t].s == 0) return set_error(c, SFA_ERR_REF_FRAME, "Frame compared to reference frame is the reference frame itself!");
+    aa.dt_norm = p.dataterm_norm;
+    aa.color = pen(p.robust_color); aa.grad = pen(p.robust_grad);
+    aa.chw = cw.dev; aa.chw_pl = cw.pl; aa.chw_es = cw.es; aa.chw_pitch = cw.pitch; aa.chw_stride0 = cw.stride0; aa.lstride = L.lstride;
+    aa.accumulate = 0; aa.do_laplacian = 1;
+
+    const bool use_thres_in = p.thres_inner > 0, use_thres_out = p.thres_outer > 0;
+    double *red = c->d_red;
+    std::vector<double> last(2 * L.nb, 0.0);
+    const double npx = (double)L.h * L.w;
+
+    for (int alter = 0; alter < p.niter_alter; alter++) {
+        active = all;
+        g.active = active;
+        get_derivatives(c, L, p, active, need_toref);                                                       // :266
+        // alter > 0 with occlusion reasoning: optimizeOcc (GCO graph cut, :269-273) -- third-party, absent;
+        // the occlusion plane keeps its initial value (documented in DESIGN.md)
+        for (int outer = 0; outer < p.niter_outer; outer++) {
+            g.active = active;
+            if (outer > 0) get_derivatives(c, L, p, active, need_toref);                                    // :289-290
+            launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);           // :293-320
+            for (int b = 0; b < L.nb; b++)
+                if ((active >> b) & 1) SFA_HIP(c, hipMemsetAsync(L.plane(P_DU) + b * L.es, 0, (size_t)2 * L.pl * sizeof(float), c->stream));   // :323-324
+            unsigned long long in_active = active;
+            for (int inner = 0; inner < p.niter_inner; inner++) {
+                Geo gi = g;
+                gi.active = in_active;
+                launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                    // :329-330
+                launch_smoothness(c, gi, p.smoothing, L.plane(P_SH), L.plane(P_SV), L.plane(P_UU), L.plane(P_VV), L.plane(P_DPSIS), p.alpha,
+                                  pen(p.robust_reg));                                                       // :333
+                launch_assemble(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
+                                L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV));   // :336-365
+                if (in_active == all) {
+                    SFA_TRY(sor_run(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1),
+                                    L.plane(P_B2), L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega, false));   // :368
+                } else {
+                    // some elements already broke out of the inner loop: solve the remaining ones one by one
+                    for (int b = 0; b < L.nb; b++)
+                        if ((in_active >> b) & 1) {
+                            Geo g1 = gi;
+                            g1.nb = 1; g1.active = 1;
+                            const long eb = b * L.es;
+                            SFA_TRY(sor_run(c, sorws, g1, L.plane(P_DU) + eb, L.plane(P_DV) + eb, L.plane(P_A11) + eb, L.plane(P_A12) + eb,
+                                            L.plane(P_A22) + eb, L.plane(P_B1) + eb, L.plane(P_B2) + eb, L.plane(P_SH) + eb, L.plane(P_SV) + eb,
+                                            p.niter_solver, p.sor_omega, false));
+                        }
+                }
+                launch_update_inner(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), L.plane(P_DU), L.plane(P_DV), L.plane(P_ODU),
+                                    L.plane(P_ODV), red);                                                   // :371-402
+                if (use_thres_in && inner + 1 < p.niter_inner) {
+                    SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                    SFA_HIP(c, hipStreamSynchronize(c->stream));
+                    for (int b = 0; b < L.nb; b++)
+                        if ((in_active >> b) & 1) {
+                            const float a = (float)(c->h_red[2 * b] / npx), d = (float)(c->h_red[2 * b + 1] / npx);
+                            if (std::max(a, d) < p.thres_inner) in_active &= ~(1ull << b);                   // :407
+                        }
+                    if (!in_active) break;
+                }
+            }
+            launch_update_outer(c, g, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);      // :412-429
+            const bool last_iter = (alter == p.niter_alter - 1 && outer == p.niter_outer - 1);
+            if (use_thres_out || last_iter) {
+                SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                SFA_HIP(c, hipStreamSynchronize(c->stream));
+                for (int b = 0; b < L.nb; b++)
+                    if ((active >> b) & 1) {
+                        last[2 * b] = c->h_red[2 * b] / npx;
+                        last[2 * b + 1] = c->h_red[2 * b + 1] / npx;
+                        if (use_thres_out && std::max((float)last[2 * b], (float)last[2 * b + 1]) < p.thres_outer) active &= ~(1ull << b);   // :436
+                    }
+                if (!active) break;
+            }
+        }
+    }
+    if (change)
+        for (int i = 0; i < 2 * L.nb; i++) change[i] = (float)last[i];
+    return SFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pyramid geometry (variational_mt.cpp:576-652)
+// ---------------------------------------------------------------------------------------------------
+static int gaussian_filter_order(float sigma) {      // image.c:320-322
+    int order = (int)floor(3 * sigma) + 1;
+    if (order == 0) order = 1;
+    return order;
+}
+static int pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs) {
+    const float sigma = 1 / sqrtf(2 * p_scale);      // :578
+    const int order = gaussian_filter_order(sigma);
+    int L = layers;
+    for (int l = 0; l < layers; l++) {
+        if (l == 0) { ws[0] = w; hs[0] = h; }
+        else {
+            ws[l] = (int)(float)floor(ws[l - 1] * p_scale);   // :609-611 (product rounded to fp32 before the floor)
+            hs[l] = (int)(float)floor(hs[l - 1] * p_scale);
+        }
+        if (floor(ws[l] * p_scale) <= order + 1 || floor(hs[l] * p_scale) <= order + 1) { L = l; break; }   // :647-651
+    }
+    return L;
+}
+// cv::getGaussianKernel(ksize, sigma, CV_32F) with ksize = cvRound(sigma*8+1)|1 (cv::GaussianBlur, Size(0,0), CV_32F)
+static int cv_gauss_taps(float sigma, float *k) {
+    const int ksize = ((int)lrint((double)sigma * 4 * 2 + 1)) | 1;
+    const double scale2X = -0.5 / ((double)sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < ksize; i++) {
+        const double x = i - (ksize - 1) * 0.5;
+        k[i] = (float)exp(scale2X * x * x);
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < ksize; i++) k[i] = (float)(k[i] * sum);
+    return ksize / 2;
+}
+
+}  // namespace sfa
+
+using namespace sfa;
+
+// ---------------------------------------------------------------------------------------------------
+// the resident job (variational over a batch)
+// ---------------------------------------------------------------------------------------------------
+struct sfa_job {
+    sfa_ctx *ctx = nullptr;
+    sfa_params p;
+    int w = 0, h = 0, nb = 0, ref = 0, F = 0, L = 0;
+    int ws[64], hs[64];
+    long es = 0;                       // floats per element (all levels)
+    std::vector<long> level_off;       // offset of each level's arena inside the element
+    DevMem arena;                      // nb * es floats
+    DevMem init_flow;                  // nb x 2 planes at level-0 pitch: the uploaded initial flow
+    DevMem chw;                        // nb x 3 planes (level-0 pitch) or empty
+    bool has_chw = false;
+    int chw_stride0 = 0;
+    std::vector<std::unique_ptr<SorWorkspace>> sor;   // one per level: no re-allocation between runs
+    std::vector<float> change;         // nb x 2
+    double mpix_iters = 0;
+    Level level(int l) const {
+        Level Lv;
+        Lv.layout(arena.f() + level_off[l], ws[l], hs[l], l == 0 ? host_stride0 : host_stride(ws[l]), ref, nb, es);
+        return Lv;
+    }
+    int host_stride0 = 0;
+};
+
+extern "C" {
+
+int sfa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sfa_ctx_create(int device, sfa_ctx **out) {
+    if (!out) return set_error(nullptr, SFA_ERR_ARG, "sfa_ctx_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_error(nullptr, SFA_ERR_NO_DEVICE, "no HIP device available: slowflow_amd has no CPU fallback");
+    if (device < 0 || device >= n) return set_error(nullptr, SFA_ERR_ARG, "device %d out of range (%d devices)", device, n);
+    std::unique_ptr<sfa_ctx> c(new sfa_ctx());
+    c->device = device;
+    SFA_HIP(c.get(), hipSetDevice(device));
+    SFA_HIP(c.get(), hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    SFA_HIP(c.get(), hipMalloc((void **)&c->d_red, kRedDoubles * sizeof(double)));
+    SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, 2 * kMaxBatch * sizeof(double) + 64, hipHostMallocDefault));
+    SFA_HIP(c.get(), hipMalloc((void **)&c->d_err, 64));
+    SFA_HIP(c.get(), hipMemset(c->d_err, 0, 64));
+    SFA_HIP(c.get(), hipEventCreate(&c->t0));
+    SFA_HIP(c.get(), hipEventCreate(&c->t1));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    *out = c.release();
+    return SFA_OK;
+}
+
+void sfa_ctx_destroy(sfa_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto e : c->ev) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->d_red) (void)hipFree(c->d_red);
+    if (c->h_red) (void)hipHostFree(c->h_red);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *sfa_last_error(const sfa_ctx *c) { return c ? c->err.c_str() : g_thread_err.c_str(); }
+
+int sfa_ctx_sync(sfa_ctx *c) {
+    if (!c) return set_error(nullptr, SFA_ERR_ARG, "null context");
+    SFA_HIP(c, hipSetDevice(c->device));
+    return check_device_error(c);
+}
+
+void sfa_params_default(sfa_params *p) {           // slow_flow.cpp:64-128
+    memset(p, 0, sizeof *p);
+    p->S = 2; p->one_direction = 0; p->smoothing = 1; p->dataterm_norm = 1;
+    p->niter_alter = 10; p->niter_outer = 10; p->niter_inner = 1; p->niter_solver = 30;
+    p->thres_outer = 1e-5f; p->thres_inner = 1e-5f; p->sor_omega = 1.9f;
+    p->alpha = 4.0f; p->gamma = 6.0f; p->delta = 1.0f;
+    p->robust_color = sfa_penalty{1, 0.001f, 0.5f};
+    p->robust_grad = p->robust_color; p->robust_reg = p->robust_color;
+    p->rho[0] = 1; p->rho[1] = 1; p->rho[2] = 1; p->rho[3] = 1;
+    p->omega[0] = 0; p->omega[1] = 2; p->omega[2] = 1; p->omega[3] = 1;
+    p->hbit = 1;
+    for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
+    p->occlusion_reasoning = 1; p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;
+}
+
+int sfa_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs) {
+    if (layers < 1 || layers > 64 || !ws || !hs) return 0;
+    return pyramid_sizes(w, h, layers, p_scale, ws, hs);
+}
+
+// ---- profiling / timing -----------------------------------------------------------------------------
+int sfa_profile_enable(sfa_ctx *c, int on) {
+    if (!c) return SFA_ERR_ARG;
+    SFA_HIP(c, hipSetDevice(c->device));
+    c->profile = on != 0;
+    c->ev_used = 0;
+    c->sor_bytes = 0;
+    if (on && c->ev.empty()) {
+        c->ev.resize(4096);
+        for (auto &e : c->ev) SFA_HIP(c, hipEventCreate(&e));
+    }
+    return SFA_OK;
+}
+int sfa_profile_read(sfa_ctx *c, int *n, double *ms_total, double *bytes_total) {
+    if (!c) return SFA_ERR_ARG;
+    SFA_HIP(c, hipStreamSynchronize(c->stream));
+    double tot = 0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0;
+        SFA_HIP(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        tot += ms;
+    }
+    if (n) *n = (int)(c->ev_used / 2);
+    if (ms_total) *ms_total = tot;
+    if (bytes_total) *bytes_total = c->sor_bytes;
+    c->ev_used = 0;
+    c->sor_bytes = 0;
+    return SFA_OK;
+}
+int sfa_timer_start(sfa_ctx *c) {
+    if (!c) return SFA_ERR_ARG;
+    SFA_HIP(c, hipEventRecord(c->t0, c->stream));
+    return SFA_OK;
+}
+int sfa_timer_stop(sfa_ctx *c, float *ms) {
+    if (!c) return SFA_ERR_ARG;
+    SFA_HIP(c, hipEventRecord(c->t1, c->stream));
+    SFA_HIP(c, hipEventSynchronize(c->t1));
+    float v = 0;
+    SFA_HIP(c, hipEventElapsedTime(&v, c->t0, c->t1));
+    if (ms) *ms = v;
+    return SFA_OK;
+}
+
+// ---- stage entry points on host planes ------------------------------------------------------------------
+struct Staging {
+    sfa_ctx *c;
+    DevMem mem;
+    int w, h, pitch; long pl;
+    float *plane(int i) { return mem.f() + (long)i * pl; }
+    int init(sfa_ctx *ctx, int w_, int h_, int nplanes) {
+        c = ctx; w = w_; h = h_; pitch = dev_pitch(w_); pl = (long)pitch * h_;
+        SFA_HIP(c, hipSetDevice(c->device));
+        SFA_TRY(mem.alloc(c, (size_t)nplanes * pl * sizeof(float)));
+        SFA_HIP(c, hipMemsetAsync(mem.p, 0, (size_t)nplanes * pl * sizeof(float), c->stream));
+        return SFA_OK;
+    }
+    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, 1ull}; }
+    int up(int i, const float *host, int stride, int n = 1) {
+        for (int k = 0; k < n; k++) SFA_TRY(upload_plane(c, plane(i + k), pitch, host + (size_t)k * stride * h, stride, w, h));
+        return SFA_OK;
+    }
+    int down(float *host, int stride, int i, int n = 1) {
+        for (int k = 0; k < n; k++) SFA_TRY(download_plane(c, host + (size_t)k * stride * h, stride, plane(i + k), pitch, w, h));
+        return SFA_OK;
+    }
+};
+#define CHECK_ARGS(cond, msg) do { if (!(cond)) return set_error(ctx, SFA_ERR_ARG, "%s: %s", __func__, msg); } while (0)
+
+int sfa_image_warp(sfa_ctx *ctx, float *dst3, float *mask, const float *src3, const float *wx, const float *wy, int w, int h, int stride, int factor) {
+    CHECK_ARGS(ctx && dst3 && src3 && wx && wy && w > 0 && h > 0 && stride >= w, "bad arguments");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 9));
+    SFA_TRY(s.up(0, src3, stride, 3)); SFA_TRY(s.up(3, wx, stride)); SFA_TRY(s.up(4, wy, stride));
+    if (mask) SFA_TRY(s.up(8, mask, stride));
+    launch_warp(ctx, s.geo(), s.plane(5), mask ? s.plane(8) : nullptr, s.plane(0), s.plane(3), s.plane(4), factor, 0);
+    SFA_TRY(s.down(dst3, stride, 5, 3));
+    if (mask) SFA_TRY(s.down(mask, stride, 8));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_derivative_stack(sfa_ctx *ctx, float *out8x3, const float *I1, const float *I2, int w, int h, int stride) {
+    CHECK_ARGS(ctx && out8x3 && I1 && I2 && w > 0 && h >= 4 && stride >= w, "bad arguments (h >= 4 needed by the 5-tap vertical filter, image.c:443)");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 30));
+    SFA_TRY(s.up(24, I1, stride, 3)); SFA_TRY(s.up(27, I2, stride, 3));
+    launch_deriv_stack(ctx, s.geo(), s.plane(0), s.plane(24), s.plane(27), 0, 0);
+    SFA_TRY(s.down(out8x3, stride, 0, 24));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_convolve(sfa_ctx *ctx, float *dst, const float *src, int w, int h, int stride, int order, int horizontal) {
+    CHECK_ARGS(ctx && dst && src && w > 0 && h > 0 && stride >= w && (order == 1 || order == 2), "bad arguments");
+    CHECK_ARGS(horizontal || h >= (order == 2 ? 4 : 2), "image too small for the vertical fast path");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 2));
+    SFA_TRY(s.up(0, src, stride));
+    launch_convolve(ctx, s.geo(), s.plane(1), s.plane(0), order, horizontal, 1);
+    SFA_TRY(s.down(dst, stride, 1));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_dpsis_weight(sfa_ctx *ctx, float *dst, const float *im3, int w, int h, int stride, float coef, const float avg[3], const float std_dev[3], int hbit) {
+    CHECK_ARGS(ctx && dst && im3 && avg && std_dev && w > 0 && h >= 4 && stride >= w, "bad arguments");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 4));
+    SFA_TRY(s.up(0, im3, stride, 3));
+    launch_dpsis(ctx, s.geo(), s.plane(3), s.plane(0), 0, coef, avg, std_dev, hbit);
+    SFA_TRY(s.down(dst, stride, 3));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_smoothness(sfa_ctx *ctx, int method, float *dst_horiz, float *dst_vert, const float *uu, const float *vv, const float *dpsis, int w, int h,
+                   int stride, float alpha, const sfa_penalty *reg) {
+    CHECK_ARGS(ctx && dst_horiz && dst_vert && uu && vv && dpsis && reg && w > 0 && h >= 2 && stride >= w, "bad arguments");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 5));
+    SFA_TRY(s.up(0, uu, stride)); SFA_TRY(s.up(1, vv, stride)); SFA_TRY(s.up(2, dpsis, stride));
+    launch_smoothness(ctx, s.geo(), method, s.plane(3), s.plane(4), s.plane(0), s.plane(1), s.plane(2), alpha, pen(*reg));
+    SFA_TRY(s.down(dst_horiz, stride, 3)); SFA_TRY(s.down(dst_vert, stride, 4));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_sub_laplacian(sfa_ctx *ctx, float *dst, const float *src, const float *wh, const float *wv, int w, int h, int stride) {
+    CHECK_ARGS(ctx && dst && src && wh && wv && w > 0 && h > 0 && stride >= w, "bad arguments");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 4));
+    SFA_TRY(s.up(0, dst, stride)); SFA_TRY(s.up(1, src, stride)); SFA_TRY(s.up(2, wh, stride)); SFA_TRY(s.up(3, wv, stride));
+    launch_sub_laplacian(ctx, s.geo(), s.plane(0), s.plane(1), s.plane(2), s.plane(3));
+    SFA_TRY(s.down(dst, stride, 0));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_add_data_and_match(sfa_ctx *ctx, float *a11, float *a12, float *a22, float *b1, float *b2, const float *mask, const float *du, const float *dv,
+                           const float *D8x3, const float *const chw[3], int w, int h, int stride, float delta_over3, float gamma_over3, float sfac,
+                           int ref_term, int dt_norm, const sfa_penalty *color, const sfa_penalty *grad) {
+    CHECK_ARGS(ctx && a11 && a12 && a22 && b1 && b2 && mask && du && dv && D8x3 && color && grad && w > 0 && h > 0 && stride >= w, "bad arguments");
+    if (ref_term && sfac == 0) return set_error(ctx, SFA_ERR_REF_FRAME, "Frame compared to reference frame is the reference frame itself!");
+    Staging s;
+    // planes: 0-4 system, 5 mask, 6 du, 7 dv, 8..31 stack, 32..34 chw
+    SFA_TRY(s.init(ctx, w, h, 35));
+    float *sysm[5] = {a11, a12, a22, b1, b2};
+    for (int i = 0; i < 5; i++) SFA_TRY(s.up(i, sysm[i], stride));
+    SFA_TRY(s.up(5, mask, stride)); SFA_TRY(s.up(6, du, stride)); SFA_TRY(s.up(7, dv, stride));
+    SFA_TRY(s.up(8, D8x3, stride, 24));
+    AssembleArgs aa;
+    memset(&aa, 0, sizeof aa);
+    aa.n = 1;
+    aa.t[0] = Term{8 * s.pl, 5 * s.pl, delta_over3, gamma_over3, sfac, ref_term};
+    aa.dt_norm = dt_norm; aa.color = pen(*color); aa.grad = pen(*grad);
+    if (chw) {
+        for (int k = 0; k < 3; k++) SFA_TRY(upload_plane(ctx, s.plane(32 + k), s.pitch, chw[k], stride, w, h));
+        aa.chw = s.plane(32); aa.chw_pl = s.pl; aa.chw_es = 0; aa.chw_pitch = s.pitch; aa.chw_stride0 = stride; aa.lstride = stride;
+    }
+    aa.accumulate = 1; aa.do_laplacian = 0;
+    launch_assemble(ctx, s.geo(), aa, s.plane(0), s.plane(0), s.plane(1), s.plane(2), s.plane(3), s.plane(4), s.plane(6), s.plane(7), nullptr, nullptr,
+                    nullptr, nullptr);
+    for (int i = 0; i < 5; i++) SFA_TRY(s.down(sysm[i], stride, i));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_gaussian_blur(sfa_ctx *ctx, float *dst, const float *src, int w, int h, int stride, float sigma) {
+    CHECK_ARGS(ctx && dst && src && w > 0 && h > 0 && stride >= w && sigma > 0, "bad arguments");
+    float taps[64];
+    CHECK_ARGS(sigma * 8 + 1 < 33, "sigma too large");
+    const int r = cv_gauss_taps(sigma, taps);
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 3));
+    SFA_TRY(s.up(0, src, stride));
+    launch_gauss_blur(ctx, s.geo(), s.plane(1), s.plane(2), s.plane(0), 1, taps, r);
+    SFA_TRY(s.down(dst, stride, 1));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_resize_linear(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride) {
+    CHECK_ARGS(ctx && dst && src && dw > 0 && dh > 0 && sw > 0 && sh > 0 && dstride >= dw && sstride >= sw, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    DevMem a, b;
+    const int sp = dev_pitch(sw), dp = dev_pitch(dw);
+    SFA_TRY(a.alloc(ctx, (size_t)sp * sh * 4)); SFA_TRY(b.alloc(ctx, (size_t)dp * dh * 4));
+    SFA_TRY(upload_plane(ctx, a.f(), sp, src, sstride, sw, sh));
+    launch_resize(ctx, b.f(), dw, dh, dp, (long)dp * dh, 0, a.f(), sw, sh, sp, (long)sp * sh, 0, 1, 1, 1.0f);
+    SFA_TRY(download_plane(ctx, dst, dstride, b.f(), dp, dw, dh));
+    return sfa_ctx_sync(ctx);
+}
+
+// ---- SOR ----------------------------------------------------------------------------------------------------
+struct sfa_sor_batch {
+    sfa_ctx *ctx = nullptr;
+    int w = 0, h = 0, nb = 0, pitch = 0;
+    long pl = 0, es = 0;
+    DevMem mem;          // nb x 9 planes: du dv a11 a12 a22 b1 b2 sh sv
+    SorWorkspace ws;
+    float *plane(int b, int i) const { return mem.f() + b * es + (long)i * pl; }
+};
+
+int sfa_sor_batch_create(sfa_ctx *ctx, int w, int h, int batch, sfa_sor_batch **out) {
+    CHECK_ARGS(ctx && out && w > 0 && h > 0 && batch > 0 && batch <= kMaxBatch, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<sfa_sor_batch> sb(new sfa_sor_batch());
+    sb->ctx = ctx; sb->w = w; sb->h = h; sb->nb = batch; sb->pitch = dev_pitch(w);
+    sb->pl = (long)sb->pitch * h; sb->es = 9 * sb->pl;
+    SFA_TRY(sb->mem.alloc(ctx, (size_t)batch * sb->es * sizeof(float)));
+    SFA_HIP(ctx, hipMemsetAsync(sb->mem.p, 0, (size_t)batch * sb->es * sizeof(float), ctx->stream));
+    *out = sb.release();
+    return SFA_OK;
+}
+void sfa_sor_batch_destroy(sfa_sor_batch *sb) {
+    if (!sb) return;
+    (void)hipSetDevice(sb->ctx->device);
+    (void)hipStreamSynchronize(sb->ctx->stream);
+    delete sb;
+}
+int sfa_sor_batch_upload(sfa_sor_batch *sb, int b, const float *du, const float *dv, const float *a11, const float *a12, const float *a22, const float *b1,
+                         const float *b2, const float *sh, const float *sv, int stride) {
+    sfa_ctx *ctx = sb ? sb->ctx : nullptr;
+    CHECK_ARGS(sb && b >= 0 && b < sb->nb && du && dv && a11 && a12 && a22 && b1 && b2 && sh && sv && stride >= sb->w, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    const float *src[9] = {du, dv, a11, a12, a22, b1, b2, sh, sv};
+    for (int i = 0; i < 9; i++) SFA_TRY(upload_plane(ctx, sb->plane(b, i), sb->pitch, src[i], stride, sb->w, sb->h));
+    SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFA_OK;
+}
+int sfa_sor_batch_run(sfa_sor_batch *sb, int iterations, float omega) {
+    sfa_ctx *ctx = sb ? sb->ctx : nullptr;
+    CHECK_ARGS(sb, "null batch");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    Geo g{sb->w, sb->h, sb->pitch, sb->pl, sb->es, sb->nb, sb->nb >= 64 ? ~0ull : ((1ull << sb->nb) - 1)};
+    return sor_run(ctx, sb->ws, g, sb->plane(0, 0), sb->plane(0, 1), sb->plane(0, 2), sb->plane(0, 3), sb->plane(0, 4), sb->plane(0, 5), sb->plane(0, 6),
+                   sb->plane(0, 7), sb->plane(0, 8), iterations, omega, true);
+}
+int sfa_sor_batch_download(sfa_sor_batch *sb, int b, float *du, float *dv, int stride) {
+    sfa_ctx *ctx = sb ? sb->ctx : nullptr;
+    CHECK_ARGS(sb && b >= 0 && b < sb->nb && du && dv && stride >= sb->w, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    SFA_TRY(download_plane(ctx, du, stride, sb->plane(b, 0), sb->pitch, sb->w, sb->h));
+    SFA_TRY(download_plane(ctx, dv, stride, sb->plane(b, 1), sb->pitch, sb->w, sb->h));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_sor_coupled(sfa_ctx *ctx, sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, sfa_image *a22, sfa_image *b1, sfa_image *b2,
+                    sfa_image *dpsis_horiz, sfa_image *dpsis_vert, int iterations, float omega) {
+    CHECK_ARGS(ctx && du && dv && a11 && a12 && a22 && b1 && b2 && dpsis_horiz && dpsis_vert, "null image");
+    const int w = du->width, h = du->height, stride = du->stride;
+    CHECK_ARGS(w > 0 && h > 0 && stride >= w, "bad image geometry");
+    sfa_image *im[9] = {du, dv, a11, a12, a22, b1, b2, dpsis_horiz, dpsis_vert};
+    for (auto *i : im) CHECK_ARGS(i->data && i->width == w && i->height == h && i->stride == stride, "images must share one geometry");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 9));
+    for (int i = 0; i < 9; i++) SFA_TRY(s.up(i, im[i]->data, stride));
+    SorWorkspace ws;
+    SFA_TRY(sor_run(ctx, ws, s.geo(), s.plane(0), s.plane(1), s.plane(2), s.plane(3), s.plane(4), s.plane(5), s.plane(6), s.plane(7), s.plane(8), iterations,
+                    omega, true));
+    SFA_TRY(s.down(du->data, stride, 0)); SFA_TRY(s.down(dv->data, stride, 1));
+    if (!(w < 2 || h < 2 || iterations < 1))                                          // the fast path inverts the blocks in place (solver.c:104-106)
+        for (int i = 2; i < 5; i++) SFA_TRY(s.down(im[i]->data, stride, i));
+    return sfa_ctx_sync(ctx);
+}
+
+void sor_coupled(sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, sfa_image *a22, sfa_image *b1, sfa_image *b2, sfa_image *dpsis_horiz,
+                 sfa_image *dpsis_vert, const int iterations, const float omega) {
+    static std::mutex mu;
+    static sfa_ctx *def = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!def && sfa_ctx_create(0, &def) != SFA_OK) {
+        fprintf(stderr, "error in sor_coupled(): %s\n", sfa_last_error(nullptr));
+        exit(1);
+    }
+    if (sfa_sor_coupled(def, du, dv, a11, a12, a22, b1, b2, dpsis_horiz, dpsis_vert, iterations, omega) != SFA_OK) {
+        fprintf(stderr, "error in sor_coupled(): %s\n", sfa_last_error(def));
+        exit(1);
+    }
+}
+
+// ---- normalize ---------------------------------------------------------------------------------------------
+int sfa_normalize(sfa_ctx *ctx, float *const *frames, int F, int w, int h, int stride, double avg[3], double std_dev[3]) {
+    CHECK_ARGS(ctx && frames && F > 0 && w > 0 && h > 0 && stride >= w && avg && std_dev, "bad arguments");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 3 * F));
+    for (int k = 0; k < 3; k++) { avg[k] = 0; std_dev[k] = 0; }
+    for (int f = 0; f < F; f++) {
+        CHECK_ARGS(frames[f], "null frame");
+        SFA_TRY(s.up(3 * f, frames[f], stride, 3));
+        launch_normalize_sums(ctx, s.geo(), s.plane(3 * f), ctx->d_red);
+        SFA_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 3; k++) {
+            avg[k] += ctx->h_red[2 * k] / (h * w);                                     // variational_mt.cpp:41-47
+            std_dev[k] += ctx->h_red[2 * k + 1] / (h * w);
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        avg[k] /= F;
+        std_dev[k] = sqrt((std_dev[k] / F) - avg[k] * avg[k]) / 255.0f;               // :52
+    }
+    for (int f = 0; f < F; f++) {
+        launch_normalize_apply(ctx, s.geo(), s.plane(3 * f), avg, std_dev);
+        SFA_TRY(s.down(frames[f], stride, 3 * f, 3));
+    }
+    return sfa_ctx_sync(ctx);
+}
+
+// ---- job ------------------------------------------------------------------------------------------------------
+int sfa_job_create(sfa_ctx *ctx, const sfa_params *p, int w, int h, int batch, sfa_job **out) {
+    CHECK_ARGS(ctx && p && out && w >= 2 && h >= 5 && batch > 0 && batch <= kMaxBatch, "bad arguments (h >= 5, w >= 2)");
+    CHECK_ARGS(p->S >= 2 && p->S - 1 <= SFA_MAX_REF && p->layers >= 1 && p->layers <= 64, "unsupported slow_flow_S / slow_flow_layers");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<sfa_job> j(new sfa_job());
+    j->ctx = ctx; j->p = *p; j->w = w; j->h = h; j->nb = batch; j->ref = p->S - 1; j->F = 2 * j->ref + 1;
+    j->L = pyramid_sizes(w, h, p->layers, p->p_scale, j->ws, j->hs);
+    CHECK_ARGS(j->L >= 1, "image too small for even one pyramid level");
+    j->level_off.resize(j->L);
+    long off = 0;
+    for (int l = 0; l < j->L; l++) {
+        j->level_off[l] = off;
+        off += Level::elem_floats(dev_pitch(j->ws[l]), j->hs[l], j->ref);
+    }
+    j->es = off;
+    j->host_stride0 = host_stride(w);
+    SFA_TRY(j->arena.alloc(ctx, (size_t)batch * j->es * sizeof(float)));
+    SFA_HIP(ctx, hipMemsetAsync(j->arena.p, 0, (size_t)batch * j->es * sizeof(float), ctx->stream));
+    SFA_TRY(j->init_flow.alloc(ctx, (size_t)batch * 2 * dev_pitch(w) * h * sizeof(float)));
+    SFA_HIP(ctx, hipMemsetAsync(j->init_flow.p, 0, (size_t)batch * 2 * dev_pitch(w) * h * sizeof(float), ctx->stream));
+    j->change.assign(2 * batch, 0.f);
+    for (int l = 0; l < j->L; l++) j->sor.emplace_back(new SorWorkspace());
+    // sum over levels of outer x inner solves (thresholds may end earlier; this is the scheduled amount)
+    double px = 0;
+    for (int l = 0; l < j->L; l++) px += (double)j->ws[l] * j->hs[l];
+    j->mpix_iters = px * p->niter_alter * p->niter_outer * p->niter_inner * p->niter_solver * batch / 1e6;
+    *out = j.release();
+    return SFA_OK;
+}
+void sfa_job_destroy(sfa_job *j) {
+    if (!j) return;
+    (void)hipSetDevice(j->ctx->device);
+    (void)hipStreamSynchronize(j->ctx->stream);
+    delete j;
+}
+double sfa_job_mpix_iters(const sfa_job *j) { return j ? j->mpix_iters : 0; }
+
+int sfa_job_upload(sfa_job *j, int b, const float *const *frames, int n_frames, const float *wx, const float *wy, int stride, const float *const chw[3]) {
+    sfa_ctx *ctx = j ? j->ctx : nullptr;
+    CHECK_ARGS(j && b >= 0 && b < j->nb && frames && n_frames == j->F && stride >= j->w, "bad arguments (n_frames must be 2*(S-1)+1)");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    Level L0 = j->level(0);
+    j->host_stride0 = stride;
+    for (int f = 0; f < j->F; f++) {
+        CHECK_ARGS(frames[f], "null frame");
+        for (int k = 0; k < 3; k++)
+            SFA_TRY(upload_plane(ctx, L0.frame(f) + b * j->es + k * L0.pl, L0.pitch, frames[f] + (size_t)k * stride * j->h, stride, j->w, j->h));
+    }
+    float *f0 = j->init_flow.f() + (long)b * 2 * L0.pl;
+    if (wx) SFA_TRY(upload_plane(ctx, f0, L0.pitch, wx, stride, j->w, j->h));
+    else SFA_HIP(ctx, hipMemsetAsync(f0, 0, L0.pl * sizeof(float), ctx->stream));
+    if (wy) SFA_TRY(upload_plane(ctx, f0 + L0.pl, L0.pitch, wy, stride, j->w, j->h));
+    else SFA_HIP(ctx, hipMemsetAsync(f0 + L0.pl, 0, L0.pl * sizeof(float), ctx->stream));
+    if (chw) {
+        // weights keep the level-0 host geometry, padding lanes included (the reference indexes them linearly)
+        if (!j->has_chw) {
+            SFA_TRY(j->chw.alloc(ctx, (size_t)j->nb * 3 * dev_pitch(stride) * j->h * sizeof(float)));
+            launch_fill(ctx, j->chw.f(), (size_t)j->nb * 3 * dev_pitch(stride) * j->h, 1.0f);
+            j->has_chw = true;
+            j->chw_stride0 = stride;
+        }
+        CHECK_ARGS(j->chw_stride0 == stride, "channel weights of all elements must share one stride");
+        const int cp = dev_pitch(stride);
+        for (int k = 0; k < 3; k++) {
+            CHECK_ARGS(chw[k], "null weight plane");
+            SFA_TRY(upload_plane(ctx, j->chw.f() + ((long)b * 3 + k) * cp * j->h, cp, chw[k], stride, stride, j->h));
+        }
+    }
+    SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFA_OK;
+}
+
+int sfa_job_reset_flow(sfa_job *j) { return j ? SFA_OK : SFA_ERR_ARG; }   // the initial flow is re-read by every run
+
+int sfa_job_run(sfa_job *j) {
+    sfa_ctx *ctx = j ? j->ctx : nullptr;
+    CHECK_ARGS(j, "null job");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    const sfa_params &p = j->p;
+    const int nb = j->nb, F = j->F, L = j->L;
+    const unsigned long long all = nb >= 64 ? ~0ull : ((1ull << nb) - 1);
+    // ---- pyramid (variational_mt.cpp:583-652) -----------------------------------------------------------
+    const float sigma = 1 / sqrtf(2 * p.p_scale);
+    float taps[64];
+    const int radius = cv_gauss_taps(sigma, taps);
+    Level L0 = j->level(0);
+    if (p.presmooth_sigma > 0) {                                                      // :590-597
+        float *tmp = L0.base + L0.off_tmp;
+        for (int f = 0; f < F; f++) {
+            Geo g = L0.geo(all);
+            launch_presmooth(ctx, g, tmp + 3 * L0.pl, tmp, L0.frame(f), 3, p.presmooth_sigma);
+            launch_copy_planes(ctx, g, L0.frame(f), tmp + 3 * L0.pl, 3, L0.es, L0.es);
+        }
+    }
+    for (int l = 1; l < L; l++) {
+        Level Lp = j->level(l - 1), Lc = j->level(l);
+        float *tmp = Lp.base + Lp.off_tmp;
+        for (int f = 0; f < F; f++) {
+            launch_gauss_blur(ctx, Lp.geo(all), tmp + 3 * Lp.pl, tmp, Lp.frame(f), 3, taps, radius);            // :607
+            launch_resize(ctx, Lc.frame(f), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, tmp + 3 * Lp.pl, Lp.w, Lp.h, Lp.pitch, Lp.pl, Lp.es, 3, nb, 1.0f);   // :611
+        }
+    }
+    // ---- initial flow at the coarsest level (:662-681) ---------------------------------------------------
+    Level Lt = j->level(L - 1);
+    if (L > 1) {
+        const float fx = (1.0f * Lt.w) / j->w, fy = (1.0f * Lt.h) / j->h;
+        launch_resize(ctx, Lt.plane(P_WX), Lt.w, Lt.h, Lt.pitch, Lt.pl, Lt.es, j->init_flow.f(), j->w, j->h, L0.pitch, L0.pl, 2 * L0.pl, 1, nb, fx);
+        launch_resize(ctx, Lt.plane(P_WY), Lt.w, Lt.h, Lt.pitch, Lt.pl, Lt.es, j->init_flow.f() + L0.pl, j->w, j->h, L0.pitch, L0.pl, 2 * L0.pl, 1, nb, fy);
+    } else {
+        launch_copy_planes(ctx, L0.geo(all), L0.plane(P_WX), j->init_flow.f(), 2, L0.es, 2 * L0.pl);
+    }
+    ChannelWeights cw;
+    if (j->has_chw) {
+        cw.dev = j->chw.f(); cw.pitch = dev_pitch(j->chw_stride0); cw.pl = (long)cw.pitch * j->h; cw.es = 3 * cw.pl; cw.stride0 = j->chw_stride0;
+    }
+    // ---- coarse to fine (:684-762) -----------------------------------------------------------------------------
+    for (int l = L - 1; l >= 0; l--) {
+        Level Lc = j->level(l);
+        if (l < L - 1) {
+            Level Ln = j->level(l + 1);
+            const float fx = (1.0f * Lc.w) / Ln.w, fy = (1.0f * Lc.h) / Ln.h;                                   // :703-704
+            launch_resize(ctx, Lc.plane(P_WX), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WX), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fx);   // :711,716
+            launch_resize(ctx, Lc.plane(P_WY), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WY), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fy);
+        }
+        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[l], j->change.data()));                                           // :761
+    }
+    SFA_HIP(ctx, hipGetLastError());
+    return SFA_OK;
+}
+
+int sfa_job_download(sfa_job *j, int b, float *wx, float *wy, int stride, float change[2]) {
+    sfa_ctx *ctx = j ? j->ctx : nullptr;
+    CHECK_ARGS(j && b >= 0 && b < j->nb && wx && wy && stride >= j->w, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    Level L0 = j->level(0);
+    SFA_TRY(download_plane(ctx, wx, stride, L0.plane(P_WX) + b * j->es, L0.pitch, j->w, j->h));
+    SFA_TRY(download_plane(ctx, wy, stride, L0.plane(P_WY) + b * j->es, L0.pitch, j->w, j->h));
+    if (change) { change[0] = j->change[2 * b]; change[1] = j->change[2 * b + 1]; }
+    return sfa_ctx_sync(ctx);
+}
+
+// ---- host-plane convenience entry points ------------------------------------------------------------------------
+static int variational_host(sfa_ctx *ctx, const sfa_params *p, float *wx, float *wy, int w, int h, int stride, const float *const *frames, int n_frames,
+                            const float *const chw[3], float *occlusions_out, float change[2]) {
+    sfa_job *j = nullptr;
+    SFA_TRY(sfa_job_create(ctx, p, w, h, 1, &j));
+    std::unique_ptr<sfa_job, void (*)(sfa_job *)> guard(j, sfa_job_destroy);
+    SFA_TRY(sfa_job_upload(j, 0, frames, n_frames, wx, wy, stride, chw));
+    SFA_TRY(sfa_job_run(j));
+    SFA_TRY(sfa_job_download(j, 0, wx, wy, stride, change));
+    if (occlusions_out) {
+        Level L0 = j->level(0);
+        SFA_TRY(download_plane(ctx, occlusions_out, stride, L0.plane(P_OCC), L0.pitch, w, h));
+        SFA_TRY(sfa_ctx_sync(ctx));
+    }
+    return SFA_OK;
+}
+
+int sfa_variational(sfa_ctx *ctx, const sfa_params *p, float *wx, float *wy, int w, int h, int stride, const float *const *frames, int n_frames,
+                    const float *const chw[3], float *occlusions_out, float change[2]) {
+    CHECK_ARGS(ctx && p && wx && wy && frames, "null argument");
+    return variational_host(ctx, p, wx, wy, w, h, stride, frames, n_frames, chw, occlusions_out, change);
+}
+
+int sfa_compute_one_level(sfa_ctx *ctx, const sfa_params *p, float *wx, float *wy, int w, int h, int stride, const float *const *frames, int n_frames,
+                          const float *const chw[3], float *occlusions_out, float change[2]) {
+    CHECK_ARGS(ctx && p && wx && wy && frames, "null argument");
+    sfa_params q = *p;
+    q.layers = 1;
+    q.presmooth_sigma = 0;
+    return variational_host(ctx, &q, wx, wy, w, h, stride, frames, n_frames, chw, occlusions_out, change);
+}
+
+}  // extern "C"

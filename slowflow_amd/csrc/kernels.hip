@@ -1,0 +1,935 @@
+// kernels.hip -- pointwise / stencil kernels of the variational level (gfx950, wave64).
+//
+// Every kernel is HBM-bound fp32 planar work: one thread per pixel, x along the wave so that all
+// plane accesses are coalesced 256-B rows; stencil neighbours come through L1/L2 (halo <= 2).
+// Arithmetic is strict IEEE fp32 in the reference's association (no contraction, IEEE div/sqrt).
+// Each __global__ cites the reference operator it implements.
+#include "sfa_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace sfa {
+
+#define BX 64
+#define BY 4
+
+static inline dim3 grid2d(const Geo &g, int zmul = 1) { return dim3((g.w + BX - 1) / BX, (g.h + BY - 1) / BY, g.nb * zmul); }
+static inline dim3 block2d() { return dim3(BX, BY, 1); }
+
+__device__ __forceinline__ bool elem_active(unsigned long long active, int b) { return (active >> b) & 1ull; }
+__device__ __forceinline__ int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
+
+// derivative filter taps as convolution_new builds them (image.c:363-366, variational_mt.cpp:570-573)
+#define C5_0 (1.0f / 12.0f)
+#define C5_1 (-8.0f / 12.0f)
+#define C5_2 (-0.0f)
+#define C5_3 (8.0f / 12.0f)
+#define C5_4 (-(1.0f / 12.0f))
+#define C3_0 (-0.5f)
+#define C3_1 (-0.0f)
+#define C3_2 (0.5f)
+
+// image.c:521
+__device__ __forceinline__ float tap5(float m2, float m1, float c, float p1, float p2) {
+    return C5_0 * m2 + C5_1 * m1 + C5_2 * c + C5_3 * p1 + C5_4 * p2;
+}
+
+// horizontal 5-tap at (x,y) of a plane accessor F(x,y); replicate border (image.c:501-516)
+template <class F>
+__device__ __forceinline__ float d5x(F f, int x, int y, int w) {
+    return tap5(f(clampi(x - 2, 0, w - 1), y), f(clampi(x - 1, 0, w - 1), y), f(x, y), f(clampi(x + 1, 0, w - 1), y), f(clampi(x + 2, 0, w - 1), y));
+}
+// vertical 5-tap with the run-time folded border coefficients (image.c:433-457)
+template <class F>
+__device__ __forceinline__ float d5y(F f, int x, int y, int h) {
+    if (y == 0) return (C5_0 + C5_1 + C5_2) * f(x, 0) + C5_3 * f(x, 1) + C5_4 * f(x, 2);
+    if (y == 1) return (C5_0 + C5_1) * f(x, 0) + C5_2 * f(x, 1) + C5_3 * f(x, 2) + C5_4 * f(x, 3);
+    if (y == h - 2) return C5_0 * f(x, y - 2) + C5_1 * f(x, y - 1) + C5_2 * f(x, y) + (C5_3 + C5_4) * f(x, y + 1);
+    if (y == h - 1) return C5_0 * f(x, y - 2) + C5_1 * f(x, y - 1) + (C5_2 + C5_3 + C5_4) * f(x, y);
+    return tap5(f(x, y - 2), f(x, y - 1), f(x, y), f(x, y + 1), f(x, y + 2));
+}
+// 3-tap (image.c:482, 407-422)
+template <class F>
+__device__ __forceinline__ float d3x(F f, int x, int y, int w) {
+    return C3_0 * f(clampi(x - 1, 0, w - 1), y) + C3_1 * f(x, y) + C3_2 * f(clampi(x + 1, 0, w - 1), y);
+}
+template <class F>
+__device__ __forceinline__ float d3y(F f, int x, int y, int h) {
+    if (y == 0) return (C3_0 + C3_1) * f(x, 0) + C3_2 * f(x, 1);
+    if (y == h - 1) return C3_0 * f(x, y - 1) + (C3_1 + C3_2) * f(x, y);
+    return C3_0 * f(x, y - 1) + C3_1 * f(x, y) + C3_2 * f(x, y + 1);
+}
+
+// IEEE-correct fp32 square root (sqrtps in the reference).  NOT __fsqrt_rn: in this toolchain that is the native
+// approximate instruction (__clang_hip_math.h:302); __builtin_sqrtf is correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt.
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+
+struct PlaneAcc {
+    const float *p; int pitch;
+    __device__ __forceinline__ float operator()(int x, int y) const { return p[(size_t)y * pitch + x]; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// psi'(x^2): penalty_functions headers.  scalar overloads (double inside) and v4sf overloads (fp32).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float psi_vec(const PenaltyDev &p, float xsq) {
+    const float e2 = p.eps * p.eps;
+    switch (p.id) {
+    case 0: return 1.0f;
+    case 2: return __fdiv_rn(1.0f, 2.0f * e2 + xsq);                                   // lorentzian.h:40-42
+    case 3: {                                                                           // trunc_modified_l1_norm.h:47-56
+        float out = __fdiv_rn(1.0f, 2.0f * sqrt_rn(xsq + e2));
+        if (sqrt_rn(xsq) > p.trunc) out = 0.0f;
+        return out;
+    }
+    case 4: {                                                                           // geman_mcclure.h:34-38
+        float t = e2 + xsq;
+        t = t * t;
+        return __fdiv_rn(e2 + 2.0f * xsq, t);
+    }
+    default: return __fdiv_rn(1.0f, 2.0f * sqrt_rn(xsq + e2));                       // modified_l1_norm.h:32-34
+    }
+}
+__device__ __forceinline__ float psi_scalar(const PenaltyDev &p, float xsq) {
+    const float e2f = p.eps * p.eps;
+    const double e2d = (double)e2f;
+    switch (p.id) {
+    case 0: return 1.0f;
+    case 2: return (float)(1.0 / (2.0 * e2d + (double)xsq));                            // lorentzian.h:36-38
+    case 3:                                                                             // trunc_modified_l1_norm.h:40-45 (all float)
+        if (sqrt_rn(xsq) > p.trunc) return 0.0f;
+        return __fdiv_rn(1.0f, 2.0f * sqrt_rn(xsq + e2f));
+    case 4: {                                                                           // geman_mcclure.h:28-32
+        float t = (float)(e2d + (double)xsq);
+        t = t * t;
+        return (float)((e2d + (double)(2.0f * xsq)) / (double)t);
+    }
+    default: return (float)(1.0 / (2.0 * __dsqrt_rn((double)xsq + e2d)));               // modified_l1_norm.h:28-30
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1 image_warp (variational_aux_mt.cpp:722-756)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_warp(float *__restrict__ dst3, float *__restrict__ mask, const float *__restrict__ src3, const float *__restrict__ wx,
+                       const float *__restrict__ wy, Geo g, int factor, long src_es) {
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    dst3 += b * g.es; wx += b * g.es; wy += b * g.es; src3 += b * src_es;
+    const size_t o = (size_t)y * g.pitch + x;
+    if (factor == 0) {                                               // :723-728
+        for (int k = 0; k < 3; k++) dst3[k * g.pl + o] = src3[k * g.pl + o];
+        return;
+    }
+    const float xx = x + factor * wx[o];                             // :735
+    const float yy = y + factor * wy[o];
+    const int xi = (int)floorf(xx), yi = (int)floorf(yy);
+    const float dx = xx - xi, dy = yy - yi;
+    if (mask) mask[b * g.es + o] = (xx >= 0 && xx <= g.w - 1 && yy >= 0 && yy <= g.h - 1) ? 1.0f : 0.0f;   // :742
+    const int x1 = clampi(xi, 0, g.w - 1), x2 = clampi(xi + 1, 0, g.w - 1);
+    const int y1 = clampi(yi, 0, g.h - 1), y2 = clampi(yi + 1, 0, g.h - 1);
+    const float ax = 1.0f - dx, ay = 1.0f - dy;
+    for (int k = 0; k < 3; k++) {
+        const float *s = src3 + k * g.pl;
+        dst3[k * g.pl + o] = s[(size_t)y1 * g.pitch + x1] * ax * ay + s[(size_t)y1 * g.pitch + x2] * dx * ay
+                           + s[(size_t)y2 * g.pitch + x1] * ax * dy + s[(size_t)y2 * g.pitch + x2] * dx * dy;   // :748-753
+    }
+}
+void launch_warp(sfa_ctx *c, const Geo &g, float *dst3, float *mask, const float *src3, const float *wx, const float *wy, int factor, long src_es) {
+    hipLaunchKernelGGL(k_warp, grid2d(g), block2d(), 0, c->stream, dst3, mask, src3, wx, wy, g, factor, src_es);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2/K3 derivative stack of get_derivatives (variational_mt.cpp:113-133)
+//   pass 1: Iz = I1 - I2, Ix = D5x(M), Iy = D5y(M) with M = .5*(I2 + I1) formed on the fly
+//   pass 2: Ixx = D5x(Ix), Ixy = D5y(Ix), Iyy = D5y(Iy), Ixz = D5x(Iz), Iyz = D5y(Iz)
+// out24 plane order: Ix,Iy,Iz,Ixx,Ixy,Iyy,Ixz,Iyz, 3 channels each.
+// ---------------------------------------------------------------------------------------------------
+struct MeanAcc {
+    const float *a, *b; int pitch;   // a = I1, b = I2
+    __device__ __forceinline__ float operator()(int x, int y) const {
+        const size_t o = (size_t)y * pitch + x;
+        return 0.5f * (b[o] + a[o]);                                 // :120
+    }
+};
+
+__global__ void k_deriv1(float *__restrict__ out24, const float *__restrict__ I1, const float *__restrict__ I2, Geo g, long es1, long es2) {
+    const int b = blockIdx.z / 3, ch = blockIdx.z % 3;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const float *a = I1 + b * es1 + ch * g.pl, *bb = I2 + b * es2 + ch * g.pl;
+    float *o24 = out24 + b * g.es;
+    const size_t o = (size_t)y * g.pitch + x;
+    MeanAcc m{a, bb, g.pitch};
+    o24[(0 * 3 + ch) * g.pl + o] = d5x(m, x, y, g.w);                 // Ix  :127
+    o24[(1 * 3 + ch) * g.pl + o] = d5y(m, x, y, g.h);                 // Iy  :128
+    o24[(2 * 3 + ch) * g.pl + o] = a[o] - bb[o];                      // Iz  :122
+}
+__global__ void k_deriv2(float *__restrict__ out24, Geo g) {
+    const int b = blockIdx.z / 3, ch = blockIdx.z % 3;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    float *o24 = out24 + b * g.es;
+    const size_t o = (size_t)y * g.pitch + x;
+    PlaneAcc ix{o24 + (0 * 3 + ch) * g.pl, g.pitch}, iy{o24 + (1 * 3 + ch) * g.pl, g.pitch}, iz{o24 + (2 * 3 + ch) * g.pl, g.pitch};
+    o24[(3 * 3 + ch) * g.pl + o] = d5x(ix, x, y, g.w);                // Ixx :129
+    o24[(4 * 3 + ch) * g.pl + o] = d5y(ix, x, y, g.h);                // Ixy :130
+    o24[(5 * 3 + ch) * g.pl + o] = d5y(iy, x, y, g.h);                // Iyy :131
+    o24[(6 * 3 + ch) * g.pl + o] = d5x(iz, x, y, g.w);                // Ixz :132
+    o24[(7 * 3 + ch) * g.pl + o] = d5y(iz, x, y, g.h);                // Iyz :133
+}
+void launch_deriv_stack(sfa_ctx *c, const Geo &g, float *out24, const float *I1, const float *I2, long es1, long es2) {
+    hipLaunchKernelGGL(k_deriv1, grid2d(g, 3), block2d(), 0, c->stream, out24, I1, I2, g, es1, es2);
+    hipLaunchKernelGGL(k_deriv2, grid2d(g, 3), block2d(), 0, c->stream, out24, g);
+}
+
+// generic single-filter convolution (stage API: convolve_horiz / convolve_vert, image.c:400-526)
+__global__ void k_convolve(float *__restrict__ dst, const float *__restrict__ src, Geo g, int order, int horiz, int nplanes) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    PlaneAcc s{src + b * g.es + pl * g.pl, g.pitch};
+    float v;
+    if (order == 2) v = horiz ? d5x(s, x, y, g.w) : d5y(s, x, y, g.h);
+    else            v = horiz ? d3x(s, x, y, g.w) : d3y(s, x, y, g.h);
+    dst[b * g.es + pl * g.pl + (size_t)y * g.pitch + x] = v;
+}
+void launch_convolve(sfa_ctx *c, const Geo &g, float *dst, const float *src, int order, int horiz, int nplanes) {
+    hipLaunchKernelGGL(k_convolve, grid2d(g, nplanes), block2d(), 0, c->stream, dst, src, g, order, horiz, nplanes);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4 compute_dpsis_weight, first output (variational_aux_mt.cpp:673-719)
+// ---------------------------------------------------------------------------------------------------
+// The reference calls glibc's expf.  glibc (>= 2.27) is NOT correctly rounded (0.502 ulp: ~0.06 % of the arguments
+// round the other way), so a correctly rounded exponential does not reproduce it.  This is glibc's published
+// algorithm (sysdeps/ieee754/flt-32/e_expf.c, from Arm's optimized-routines: N = 32 table of 2^(i/N), degree-3
+// polynomial, all in fp64), restated; tests/test_oracle_pin.py::test_expf_restatement checks the same restatement
+// against libm on 5e5 arguments (0 mismatches).  T[i] = bits(2^(i/32)) - (i << 47).
+__device__ const unsigned long long kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+__device__ __forceinline__ float expf_glibc(float x) {
+    if (x < -0x1.9fe368p6f) return 0.0f;                      // underflow (not reached by the path: x in [-5*|grad lum|, 0])
+    if (x > 0x1.62e42ep6f) return __builtin_inff();
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32, Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double xd = (double)x;
+    double z = InvLn2N * xd;
+    double kd = z + Shift;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= Shift;
+    const double r = z - kd;
+    unsigned long long t = kExp2fTab[ki % 32];
+    t += ki << (52 - 5);
+    const double s = __longlong_as_double((long long)t);
+    z = C0 * r + C1;
+    const double r2 = r * r;
+    double y = C2 * r + 1;
+    y = z * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+struct LumAcc {
+    const float *c1, *c2, *c3; int pitch; float a1, a2, a3, s1, s2, s3; int hbit;
+    __device__ __forceinline__ float operator()(int x, int y) const {
+        const size_t o = (size_t)y * pitch + x;
+        const float v = 0.299f * (c1[o] * s1 + a1) + 0.587f * (c2[o] * s2 + a2) + 0.114f * (c3[o] * s3 + a3);   // :681,683
+        return hbit ? __fdiv_rn(v, 65535.0f) : __fdiv_rn(v, 255.0f);
+    }
+};
+__global__ void k_dpsis(float *__restrict__ dst, const float *__restrict__ im3, Geo g, long im_es, float coef, float a1, float a2, float a3,
+                        float s1, float s2, float s3, int hbit) {
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const float *im = im3 + b * im_es;
+    LumAcc lum{im, im + g.pl, im + 2 * g.pl, g.pitch, a1, a2, a3, s1, s2, s3, hbit};
+    const float lx = d5x(lum, x, y, g.w), ly = d5y(lum, x, y, g.h);
+    const float n = -coef * sqrt_rn(lx * lx + ly * ly);            // :699
+    dst[b * g.es + (size_t)y * g.pitch + x] = 0.5f * expf_glibc(n);          // :700
+}
+void launch_dpsis(sfa_ctx *c, const Geo &g, float *dst, const float *im3, long im_es, float coef, const float avg[3], const float stdv[3], int hbit) {
+    hipLaunchKernelGGL(k_dpsis, grid2d(g), block2d(), 0, c->stream, dst, im3, g, im_es, coef, avg[0], avg[1], avg[2], stdv[0], stdv[1], stdv[2], hbit);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5 compute_smoothness (variational_aux_mt.cpp:18-127)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_smoothness(int method, float *__restrict__ sh, float *__restrict__ sv, const float *__restrict__ uu_, const float *__restrict__ vv_,
+                             const float *__restrict__ dps_, Geo g, float alpha, PenaltyDev reg) {
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.pitch || y >= g.h) return;
+    const size_t o = (size_t)y * g.pitch + x;
+    sh += b * g.es; sv += b * g.es;
+    if (x >= g.w) { sh[o] = 0.0f; sv[o] = 0.0f; return; }            // padding lanes stay zero
+    PlaneAcc uu{uu_ + b * g.es, g.pitch}, vv{vv_ + b * g.es, g.pitch}, dps{dps_ + b * g.es, g.pitch};
+    const int w = g.w, h = g.h;
+    if (method <= 1) {
+        float outh = 0.0f, outv = 0.0f;
+        if (x < w - 1) {
+            const float ux1 = uu(x + 1, y) - uu(x, y), vx1 = vv(x + 1, y) - vv(x, y);     // :27-28
+            float t = 0.0f, t2 = 0.0f;
+            if (method == 1) {
+                t = 0.5f * (d3y(uu, x, y, h) + d3y(uu, x + 1, y, h));                      // :57
+                t2 = 0.5f * (d3y(vv, x, y, h) + d3y(vv, x + 1, y, h));
+            }
+            t = ux1 * ux1 + t * t;                                                       // :61-64
+            t2 = vx1 * vx1 + t2 * t2;
+            t = t + t2;
+            outh = (dps(x, y) + dps(x + 1, y)) * alpha * psi_scalar(reg, t);              // :66
+        }
+        if (y < h - 1) {
+            const float uy1 = uu(x, y + 1) - uu(x, y), vy1 = vv(x, y + 1) - vv(x, y);     // :35-36
+            float t = 0.0f, t2 = 0.0f;
+            if (method == 1) {
+                t = 0.5f * (d3x(uu, x, y, w) + d3x(uu, x, y + 1, w));                      // :80
+                t2 = 0.5f * (d3x(vv, x, y, w) + d3x(vv, x, y + 1, w));
+            }
+            t = uy1 * uy1 + t * t;                                                       // :84-87
+            t2 = vy1 * vy1 + t2 * t2;
+            t = t + t2;
+            outv = (dps(x, y) + dps(x, y + 1)) * alpha * psi_scalar(reg, t);              // :89
+        }
+        sh[o] = outh;                                                                    // :68 zero last column
+        sv[o] = outv;                                                                    // :92 zero last row
+    } else {
+        // :96-116 as written: `float w` shadows the width, so the horizontal test compares x with (weight - 1)
+        float t = 0.0f;
+        float wgt = dps(x, y);
+        if ((float)x < wgt - 1) {
+            const float ux1 = uu(x + 1, y) - uu(x, y), vx1 = vv(x + 1, y) - vv(x, y);
+            t += ux1 * ux1 + vx1 * vx1;
+            wgt += dps(x + 1, y);
+        }
+        if (y < h - 1) {
+            const float uy1 = uu(x, y + 1) - uu(x, y), vy1 = vv(x, y + 1) - vv(x, y);
+            t += vy1 * vy1 + uy1 * uy1;
+            wgt += dps(x, y + 1);
+        }
+        const float v = wgt * alpha * psi_scalar(reg, t);
+        sh[o] = v;
+        sv[o] = v;
+    }
+}
+void launch_smoothness(sfa_ctx *c, const Geo &g, int method, float *sh, float *sv, const float *uu, const float *vv, const float *dpsis, float alpha,
+                       PenaltyDev reg) {
+    dim3 grid((g.pitch + BX - 1) / BX, (g.h + BY - 1) / BY, g.nb);
+    hipLaunchKernelGGL(k_smoothness, grid, block2d(), 0, c->stream, method, sh, sv, uu, vv, dpsis, g, alpha, reg);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sub_laplacian, gather form (variational_aux_mt.cpp:130-161).  The reference scatters edge by edge:
+// all horizontal edges in raster order, then all vertical ones; pixel (x,y) therefore receives
+//   b = (((b - th[x-1]) + th[x]) - tv[y-1]) + tv[y],   th[x] = wh[x]*(src[x+1]-src[x]), tv likewise,
+// with absent border terms skipped (not added as zero).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float laplacian_gather(float bval, const PlaneAcc &src, const PlaneAcc &wh, const PlaneAcc &wv, int x, int y, int w, int h) {
+    const float c = src(x, y);
+    if (x > 0) bval -= wh(x - 1, y) * (c - src(x - 1, y));
+    if (x < w - 1) bval += wh(x, y) * (src(x + 1, y) - c);
+    if (y > 0) bval -= wv(x, y - 1) * (c - src(x, y - 1));
+    if (y < h - 1) bval += wv(x, y) * (src(x, y + 1) - c);
+    return bval;
+}
+__global__ void k_sub_laplacian(float *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ wh, const float *__restrict__ wv, Geo g) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    PlaneAcc s{src + b * g.es, g.pitch}, h_{wh + b * g.es, g.pitch}, v_{wv + b * g.es, g.pitch};
+    const size_t o = b * g.es + (size_t)y * g.pitch + x;
+    dst[o] = laplacian_gather(dst[o], s, h_, v_, x, y, g.w, g.h);
+}
+void launch_sub_laplacian(sfa_ctx *c, const Geo &g, float *dst, const float *src, const float *wh, const float *wv) {
+    hipLaunchKernelGGL(k_sub_laplacian, grid2d(g), block2d(), 0, c->stream, dst, src, wh, wv, g);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mask weighting by occlusion / direction (variational_mt.cpp:293-320)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_mask_weight(float *__restrict__ masks, const float *__restrict__ occ, Geo g, float data_norm, int ref, int one_direction) {
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const size_t o = (size_t)y * g.pitch + x;
+    const float oc = occ[b * g.es + o];
+    float factor = (oc == 0.0f) ? 1.0f : 0.0f;
+    factor = (1 + factor) * data_norm;                                                   // :297
+    const float backward = __fdiv_rn((oc >= 0.0f) ? 1.0f : 0.0f, factor);                // :302
+    const float forward = __fdiv_rn((oc <= 0.0f) ? 1.0f : 0.0f, factor);                 // :303
+    for (int s = one_direction ? ref : 0; s < 2 * ref; s++) {
+        float *m = masks + b * g.es + s * g.pl + o;
+        *m = (s < ref) ? 1.0f * backward * (*m) : 1.0f * forward * (*m);                 // :314,316
+    }
+}
+void launch_mask_weight(sfa_ctx *c, const Geo &g, float *masks, const float *occ, float data_norm, int ref, int one_direction) {
+    hipLaunchKernelGGL(k_mask_weight, grid2d(g), block2d(), 0, c->stream, masks, occ, g, data_norm, ref, one_direction);
+}
+
+__global__ void k_fill(float *p, size_t n, float v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) p[i] = v;
+}
+void launch_fill(sfa_ctx *c, float *p, size_t n, float v) {
+    if (!n) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, c->stream, p, n, v);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K6 data-term assembly: all active add_data_and_match / add_data_and_match_ref terms
+// (variational_aux_mt.cpp:166-403, 408-634; call order of variational_mt.cpp:343-361) accumulated in
+// registers in the reference's order, then sub_laplacian(b1,uu), (b2,vv) (:364-365), one store per plane.
+// ---------------------------------------------------------------------------------------------------
+#define DATANORM (0.1f * 0.1f)   // variational_aux_mt.h:23
+
+struct Acc { float a11, a12, a22, b1, b2; };
+
+struct Px {   // per-pixel inputs of one term
+    float wk[3], ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
+};
+
+__device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u, float v, float hd, float hg, float s, int dt_norm,
+                                          const PenaltyDev &color, const PenaltyDev &grad) {
+    const float factor = s, factorp1 = s + 1;
+    if (hd) {                                                                            // :189
+        float r[3], tx[3], ty[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r[k] = p.wk[k] * (p.iz[k] + p.ix[k] * factor * u + p.iy[k] * factor * v - p.ix[k] * factorp1 * u - p.iy[k] * factorp1 * v);   // :190-192
+            tx[k] = factor * p.ix[k] - factorp1 * p.ix[k];                               // :229-234
+            ty[k] = factor * p.iy[k] - factorp1 * p.iy[k];
+        }
+        if (!dt_norm) {
+            const float t = m * hd * psi_vec(color, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);   // :196
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float t2 = t * p.wk[k];
+                A.a11 += t2 * tx[k] * tx[k];
+                A.a12 += t2 * tx[k] * ty[k];
+                A.a22 += t2 * ty[k] * ty[k];
+                A.b1 -= t2 * p.iz[k] * tx[k];
+                A.b2 -= t2 * p.iz[k] * ty[k];
+            }
+        } else {
+            float n[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) n[k] = tx[k] * tx[k] + ty[k] * ty[k] + DATANORM;   // :236-238
+            const float t = m * hd * psi_vec(color, __fdiv_rn(r[0] * r[0], n[0]) + __fdiv_rn(r[1] * r[1], n[1]) + __fdiv_rn(r[2] * r[2], n[2]));   // :240
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float tk = __fdiv_rn(t, n[k]);
+                tk = tk * p.wk[k];
+                A.a11 += tk * tx[k] * tx[k];                                             // :246-250
+                A.a12 += tk * tx[k] * ty[k];
+                A.a22 += tk * ty[k] * ty[k];
+                A.b1 -= tk * p.iz[k] * tx[k];
+                A.b2 -= tk * p.iz[k] * ty[k];
+            }
+        }
+    }
+    float r[6], X[3], Y[3], Z[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                                                        // :269-276, 316-324
+        r[2 * k] = p.wk[k] * (p.ixz[k] + p.ixx[k] * factor * u + p.ixy[k] * factor * v - p.ixx[k] * factorp1 * u - p.ixy[k] * factorp1 * v);
+        r[2 * k + 1] = p.wk[k] * (p.iyz[k] + p.ixy[k] * factor * u + p.iyy[k] * factor * v - p.ixy[k] * factorp1 * u - p.iyy[k] * factorp1 * v);
+        X[k] = factor * p.ixx[k] - factorp1 * p.ixx[k];
+        Y[k] = factor * p.iyy[k] - factorp1 * p.iyy[k];
+        Z[k] = factor * p.ixy[k] - factorp1 * p.ixy[k];
+    }
+    if (!dt_norm) {
+        const float t = m * hg * psi_vec(grad, r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3] + r[4] * r[4] + r[5] * r[5]);   // :280
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float t2 = t * p.wk[k];
+            A.a11 += t2 * X[k] * X[k] + t2 * Z[k] * Z[k];                                // :287-291
+            A.a12 += t2 * X[k] * Z[k] + t2 * Z[k] * Y[k];
+            A.a22 += t2 * Y[k] * Y[k] + t2 * Z[k] * Z[k];
+            A.b1 -= t2 * p.ixz[k] * X[k] + t2 * p.iyz[k] * Z[k];
+            A.b2 -= t2 * p.iyz[k] * Y[k] + t2 * p.ixz[k] * Z[k];
+        }
+    } else {
+        float n[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            n[2 * k] = X[k] * X[k] + Z[k] * Z[k] + DATANORM;                             // :326-331
+            n[2 * k + 1] = Y[k] * Y[k] + Z[k] * Z[k] + DATANORM;
+        }
+        const float t = m * hg * psi_vec(grad, __fdiv_rn(r[0] * r[0], n[0]) + __fdiv_rn(r[1] * r[1], n[1]) + __fdiv_rn(r[2] * r[2], n[2]) +
+                                                   __fdiv_rn(r[3] * r[3], n[3]) + __fdiv_rn(r[4] * r[4], n[4]) + __fdiv_rn(r[5] * r[5], n[5]));   // :333
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float ta = __fdiv_rn(t, n[2 * k]), tb = __fdiv_rn(t, n[2 * k + 1]);
+            ta = ta * p.wk[k];
+            tb = tb * p.wk[k];
+            A.a11 += ta * X[k] * X[k] + tb * Z[k] * Z[k];                                // :343-347
+            A.a12 += ta * X[k] * Z[k] + tb * Z[k] * Y[k];
+            A.a22 += tb * Y[k] * Y[k] + ta * Z[k] * Z[k];
+            A.b1 -= ta * p.ixz[k] * X[k] + tb * p.iyz[k] * Z[k];
+            A.b2 -= tb * p.iyz[k] * Y[k] + ta * p.ixz[k] * Z[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void term_ref(Acc &A, const Px &p, float m, float u, float v, float hd, float hg, float s, int dt_norm,
+                                         const PenaltyDev &color, const PenaltyDev &grad) {
+    float factor = s;
+    const float factorsq = factor * factor;                                              // :417
+    if (s >= 0) factor = -factor;                                                        // :424-425
+    if (hd) {                                                                            // :439
+        float r[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) r[k] = p.wk[k] * (p.iz[k] + p.ix[k] * factor * u + p.iy[k] * factor * v);   // :441-443
+        if (!dt_norm) {
+            float t = m * hd * psi_vec(color, __fdiv_rn(r[0] * r[0], factorsq) + __fdiv_rn(r[1] * r[1], factorsq) + __fdiv_rn(r[2] * r[2], factorsq));   // :447
+            t = __fdiv_rn(t, factorsq);
+            float t2;
+            t2 = t * p.wk[0] * factor;                                                   // :450-456
+            A.b1 -= t2 * p.iz[0] * p.ix[0];
+            A.b2 -= t2 * p.iz[0] * p.iy[0];
+            t2 = t2 * factor;
+            A.a11 += t2 * p.ix[0] * p.ix[0];
+            A.a12 += t2 * p.ix[0] * p.iy[0];
+            A.a22 += t2 * p.iy[0] * p.iy[0];
+            t2 = t * factor * p.wk[1];                                                   // :458-464
+            A.b1 -= t2 * p.iz[1] * p.ix[1];
+            A.b2 -= t2 * p.iz[1] * p.iy[1];
+            t2 = t2 * factor;
+            A.a11 += t2 * p.ix[1] * p.ix[1];
+            A.a12 += t2 * p.ix[1] * p.iy[1];
+            A.a22 += t2 * p.iy[1] * p.iy[1];
+            t2 = t * factor * p.wk[2];                                                   // :466-472 (sic :469)
+            A.b1 -= t2 * p.iz[2] * p.ix[2];
+            A.b2 -= t2 * p.iz[2] * p.iy[2];
+            t2 = t * factor;
+            A.a11 += t2 * p.ix[2] * p.ix[2];
+            A.a12 += t2 * p.ix[2] * p.iy[2];
+            A.a22 += t2 * p.iy[2] * p.iy[2];
+        } else {
+            float n[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) n[k] = factorsq * p.ix[k] * p.ix[k] + factorsq * p.iy[k] * p.iy[k] + DATANORM;   // :475-477
+            const float t = m * hd * psi_vec(color, __fdiv_rn(r[0] * r[0], n[0]) + __fdiv_rn(r[1] * r[1], n[1]) + __fdiv_rn(r[2] * r[2], n[2]));   // :479
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float tk = __fdiv_rn(t, n[k]);
+                tk = tk * p.wk[k] * factor;                                              // :484-490
+                A.b1 -= tk * p.iz[k] * p.ix[k];
+                A.b2 -= tk * p.iz[k] * p.iy[k];
+                tk = tk * factor;
+                A.a11 += tk * p.ix[k] * p.ix[k];
+                A.a12 += tk * p.ix[k] * p.iy[k];
+                A.a22 += tk * p.iy[k] * p.iy[k];
+            }
+        }
+    }
+    float r[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                                                        // :511-516
+        r[2 * k] = p.wk[k] * (p.ixz[k] + p.ixx[k] * factor * u + p.ixy[k] * factor * v);
+        r[2 * k + 1] = p.wk[k] * (p.iyz[k] + p.ixy[k] * factor * u + p.iyy[k] * factor * v);
+    }
+    if (!dt_norm) {
+        float t = m * hg * psi_vec(grad, __fdiv_rn(r[0] * r[0], factorsq) + __fdiv_rn(r[1] * r[1], factorsq) + __fdiv_rn(r[2] * r[2], factorsq) +
+                                             __fdiv_rn(r[3] * r[3], factorsq) + __fdiv_rn(r[4] * r[4], factorsq) + __fdiv_rn(r[5] * r[5], factorsq));   // :520-521
+        t = __fdiv_rn(t, factorsq);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float t2 = t * p.wk[k] * factor;                                             // :524-526
+            A.b1 -= t2 * p.ixx[k] * p.ixz[k] + t2 * p.ixy[k] * p.iyz[k];
+            A.b2 -= t2 * p.iyy[k] * p.iyz[k] + t2 * p.ixy[k] * p.ixz[k];
+            t2 = t2 * factor;
+            if (k == 0) {                                                                // :528-530 (sic: extra factorsq)
+                A.a11 += t2 * factorsq * p.ixx[k] * p.ixx[k] + t2 * factorsq * p.ixy[k] * p.ixy[k];
+                A.a12 += t2 * factorsq * p.ixx[k] * p.ixy[k] + t2 * factorsq * p.ixy[k] * p.iyy[k];
+                A.a22 += t2 * factorsq * p.iyy[k] * p.iyy[k] + t2 * factorsq * p.ixy[k] * p.ixy[k];
+            } else {                                                                     // :536-538
+                A.a11 += t2 * p.ixx[k] * p.ixx[k] + t2 * p.ixy[k] * p.ixy[k];
+                A.a12 += t2 * p.ixx[k] * p.ixy[k] + t2 * p.ixy[k] * p.iyy[k];
+                A.a22 += t2 * p.iyy[k] * p.iyy[k] + t2 * p.ixy[k] * p.ixy[k];
+            }
+        }
+    } else {
+        float n[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            n[2 * k] = factorsq * p.ixx[k] * p.ixx[k] + factorsq * p.ixy[k] * p.ixy[k] + DATANORM;       // :549-554
+            n[2 * k + 1] = factorsq * p.iyy[k] * p.iyy[k] + factorsq * p.ixy[k] * p.ixy[k] + DATANORM;
+        }
+        const float t = m * hg * psi_vec(grad, __fdiv_rn(r[0] * r[0], n[0]) + __fdiv_rn(r[1] * r[1], n[1]) + __fdiv_rn(r[2] * r[2], n[2]) +
+                                                   __fdiv_rn(r[3] * r[3], n[3]) + __fdiv_rn(r[4] * r[4], n[4]) + __fdiv_rn(r[5] * r[5], n[5]));   // :556
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float ta = __fdiv_rn(t, n[2 * k]), tb = __fdiv_rn(t, n[2 * k + 1]);
+            ta = ta * p.wk[k] * factor;                                                  // :564-572
+            tb = tb * p.wk[k] * factor;
+            A.b1 -= ta * p.ixx[k] * p.ixz[k] + tb * p.ixy[k] * p.iyz[k];
+            A.b2 -= tb * p.iyy[k] * p.iyz[k] + ta * p.ixy[k] * p.ixz[k];
+            ta = ta * factor;
+            tb = tb * factor;
+            A.a11 += ta * p.ixx[k] * p.ixx[k] + tb * p.ixy[k] * p.ixy[k];
+            A.a12 += ta * p.ixx[k] * p.ixy[k] + tb * p.ixy[k] * p.iyy[k];
+            A.a22 += tb * p.iyy[k] * p.iyy[k] + ta * p.ixy[k] * p.ixy[k];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BX *BY) k_assemble(AssembleArgs a, const float *__restrict__ base, float *__restrict__ a11, float *__restrict__ a12,
+                                                      float *__restrict__ a22, float *__restrict__ b1, float *__restrict__ b2, const float *__restrict__ du,
+                                                      const float *__restrict__ dv, const float *__restrict__ uu, const float *__restrict__ vv,
+                                                      const float *__restrict__ sh, const float *__restrict__ sv, Geo g) {
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const size_t o = (size_t)y * g.pitch + x;
+    const long eb = b * g.es;
+    Acc A;
+    if (a.accumulate) { A.a11 = a11[eb + o]; A.a12 = a12[eb + o]; A.a22 = a22[eb + o]; A.b1 = b1[eb + o]; A.b2 = b2[eb + o]; }
+    else { A.a11 = A.a12 = A.a22 = A.b1 = A.b2 = 0.0f; }                                  // image_erase, variational_mt.cpp:336-340
+    const float u = du[eb + o], v = dv[eb + o];
+    Px p;
+    if (a.chw) {
+        // the reference walks the LEVEL-0 weight planes with this level's linear index (variational_aux_mt.cpp:177,366-371)
+        const long lin = (long)y * a.lstride + x;
+        const long r0 = lin / a.chw_stride0, c0 = lin % a.chw_stride0;
+        const float *cw = a.chw + b * a.chw_es + r0 * a.chw_pitch + c0;
+        p.wk[0] = cw[0]; p.wk[1] = cw[a.chw_pl]; p.wk[2] = cw[2 * a.chw_pl];
+    } else { p.wk[0] = p.wk[1] = p.wk[2] = 1.0f; }
+    for (int t = 0; t < a.n; t++) {
+        const Term &T = a.t[t];
+        const float *S = base + eb + T.stack_off + o;
+        const float m = base[eb + T.mask_off + o];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p.ix[k] = S[(0 * 3 + k) * g.pl]; p.iy[k] = S[(1 * 3 + k) * g.pl]; p.iz[k] = S[(2 * 3 + k) * g.pl];
+            p.ixx[k] = S[(3 * 3 + k) * g.pl]; p.ixy[k] = S[(4 * 3 + k) * g.pl]; p.iyy[k] = S[(5 * 3 + k) * g.pl];
+            p.ixz[k] = S[(6 * 3 + k) * g.pl]; p.iyz[k] = S[(7 * 3 + k) * g.pl];
+        }
+        if (T.is_ref) term_ref(A, p, m, u, v, T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
+        else          term_succ(A, p, m, u, v, T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
+    }
+    if (a.do_laplacian) {                                                                // variational_mt.cpp:364-365
+        PlaneAcc U{uu + eb, g.pitch}, V{vv + eb, g.pitch}, H{sh + eb, g.pitch}, W{sv + eb, g.pitch};
+        A.b1 = laplacian_gather(A.b1, U, H, W, x, y, g.w, g.h);
+        A.b2 = laplacian_gather(A.b2, V, H, W, x, y, g.w, g.h);
+    }
+    a11[eb + o] = A.a11; a12[eb + o] = A.a12; a22[eb + o] = A.a22; b1[eb + o] = A.b1; b2[eb + o] = A.b2;
+}
+void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
+                     const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv) {
+    hipLaunchKernelGGL(k_assemble, grid2d(g), block2d(), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, g);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8 flow update + L1 change norms (variational_mt.cpp:371-402, 412-429).  The reference keeps a sequential
+// fp32 running sum; here: fp64 wave __shfl reduction -> block -> one double pair per block, summed by the
+// last stage in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+// block of BX*BY threads = BY waves; returns the block sum in thread 0
+__device__ __forceinline__ void block_sum2(double &a, double &b) {
+    __shared__ double sm[2 * BY];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int wid = threadIdx.y, lane = threadIdx.x;
+    if (lane == 0) { sm[wid] = a; sm[BY + wid] = b; }
+    __syncthreads();
+    if (wid == 0 && lane == 0) {
+        double sa = 0, sb = 0;
+        for (int i = 0; i < BY; i++) { sa += sm[i]; sb += sm[BY + i]; }
+        a = sa; b = sb;
+    }
+}
+
+__global__ void __launch_bounds__(BX *BY) k_update_inner(float *__restrict__ uu, float *__restrict__ vv, const float *__restrict__ wx, const float *__restrict__ wy,
+                                                          const float *__restrict__ du, const float *__restrict__ dv, const float *__restrict__ odu,
+                                                          const float *__restrict__ odv, double *__restrict__ partial, Geo g) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x;
+    double sa = 0, sb = 0;
+    if (elem_active(g.active, b) && x < g.w)
+        for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
+            const size_t o = b * g.es + (size_t)y * g.pitch + x;
+            const float d = du[o], e = dv[o];
+            sa += (double)fabsf(odu[o] - d);                                             // :389-393
+            sb += (double)fabsf(odv[o] - e);
+            uu[o] = wx[o] + d;                                                           // :396-397
+            vv[o] = wy[o] + e;
+        }
+    block_sum2(sa, sb);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
+    }
+}
+__global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx, float *__restrict__ wy, const float *__restrict__ uu, const float *__restrict__ vv,
+                                                          double *__restrict__ partial, Geo g) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x;
+    double sa = 0, sb = 0;
+    if (elem_active(g.active, b) && x < g.w)
+        for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
+            const size_t o = b * g.es + (size_t)y * g.pitch + x;
+            const float u = uu[o], v = vv[o];
+            sa += (double)fabsf(u - wx[o]);                                              // :415-419
+            sb += (double)fabsf(v - wy[o]);
+            wx[o] = u;                                                                   // :428-429
+            wy[o] = v;
+        }
+    block_sum2(sa, sb);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
+    }
+}
+// one block per batch element sums that element's partials in a fixed order
+__global__ void k_reduce_partials(const double *__restrict__ partial, int per_elem, double *__restrict__ out) {
+    const int b = blockIdx.x;
+    double sa = 0, sb = 0;
+    for (int i = threadIdx.x; i < per_elem; i += 256) { sa += partial[2 * ((size_t)b * per_elem + i)]; sb += partial[2 * ((size_t)b * per_elem + i) + 1]; }
+    __shared__ double s0[256], s1[256];
+    s0[threadIdx.x] = sa; s1[threadIdx.x] = sb;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { s0[threadIdx.x] += s0[threadIdx.x + off]; s1[threadIdx.x] += s1[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[2 * b] = s0[0]; out[2 * b + 1] = s1[0]; }
+}
+
+// partial-sum scratch lives behind the result words in ctx->d_red: [0, 2*kMaxBatch) results, then partials
+static double *partials_of(sfa_ctx *c) { return c->d_red + 2 * kMaxBatch; }
+// reduction grids: column strips of BX, at most kRedRows row-blocks that stride over the rows
+constexpr int kRedRows = 16;
+static inline dim3 red_grid(const Geo &g, int z) { return dim3((g.w + BX - 1) / BX, std::min((g.h + BY - 1) / BY, kRedRows), z); }
+
+void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const float *du, const float *dv,
+                         const float *old_du, const float *old_dv, double *red) {
+    dim3 grid = red_grid(g, g.nb);
+    const int per_elem = grid.x * grid.y;
+    hipLaunchKernelGGL(k_update_inner, grid, block2d(), 0, c->stream, uu, vv, wx, wy, du, dv, old_du, old_dv, partials_of(c), g);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
+}
+void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red) {
+    dim3 grid = red_grid(g, g.nb);
+    const int per_elem = grid.x * grid.y;
+    hipLaunchKernelGGL(k_update_outer, grid, block2d(), 0, c->stream, wx, wy, uu, vv, partials_of(c), g);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
+}
+
+__global__ void k_copy_planes(float *__restrict__ dst, const float *__restrict__ src, Geo g, int nplanes, long dst_es, long src_es) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const size_t o = pl * g.pl + (size_t)y * g.pitch + x;
+    dst[b * dst_es + o] = src[b * src_es + o];
+}
+void launch_copy_planes(sfa_ctx *c, const Geo &g, float *dst, const float *src, int nplanes, long dst_es, long src_es) {
+    hipLaunchKernelGGL(k_copy_planes, grid2d(g, nplanes), block2d(), 0, c->stream, dst, src, g, nplanes, dst_es, src_es);
+}
+
+// image_mul_scalar (image.c:49-57)
+__global__ void k_scale_plane(float *__restrict__ p, Geo g, float s) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    p[b * g.es + (size_t)y * g.pitch + x] *= s;
+}
+void launch_scale_plane(sfa_ctx *c, const Geo &g, float *p, float s) {
+    hipLaunchKernelGGL(k_scale_plane, grid2d(g), block2d(), 0, c->stream, p, g, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K9 pyramid: cv::GaussianBlur(Size(0,0), sigma, BORDER_REPLICATE) and cv::resize(INTER_LINEAR) on CV_32F
+// (variational_mt.cpp:607,611,672-673,711-712).  OpenCV is not vendored: documented semantics restated
+// (symmetric separable fp32 taps, rows then columns; half-pixel-centre bilinear), parity unpinned.
+// ---------------------------------------------------------------------------------------------------
+struct Taps { float k[17]; int r; };
+
+__global__ void k_gauss_h(float *__restrict__ dst, const float *__restrict__ src, Geo g, int nplanes, Taps t) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const float *s = src + b * g.es + pl * g.pl + (size_t)y * g.pitch;
+    float acc = t.k[t.r] * s[x];
+    for (int j = 1; j <= t.r; j++) acc += t.k[t.r + j] * (s[clampi(x - j, 0, g.w - 1)] + s[clampi(x + j, 0, g.w - 1)]);
+    dst[b * g.es + pl * g.pl + (size_t)y * g.pitch + x] = acc;
+}
+__global__ void k_gauss_v(float *__restrict__ dst, const float *__restrict__ src, Geo g, int nplanes, Taps t) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const float *s = src + b * g.es + pl * g.pl;
+    float acc = t.k[t.r] * s[(size_t)y * g.pitch + x];
+    for (int j = 1; j <= t.r; j++)
+        acc += t.k[t.r + j] * (s[(size_t)clampi(y - j, 0, g.h - 1) * g.pitch + x] + s[(size_t)clampi(y + j, 0, g.h - 1) * g.pitch + x]);
+    dst[b * g.es + pl * g.pl + (size_t)y * g.pitch + x] = acc;
+}
+void launch_gauss_blur(sfa_ctx *c, const Geo &g, float *dst, float *tmp, const float *src, int nplanes, const float *taps, int radius) {
+    Taps t;
+    t.r = radius;
+    for (int i = 0; i < 2 * radius + 1; i++) t.k[i] = taps[i];
+    hipLaunchKernelGGL(k_gauss_h, grid2d(g, nplanes), block2d(), 0, c->stream, tmp, src, g, nplanes, t);
+    hipLaunchKernelGGL(k_gauss_v, grid2d(g, nplanes), block2d(), 0, c->stream, dst, tmp, g, nplanes, t);
+}
+
+__global__ void k_resize(float *__restrict__ dst, int dw, int dh, int dpitch, long dpl, long des, const float *__restrict__ src, int sw, int sh, int spitch,
+                         long spl, long ses, int nplanes, double scale_x, double scale_y, float post_scale) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    const int dx = blockIdx.x * BX + threadIdx.x, dy = blockIdx.y * BY + threadIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    if (sy < 0) { fy = 0; sy = 0; }
+    if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx, sy1 = sy + 1 < sh ? sy + 1 : sy;
+    const float *s = src + b * ses + pl * spl;
+    const float *r0 = s + (size_t)sy * spitch, *r1 = s + (size_t)sy1 * spitch;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const float h0 = r0[sx] * a0 + r0[sx1] * a1;
+    const float h1 = r1[sx] * a0 + r1[sx1] * a1;
+    float v = h0 * b0 + h1 * b1;
+    if (post_scale != 1.0f) v *= post_scale;                                             // image_mul_scalar after the flow resize (:679-680,716-717)
+    dst[b * des + pl * dpl + (size_t)dy * dpitch + dx] = v;
+}
+void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
+                   int nplanes, int nb, float post_scale) {
+    dim3 grid((dw + BX - 1) / BX, (dh + BY - 1) / BY, nb * nplanes);
+    hipLaunchKernelGGL(k_resize, grid, block2d(), 0, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes,
+                       (double)sw / dw, (double)sh / dh, post_scale);
+}
+
+// optional level-0 Gaussian presmoothing (cfg sigma > 0, variational_mt.cpp:590-597): gaussian_filter
+// (image.c:310-348) + the generic convolve_horiz / convolve_vert (image.c:537-644), whose border handling
+// uses the accumulated coefficients.
+struct PreTaps { float c[33]; float accu[33]; int order; };
+__global__ void k_presmooth_h(float *__restrict__ dst, const float *__restrict__ src, Geo g, int nplanes, PreTaps t) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    const int i = blockIdx.x * BX + threadIdx.x, j = blockIdx.y * BY + threadIdx.y;
+    if (i >= g.w || j >= g.h) return;
+    const float *row = src + b * g.es + pl * g.pl + (size_t)j * g.pitch;
+    const int i0 = -t.order, i1 = t.order;
+    const float *coeff = t.c + t.order, *coeff_accu = t.accu + t.order;
+    float sum;
+    if (i < -i0) {                                                                       // image.c:550-556
+        sum = coeff_accu[-i - 1] * row[0];
+        for (int ii = i1 + i; ii >= 0; ii--) sum += coeff[ii - i] * row[ii];
+    } else if (i < g.w - i1) {                                                           // image.c:558-565
+        const float *al = row + (i + i0);
+        sum = 0;
+        for (int ii = i1 - i0; ii >= 0; ii--) sum += t.c[ii] * al[ii];
+    } else {                                                                             // image.c:567-574
+        const float *al = row + (i + i0);
+        sum = coeff_accu[g.w - i] * al[g.w - i0 - 1 - i];
+        for (int ii = g.w - i0 - 1 - i; ii >= 0; ii--) sum += t.c[ii] * al[ii];
+    }
+    dst[b * g.es + pl * g.pl + (size_t)j * g.pitch + i] = sum;
+}
+__global__ void k_presmooth_v(float *__restrict__ dst, const float *__restrict__ src, Geo g, int nplanes, PreTaps t) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    const int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y;   // j = column, i = row
+    if (j >= g.w || i >= g.h) return;
+    const float *in = src + b * g.es + pl * g.pl;
+    const int i0 = -t.order, i1 = t.order, st = g.pitch;
+    const float *coeff = t.c + t.order, *coeff_accu = t.accu + t.order;
+    float sum;
+    if (i < -i0) {                                                                       // image.c:600-609
+        sum = coeff_accu[-i - 1] * in[j];
+        for (int ii = -i; ii <= i1; ii++) sum += coeff[ii] * in[(size_t)(i + ii) * st + j];
+    } else if (i < g.h - i1) {                                                           // image.c:615-626
+        sum = 0;
+        for (int ii = 0; ii <= i1 - i0; ii++) sum += t.c[ii] * in[(size_t)(i + i0 + ii) * st + j];
+    } else {                                                                             // image.c:631-640
+        sum = coeff_accu[g.h - i] * in[(size_t)(g.h - 1) * st + j];
+        for (int ii = i0; ii <= g.h - 1 - i; ii++) sum += coeff[ii] * in[(size_t)(i + ii) * st + j];
+    }
+    dst[b * g.es + pl * g.pl + (size_t)i * st + j] = sum;
+}
+void launch_presmooth(sfa_ctx *c, const Geo &g, float *dst, float *tmp, const float *src, int nplanes, float sigma) {
+    PreTaps t;
+    int order = (int)floor(3 * sigma) + 1;                                               // image.c:320
+    if (order == 0) order = 1;
+    if (order > 16) order = 16;
+    t.order = order;
+    const int n = 2 * order + 1;
+    float data[33];
+    const float alpha = 1.0f / (2.0f * sigma * sigma);
+    float sum = 0.0f;
+    for (int i = -order; i <= order; i++) { data[i + order] = (float)exp(-i * i * alpha); sum += data[i + order]; }   // image.c:332-335
+    for (int i = 0; i < n; i++) data[i] /= sum;
+    const float *half = data + order;
+    for (int i = 0; i <= order; i++) t.c[order - i] = t.c[order + i] = half[i];          // image.c:355-357
+    float acc = 0.0f;
+    for (int i = 0; i <= order; i++) { acc += t.c[i]; t.accu[2 * order - i] = t.accu[i] = acc; }   // image.c:358-361
+    hipLaunchKernelGGL(k_presmooth_h, grid2d(g, nplanes), block2d(), 0, c->stream, tmp, src, g, nplanes, t);
+    hipLaunchKernelGGL(k_presmooth_v, grid2d(g, nplanes), block2d(), 0, c->stream, dst, tmp, g, nplanes, t);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// normalize (variational_mt.cpp:17-85): per-channel sum and sum of squares (float product, double sum)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BX *BY) k_norm_sums(const float *__restrict__ frames3, double *__restrict__ partial, Geo g) {
+    const int ch = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x;
+    double sa = 0, sb = 0;
+    if (x < g.w)
+        for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
+            const float v = frames3[ch * g.pl + (size_t)y * g.pitch + x];
+            sa += (double)v;                                                             // :32-34
+            sb += (double)(v * v);                                                       // :35-37
+        }
+    block_sum2(sa, sb);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const size_t blk = ((size_t)ch * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
+    }
+}
+void launch_normalize_sums(sfa_ctx *c, const Geo &g, const float *frames3, double *red) {
+    dim3 grid = red_grid(g, 3);
+    hipLaunchKernelGGL(k_norm_sums, grid, block2d(), 0, c->stream, frames3, partials_of(c), g);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, c->stream, partials_of(c), (int)(grid.x * grid.y), red);
+}
+__global__ void k_norm_apply(float *__restrict__ frames3, Geo g, double a0, double a1, double a2, double s0, double s1, double s2) {
+    const int ch = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const double a = ch == 0 ? a0 : (ch == 1 ? a1 : a2), s = ch == 0 ? s0 : (ch == 1 ? s1 : s2);
+    if (!(s > 0)) return;                                                                // :64-66
+    float *p = frames3 + ch * g.pl + (size_t)y * g.pitch + x;
+    *p = (float)(((double)*p - a) / s);
+}
+void launch_normalize_apply(sfa_ctx *c, const Geo &g, float *frames3, const double avg[3], const double stdv[3]) {
+    dim3 grid((g.w + BX - 1) / BX, (g.h + BY - 1) / BY, 3);
+    hipLaunchKernelGGL(k_norm_apply, grid, block2d(), 0, c->stream, frames3, g, avg[0], avg[1], avg[2], stdv[0], stdv[1], stdv[2]);
+}
+
+}  // namespace sfa

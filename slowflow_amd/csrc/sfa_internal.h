@@ -1,0 +1,150 @@
+// sfa_internal.h -- internal declarations of libslowflow_amd (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/slowflow_amd.h"
+
+#pragma clang fp contract(off)   // the reference is strict fp32 without FMA contraction (CMakeLists.txt:6)
+
+namespace sfa {
+
+constexpr int kMaxBatch = 64;
+constexpr int kMaxTerms = 4 * SFA_MAX_REF;
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+struct DevBlock { void *p; size_t bytes; };
+
+}  // namespace sfa
+
+struct sfa_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scratch for reductions / flags
+    double *d_red = nullptr;      // device, kRedDoubles doubles
+    double *h_red = nullptr;      // pinned host mirror
+    unsigned *d_err = nullptr;    // device error/timeout word
+    // profiling of the SOR solve kernel
+    bool profile = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t ev_used = 0;
+    double sor_bytes = 0;         // algorithmic bytes of the bracketed launches
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // default-ctx bookkeeping
+    int cu_count = 256;
+};
+
+namespace sfa {
+
+constexpr int kRedDoubles = 1 << 18;   // 2*kMaxBatch result words + per-block partials (<= 64 x 128 x 16 blocks)
+
+int set_error(sfa_ctx *ctx, int code, const char *fmt, ...);
+extern thread_local std::string g_thread_err;
+
+#define SFA_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return sfa::set_error((ctx), SFA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define SFA_TRY(expr)            \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != SFA_OK) return _rc; \
+    } while (0)
+
+inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
+inline int host_stride(int w) { return ((w + 3) / 4) * 4; }     // image.c:25
+inline int dev_pitch(int w) { return round_up(w, 64); }         // device rows are 256-B aligned
+
+// RAII device allocation
+struct DevMem {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevMem() = default;
+    DevMem(const DevMem &) = delete;
+    DevMem &operator=(const DevMem &) = delete;
+    ~DevMem() { release(); }
+    int alloc(sfa_ctx *ctx, size_t n);
+    void release();
+    float *f() const { return static_cast<float *>(p); }
+};
+
+// host <-> device plane copies (valid columns only unless full_stride)
+int upload_plane(sfa_ctx *ctx, float *dev, int pitch, const float *host, int stride, int w, int h);
+int download_plane(sfa_ctx *ctx, float *host, int stride, const float *dev, int pitch, int w, int h);
+
+// ---------------------------------------------------------------------------------------------------
+// kernel launchers (kernels.hip).  All planes are device pointers of batch element 0; element b lives
+// `es` floats further (es = 0 for a single element).  `nb` = batch size, `active` = bit mask of the
+// elements that still iterate (threshold breaks).
+// ---------------------------------------------------------------------------------------------------
+struct Geo { int w, h, pitch; long pl; long es; int nb; unsigned long long active; };   // pl = pitch*h
+
+struct PenaltyDev { int id; float eps, trunc; };
+
+void launch_warp(sfa_ctx *c, const Geo &g, float *dst3, float *mask, const float *src3, const float *wx, const float *wy, int factor,
+                 long src_es /* batch stride of src3 (frames) */);
+void launch_deriv_stack(sfa_ctx *c, const Geo &g, float *out24, const float *I1, const float *I2, long es1, long es2);
+void launch_convolve(sfa_ctx *c, const Geo &g, float *dst, const float *src, int order, int horiz, int nplanes);
+void launch_dpsis(sfa_ctx *c, const Geo &g, float *dst, const float *im3, long im_es, float coef, const float avg[3], const float stdv[3], int hbit);
+void launch_smoothness(sfa_ctx *c, const Geo &g, int method, float *sh, float *sv, const float *uu, const float *vv, const float *dpsis,
+                       float alpha, PenaltyDev reg);
+void launch_sub_laplacian(sfa_ctx *c, const Geo &g, float *dst, const float *src, const float *wh, const float *wv);
+void launch_mask_weight(sfa_ctx *c, const Geo &g, float *masks, const float *occ, float data_norm, int ref, int one_direction);
+void launch_fill(sfa_ctx *c, float *p, size_t n, float v);
+
+struct Term { long stack_off; long mask_off; float hd, hg, s; int is_ref; };
+struct AssembleArgs {
+    Term t[kMaxTerms];
+    int n;
+    int dt_norm;
+    PenaltyDev color, grad;
+    // channel weights: NULL => ones.  chw planes live OUTSIDE the element arena stride logic: chw_es batch stride
+    const float *chw; long chw_pl; long chw_es; int chw_pitch; int chw_stride0; int lstride;
+    int accumulate;      // 1: add to existing a11.. (stage API), 0: start from zero
+    int do_laplacian;    // apply sub_laplacian(b1,uu), (b2,vv) at the end
+};
+void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base /*element arena of batch 0*/, float *a11, float *a12,
+                     float *a22, float *b1, float *b2, const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv);
+
+// du/dv -> uu,vv, zero padding, L1 change norms (variational_mt.cpp:371-402); red = per-element 2 doubles (sum|old_du-du|, sum|old_dv-dv|)
+void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const float *du, const float *dv,
+                         const float *old_du, const float *old_dv, double *red /* [nb][2] */);
+// sum|uu-wx|, sum|vv-wy|; wx<-uu, wy<-vv (variational_mt.cpp:412-429)
+void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red);
+void launch_copy_planes(sfa_ctx *c, const Geo &g, float *dst, const float *src, int nplanes, long dst_es, long src_es);
+void launch_scale_plane(sfa_ctx *c, const Geo &g, float *p, float s);
+
+// pyramid (kernels.hip)
+void launch_gauss_blur(sfa_ctx *c, const Geo &g, float *dst, float *tmp, const float *src, int nplanes, const float *taps, int radius);
+void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
+                   int nplanes, int nb, float post_scale);
+void launch_presmooth(sfa_ctx *c, const Geo &g, float *dst, float *tmp, const float *src, int nplanes, float sigma);
+void launch_normalize_sums(sfa_ctx *c, const Geo &g, const float *frames3, double *red /* [3][2] */);
+void launch_normalize_apply(sfa_ctx *c, const Geo &g, float *frames3, const double avg[3], const double stdv[3]);
+
+// ---------------------------------------------------------------------------------------------------
+// SOR (sor.hip)
+// ---------------------------------------------------------------------------------------------------
+struct SorWorkspace {
+    sfa_ctx *ctx = nullptr;
+    int w = 0, h = 0, K = 0, nb = 0;
+    int NB = 0, RP = 0, ND = 0, G = 0, NS = 0, NCH = 0, ntasks = 0;
+    long ent = 0;                 // entries per element (ND*RP)
+    DevMem sa, sb, x, flags, order;
+    int configure(sfa_ctx *ctx, int w, int h, int K, int nb);   // (re)allocates for this shape
+};
+// planes: row-major device planes of element 0 (+es).  inv_out: write the inverted blocks back to a11/a12/a22
+int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
+            const float *sh, const float *sv, int K, float omega, bool inv_out);
+
+}  // namespace sfa

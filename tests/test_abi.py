@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the HIP library builds for gfx950, loads, exports every symbol that
+include/slowflow_amd.h declares, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import slowflow_amd as sfa
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    if not os.path.exists(sfa.LIB_PATH):
+        sfa.build()
+    return sfa.LIB_PATH
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "slowflow_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(sfa_[a-z0-9_]+|sor_coupled)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_symbols_exported(libpath):
+    L = C.CDLL(libpath)
+    decl = declared_symbols()
+    assert len(decl) >= 30
+    missing = [n for n in decl if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(set(sfa.EXPORTS)) == decl
+
+
+def test_struct_layouts_match_reference_images():
+    # image_t: int width,height,stride; float* data (epic_flow_extended/image.h:17-23)
+    assert C.sizeof(sfa.Image) == 24 and sfa.Image.data.offset == 16
+    assert C.sizeof(sfa.Params) == C.sizeof(C.c_int) * 8 + 4 * 6 + 12 * 3 + 16 * 2 + 4 + 12 * 2 + 4 * 4
+
+
+def test_params_default_matches_driver_defaults(libpath):
+    p = sfa.default_params()       # slow_flow.cpp:64-128
+    assert (p.S, p.smoothing, p.dataterm_norm, p.niter_alter, p.niter_outer, p.niter_inner, p.niter_solver) == (2, 1, 1, 10, 10, 1, 30)
+    assert abs(p.sor_omega - 1.9) < 1e-6 and p.alpha == 4.0 and p.gamma == 6.0 and p.delta == 1.0
+    assert p.robust_color.id == 1 and abs(p.robust_color.eps - 0.001) < 1e-9
+    assert list(p.omega)[:2] == [0.0, 2.0] and p.layers == 1 and abs(p.p_scale - 0.9) < 1e-6
+
+
+def test_pyramid_sizes_host_logic(libpath):
+    L = sfa.lib()
+    ws, hs = (C.c_int * 64)(), (C.c_int * 64)()
+    n = L.sfa_pyramid_sizes(1024, 436, 5, C.c_float(0.9), ws, hs)
+    assert n == 5
+    assert [ws[i] for i in range(5)] == [1024, 921, 828, 745, 670]
+    assert [hs[i] for i in range(5)] == [436, 392, 352, 316, 284]
+    n = L.sfa_pyramid_sizes(2048, 2048, 6, C.c_float(0.9), ws, hs)
+    assert [ws[i] for i in range(n)] == [2048, 1843, 1658, 1492, 1342, 1207]
+    n = L.sfa_pyramid_sizes(256, 256, 4, C.c_float(0.9), ws, hs)
+    assert [ws[i] for i in range(n)] == [256, 230, 207, 186]
+    # the size break: levels stop when floor(w*p) <= order+1 = 4 (variational_mt.cpp:647)
+    n = L.sfa_pyramid_sizes(9, 9, 10, C.c_float(0.9), ws, hs)
+    assert 1 <= n < 10
+
+
+def test_pyramid_sizes_match_oracle(libpath, oracle):
+    L = sfa.lib()
+    ws, hs = (C.c_int * 64)(), (C.c_int * 64)()
+    for (w, h, layers, p) in [(1024, 436, 5, 0.9), (67, 45, 8, 0.9), (130, 98, 6, 0.8), (33, 200, 30, 0.95)]:
+        n = L.sfa_pyramid_sizes(w, h, layers, C.c_float(p), ws, hs)
+        assert [(ws[i], hs[i]) for i in range(n)] == oracle.pyramid_sizes(w, h, layers, p)
+
+
+def test_no_cpu_fallback(libpath):
+    """Without a GPU the product must fail loudly; with one this test is vacuous (covered by the gpu tests)."""
+    if sfa.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sfa.SlowflowError) as e:
+        sfa.Context(0)
+    assert "no HIP device" in str(e.value) or "-3" in str(e.value)
+
+
+def test_product_does_not_touch_the_oracle():
+    """the product path may not import, link or call anything under oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "slowflow_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "slowflow_oracle" not in txt and "import oracle" not in txt and "orc_" not in txt, fn

@@ -1,0 +1,471 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle on the same seeded inputs, against the committed
+golden vectors, and -- at BASELINE.json's full sizes -- through properties.  fp32 everywhere; the bar is
+bit-identical (IEEE ==) for every stage except where noted, and <= 1e-4 max-abs on (u,v) for the whole path
+(north_star).  Needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import slowflow_amd as sfa
+from synth import copy_sys, noise_color, noise_plane, smooth_noise_color, sor_system, texture_frame
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz"))
+TOL_UV = 1e-4          # north_star: (u,v) within 1e-4 max-abs of the CPU reference
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sfa.Context(0)
+    yield c
+    c.close()
+
+
+def valid(a, w):
+    return a[..., :w]
+
+
+def c_(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def mk_params(o, **kw):
+    """oracle params and the layout-identical product params"""
+    po = o.default_params()
+    ps = sfa.default_params()
+    for p in (po, ps):
+        p.niter_alter = 1; p.niter_outer = 3; p.occlusion_reasoning = 0; p.thres_outer = 0; p.thres_inner = 0; p.hbit = 0
+        for k, v in kw.items():
+            if k in ("rho", "omega"):
+                for i, x in enumerate(v):
+                    getattr(p, k)[i] = x
+            elif k in ("robust_color", "robust_grad", "robust_reg"):
+                getattr(p, k).id, getattr(p, k).eps, getattr(p, k).trunc = v
+            elif k in ("norm_avg", "norm_std"):
+                for i, x in enumerate(v):
+                    getattr(p, k)[i] = x
+            else:
+                setattr(p, k, v)
+    return po, ps
+
+
+# ------------------------------------------------------------------------------------------------------
+# stages
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (130, 98), (5, 4)])
+def test_convolve(ctx, oracle, w, h):
+    rng = np.random.default_rng(w * h)
+    src = noise_plane(rng, w, h, -3, 3)
+    for order in (1, 2):
+        for horiz in (True, False):
+            assert np.array_equal(valid(ctx.convolve(c_(src), w, order, horiz), w), valid(oracle.convolve(src, w, order, horiz), w))
+
+
+def test_convolve_golden(ctx):
+    for (w, h) in ((67, 45), (64, 48)):
+        src = c_(G[f"conv_{w}x{h}_src"])
+        for order in (1, 2):
+            for horiz in (0, 1):
+                assert np.array_equal(valid(ctx.convolve(src, w, order, horiz), w), G[f"conv_{w}x{h}_o{order}_h{horiz}"][:, :w])
+
+
+@pytest.mark.parametrize("factor", [-2, -1, 0, 1, 2, 3])
+def test_image_warp(ctx, oracle, factor):
+    w, h = 130, 98
+    rng = np.random.default_rng(factor + 10)
+    src = smooth_noise_color(rng, w, h)
+    wx, wy = noise_plane(rng, w, h, -4, 4), noise_plane(rng, w, h, -4, 4)
+    wx[0, :5] = 1000; wy[1, :5] = -1000
+    a, ma = oracle.image_warp(src, wx, wy, w, factor)
+    b, mb = ctx.image_warp(c_(src), c_(wx), c_(wy), w, factor)
+    assert np.array_equal(valid(a, w), valid(b, w))
+    if factor != 0:
+        assert np.array_equal(valid(ma, w), valid(mb, w))
+
+
+def test_image_warp_golden(ctx):
+    w = 67
+    for factor in (-2, -1, 1, 2):
+        d, m = ctx.image_warp(c_(G["warp_src"]), c_(G["warp_wx"]), c_(G["warp_wy"]), w, factor)
+        assert np.array_equal(d[..., :w], G[f"warp_f{factor}_dst"][..., :w])
+        assert np.array_equal(m[:, :w], G[f"warp_f{factor}_mask"][:, :w])
+
+
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (35, 21)])
+def test_derivative_stack(ctx, oracle, w, h):
+    rng = np.random.default_rng(w + h)
+    I1, I2 = smooth_noise_color(rng, w, h), smooth_noise_color(rng, w, h)
+    assert np.array_equal(valid(ctx.derivative_stack(c_(I1), c_(I2), w), w), valid(oracle.derivative_stack(I1, I2, w), w))
+
+
+def test_derivative_stack_golden(ctx):
+    w2 = 35
+    st = ctx.derivative_stack(c_(G["stack_I1"]), c_(G["stack_I2"]), w2)
+    assert np.array_equal(st[..., :w2], G["stack_out"][..., :w2])
+
+
+def test_dpsis_weight(ctx, oracle):
+    """expf is glibc's algorithm restated on the device (glibc is not correctly rounded): expect bit equality; a
+    different libm variant on the host (FMA ifunc) may flip ~1e-9 of the results by one ulp"""
+    w, h = 130, 98
+    rng = np.random.default_rng(1)
+    im = smooth_noise_color(rng, w, h)
+    for (avg, std, hbit) in (((0, 0, 0), (1, 1, 1), 0), ((127.3, 120.1, 99.9), (0.178, 0.21, 0.19), 0), ((3000, 2000, 1000), (40, 30, 50), 1)):
+        a = valid(oracle.dpsis_weight(im, w, avg, std, hbit), w)
+        b = valid(ctx.dpsis_weight(c_(im), w, avg, std, hbit), w)
+        ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1
+        assert (ulp > 0).mean() < 1e-5
+    assert np.array_equal(valid(ctx.dpsis_weight(c_(G["dpsis_im"]), 67), 67), G["dpsis_out"][:, :67])
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("pid", [0, 1, 2, 3, 4])
+def test_smoothness(ctx, oracle, method, pid):
+    w, h = 67, 45
+    rng = np.random.default_rng(method * 10 + pid)
+    uu, vv = noise_plane(rng, w, h, -2, 2), noise_plane(rng, w, h, -2, 2)
+    dps = noise_plane(rng, w, h, 0.05, 0.5)
+    eps = 0.001 if pid in (1, 3) else 0.05
+    a = oracle.smoothness(method, uu, vv, dps, w, 4.0, orc.Penalty(pid, eps, 0.5))
+    b = ctx.smoothness(method, c_(uu), c_(vv), c_(dps), w, 4.0, sfa.Penalty(pid, eps, 0.5))
+    for x, y in zip(a, b):
+        assert np.array_equal(valid(x, w), valid(y, w))
+
+
+def test_sub_laplacian(ctx, oracle):
+    w, h = 67, 45
+    rng = np.random.default_rng(4)
+    src, wh, wv, d0 = noise_plane(rng, w, h), noise_plane(rng, w, h, 0, 2), noise_plane(rng, w, h, 0, 2), noise_plane(rng, w, h)
+    a = orc.plane(*d0.shape); a[...] = d0
+    oracle.sub_laplacian(a, src, wh, wv, w)
+    b = ctx.sub_laplacian(c_(d0).copy(), c_(src), c_(wh), c_(wv), w)
+    assert np.array_equal(valid(a, w), valid(b, w))
+    d = ctx.sub_laplacian(c_(G["sublap_dst0"]).copy(), c_(G["sublap_src"]), c_(G["sublap_wh"]), c_(G["sublap_wv"]), 67)
+    assert np.array_equal(d[:, :67], G["sublap_dst"][:, :67])
+
+
+@pytest.mark.parametrize("ref_term", [False, True])
+@pytest.mark.parametrize("dt_norm", [0, 1])
+@pytest.mark.parametrize("pid", [0, 1, 2, 3, 4])
+def test_data_terms(ctx, oracle, ref_term, dt_norm, pid):
+    w, h = 67, 45
+    rng = np.random.default_rng(pid + 7 * dt_norm + 13 * ref_term)
+    I1, I2 = smooth_noise_color(rng, w, h, 10), smooth_noise_color(rng, w, h, 10)
+    D = oracle.derivative_stack(I1, I2, w)
+    du, dv = noise_plane(rng, w, h, -.5, .5), noise_plane(rng, w, h, -.5, .5)
+    mask = noise_plane(rng, w, h, 0, 1)
+    mask[:, :w] = (mask[:, :w] > 0.2) * 0.5
+    chw = [noise_plane(rng, w, h, 0.5, 1.5) for _ in range(3)]
+    eps = 0.001 if pid in (1, 3) else 0.05
+    for s in ((-2.0, -1.0, 1.0, 2.0) if ref_term else (-2.0, -1.0, 0.0, 1.0)):
+        for hd in (0.0, 1.0 / 3.0):
+            sys_o = [noise_plane(rng, w, h) for _ in range(5)]
+            sys_g = [c_(x).copy() for x in sys_o]
+            rc_o = oracle.add_data(sys_o, mask, du, dv, D, chw, w, hd, 2.0, s, dt_norm, orc.Penalty(pid, eps, 0.5), orc.Penalty(pid, eps, 0.5), ref_term)
+            rc_g = ctx.add_data(sys_g, c_(mask), c_(du), c_(dv), c_(D), [c_(x) for x in chw], w, hd, 2.0, s, dt_norm, sfa.Penalty(pid, eps, 0.5),
+                                sfa.Penalty(pid, eps, 0.5), ref_term)
+            assert rc_g == 0 and (rc_o in (0, None))
+            for x, y, n in zip(sys_o, sys_g, ["a11", "a12", "a22", "b1", "b2"]):
+                assert np.array_equal(valid(x, w), valid(y, w)), (n, s, hd)
+
+
+def test_data_term_ref_rejects_reference_frame(ctx, oracle):
+    w, h = 16, 8
+    z = np.zeros((h, 16), np.float32)
+    D = np.zeros((8, 3, h, 16), np.float32)
+    rc = ctx.add_data([z.copy() for _ in range(5)], z, z, z, D, None, w, 1.0, 1.0, 0.0, 1, sfa.Penalty(1, .001, .5), sfa.Penalty(1, .001, .5), True)
+    assert rc == -4        # SFA_ERR_REF_FRAME: the logic_error of variational_aux_mt.cpp:419
+
+
+# ------------------------------------------------------------------------------------------------------
+# SOR
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (130, 98), (3, 7), (2, 2), (200, 3), (1, 9), (300, 70)])
+@pytest.mark.parametrize("K,omega", [(1, 1.9), (2, 1.9), (30, 1.9), (5, 1.0)])
+def test_sor_vs_oracle(ctx, oracle, w, h, K, omega):
+    rng = np.random.default_rng(w * 7 + h * 3 + K)
+    s0 = sor_system(rng, w, h)
+    s0["du"][:, :w] = rng.uniform(-.2, .2, (h, w)); s0["dv"][:, :w] = rng.uniform(-.2, .2, (h, w))
+    a = copy_sys(s0)
+    oracle.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, K, omega)
+    b = {k: c_(v).copy() for k, v in s0.items()}
+    ctx.sor_coupled(b["du"], b["dv"], b["a11"], b["a12"], b["a22"], b["b1"], b["b2"], b["sh"], b["sv"], w, K, omega)
+    for k in ("du", "dv"):
+        assert np.array_equal(valid(a[k], w), valid(b[k], w)), k
+    if w >= 2 and h >= 2:
+        for k in ("a11", "a12", "a22"):     # in-place inverted blocks, solver.c:104-106
+            assert np.array_equal(valid(a[k], w), valid(b[k], w)), k
+
+
+def test_sor_generic_planes(ctx, oracle):
+    """the drop-in accepts any planes: non-zero last column / row weights, non-zero start"""
+    w, h = 37, 21
+    rng = np.random.default_rng(5)
+    s0 = sor_system(rng, w, h)
+    for k in ("sh", "sv", "du", "dv"):
+        s0[k][:, :] = rng.uniform(0.1, 1, s0[k].shape)
+    a = copy_sys(s0)
+    oracle.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, 7, 1.9)
+    b = {k: c_(v).copy() for k, v in s0.items()}
+    ctx.sor_coupled(b["du"], b["dv"], b["a11"], b["a12"], b["a22"], b["b1"], b["b2"], b["sh"], b["sv"], w, 7, 1.9)
+    assert np.array_equal(valid(a["du"], w), valid(b["du"], w)) and np.array_equal(valid(a["dv"], w), valid(b["dv"], w))
+
+
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48)])
+def test_sor_golden(ctx, w, h):
+    for K in (1, 2, 30):
+        s = {k: c_(G[f"sor_{w}x{h}_in_{k}"]).copy() for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")}
+        ctx.sor_coupled(s["du"], s["dv"], s["a11"], s["a12"], s["a22"], s["b1"], s["b2"], s["sh"], s["sv"], w, K, 1.9)
+        assert np.array_equal(s["du"][:, :w], G[f"sor_{w}x{h}_K{K}_du"][:, :w])
+        assert np.array_equal(s["dv"][:, :w], G[f"sor_{w}x{h}_K{K}_dv"][:, :w])
+
+
+def test_sor_full_size_and_batch(ctx, oracle):
+    """1024x436, K=30 (the metric's configuration): bit-identical to the raster-order oracle, for every element of a
+    batch of different systems solved by one launch; repeated runs are deterministic."""
+    w, h, K, nb = 1024, 436, 30, 3
+    rng = np.random.default_rng(42)
+    systems = [sor_system(rng, w, h) for _ in range(nb)]
+    sb = sfa.SorBatch(ctx, w, h, nb)
+    for b, s in enumerate(systems):
+        sb.upload(b, *[c_(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb.run(K, 1.9)
+    outs = [sb.download(b) for b in range(nb)]
+    for b, s in enumerate(systems):
+        a = copy_sys(s)
+        oracle.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, K, 1.9)
+        assert np.array_equal(valid(a["du"], w), valid(outs[b][0], w))
+        assert np.array_equal(valid(a["dv"], w), valid(outs[b][1], w))
+    # the batch run inverted a11.. in place on the device: re-upload and run again -> same answer
+    for b, s in enumerate(systems):
+        sb.upload(b, *[c_(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb.run(K, 1.9)
+    for b in range(nb):
+        du, dv = sb.download(b)
+        assert np.array_equal(du, outs[b][0]) and np.array_equal(dv, outs[b][1])
+    sb.close()
+
+
+def test_sor_fixed_point_property(ctx):
+    """size-independent property: started from the converged solution one more sweep changes nothing beyond rounding,
+    and the residual of the original system is small"""
+    w, h = 1024, 436
+    rng = np.random.default_rng(3)
+    s = sor_system(rng, w, h)
+    b = {k: c_(v).copy() for k, v in s.items()}
+    ctx.sor_coupled(b["du"], b["dv"], b["a11"], b["a12"], b["a22"], b["b1"], b["b2"], b["sh"], b["sv"], w, 400, 1.0)
+    du, dv = b["du"].copy(), b["dv"].copy()
+    b2 = {k: c_(v).copy() for k, v in s.items()}
+    b2["du"], b2["dv"] = du.copy(), dv.copy()
+    ctx.sor_coupled(b2["du"], b2["dv"], b2["a11"], b2["a12"], b2["a22"], b2["b1"], b2["b2"], b2["sh"], b2["sv"], w, 1, 1.0)
+    assert np.max(np.abs(b2["du"] - du)) < 5e-6 and np.max(np.abs(b2["dv"] - dv)) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------------
+# the level and the whole path
+# ------------------------------------------------------------------------------------------------------
+TOL_LEVEL = 2e-5       # rounding-level stage differences grow to 1e-6..2e-5 through the outer loop
+
+
+def oracle_sensitivity(oracle, po, frames, w, h, level_only=True):
+    """how much the ORACLE's own (u,v) moves when 20 pixels per frame change by one ulp: the conditioning of the
+    configuration.  The GPU may differ from the oracle by a small multiple of this and no more."""
+    stride = orc.stride_of(w)
+    outs = []
+    for pert in (False, True):
+        fr = []
+        rng = np.random.default_rng(1)
+        for f in frames:
+            g = orc.aligned_zeros(f.shape); g[...] = f
+            if pert:
+                for i in rng.integers(0, h * w, 20):
+                    y, x = divmod(int(i), w)
+                    g[0, y, x] = np.nextafter(g[0, y, x], np.float32(1e9))
+            fr.append(g)
+        wx, wy = orc.plane(h, stride), orc.plane(h, stride)
+        if level_only:
+            oracle.compute_one_level(po, wx, wy, fr, w)
+        else:
+            oracle.variational(po, wx, wy, fr, w)
+        outs.append((wx, wy))
+    return max(np.abs(outs[0][0][:, :w] - outs[1][0][:, :w]).max(), np.abs(outs[0][1][:, :w] - outs[1][1][:, :w]).max())
+
+
+def run_both(ctx, oracle, po, ps, frames, w, h, level_only=True, chw=None, init=None):
+    stride = orc.stride_of(w)
+    wxo, wyo = orc.plane(h, stride), orc.plane(h, stride)
+    if init is not None:
+        wxo[...] = init[0]; wyo[...] = init[1]
+    wxg, wyg = c_(wxo).copy(), c_(wyo).copy()
+    if level_only:
+        rc, cho, _ = oracle.compute_one_level(po, wxo, wyo, frames, w, chw)
+        chg, _ = ctx.compute_one_level(ps, wxg, wyg, [c_(f) for f in frames], w, [c_(x) for x in chw] if chw else None)
+    else:
+        rc, cho = oracle.variational(po, wxo, wyo, frames, w, chw)
+        chg, _ = ctx.variational(ps, wxg, wyg, [c_(f) for f in frames], w, [c_(x) for x in chw] if chw else None)
+    assert rc == 0
+    return (wxo, wyo, cho), (wxg, wyg, chg)
+
+
+def normalized_frames(oracle, w, h, n, seed=None):
+    if seed is None:
+        frames = [texture_frame(w, h, k) for k in range(n)]
+    else:
+        rng = np.random.default_rng(seed)
+        base = smooth_noise_color(rng, w + 16, h + 16, 40)
+        frames = []
+        for k in range(n):
+            f = orc.aligned_zeros((3, h, orc.stride_of(w)))
+            # integer-shifted crops: a known translation of (2,1) px per frame
+            f[:, :, :w] = base[:, 8 - k:8 - k + h, 8 - 2 * k:8 - 2 * k + w]
+            frames.append(f)
+    _, _, af, sf = oracle.normalize(frames, w)
+    return frames, af, sf
+
+
+@pytest.mark.parametrize("w,h", [(67, 45), (128, 96)])
+def test_level_symmetric_S2(ctx, oracle, w, h):
+    frames, af, sf = normalized_frames(oracle, w, h, 3)
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_LEVEL, d
+    assert abs(o[2][0] - g[2][0]) < 1e-6 and abs(o[2][1] - g[2][1]) < 1e-6
+
+
+def test_level_cfg_default_S3(ctx, oracle):
+    """cfgs/slow_flow.cfg terms: S=3, rho 1/1, omega 0/2, smoothing 1, normalised data term"""
+    w, h = 96, 64
+    frames, af, sf = normalized_frames(oracle, w, h, 5)
+    po, ps = mk_params(oracle, S=3, rho=[1, 1], omega=[0, 2], norm_avg=af, norm_std=sf, niter_outer=4)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_LEVEL, d
+
+
+@pytest.mark.parametrize("kw", [
+    dict(one_direction=1), dict(smoothing=0), dict(smoothing=2), dict(dataterm_norm=0),
+    dict(robust_color=(2, 0.05, 0.5), robust_grad=(2, 0.05, 0.5), robust_reg=(2, 0.05, 0.5)),
+    dict(robust_color=(3, 0.001, 0.5), robust_grad=(3, 0.001, 0.5), robust_reg=(3, 0.001, 0.5)),
+    dict(robust_color=(4, 0.05, 0.5), robust_grad=(4, 0.05, 0.5), robust_reg=(4, 0.05, 0.5)),
+    dict(robust_color=(0, 0.05, 0.5), robust_grad=(0, 0.05, 0.5), robust_reg=(0, 0.05, 0.5)),
+    dict(niter_inner=3), dict(delta=0.0), dict(occlusion_reasoning=1, niter_alter=1), dict(hbit=1), dict(niter_solver=7, sor_omega=1.5),
+])
+def test_level_variants(ctx, oracle, kw):
+    w, h = 67, 45
+    frames, af, sf = normalized_frames(oracle, w, h, 5, seed=7)
+    po, ps = mk_params(oracle, S=3, rho=[1, 0.5], omega=[0.5, 2], norm_avg=af, norm_std=sf, niter_outer=2, **kw)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    # ill-conditioned variants (e.g. all-quadratic penalties: the oracle itself moves by 6e-4 under 1-ulp input noise)
+    # are held to a small multiple of the oracle's own sensitivity
+    tol = max(TOL_LEVEL, 3 * oracle_sensitivity(oracle, po, frames, w, h))
+    assert d <= tol, (kw, d, tol)
+
+
+def test_level_channel_weights_and_initial_flow(ctx, oracle):
+    w, h = 67, 45
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=9)
+    rng = np.random.default_rng(0)
+    chw = [noise_plane(rng, w, h, 0.5, 1.5) for _ in range(3)]
+    init = (noise_plane(rng, w, h, 1.5, 2.5), noise_plane(rng, w, h, 0.5, 1.5))
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h, chw=chw, init=init)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_LEVEL, d
+
+
+def test_thresholds_break_like_the_oracle(ctx, oracle):
+    w, h = 67, 45
+    frames, af, sf = normalized_frames(oracle, w, h, 3)
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=30, thres_outer=2e-3, thres_inner=1e-9)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_LEVEL, d
+    assert o[2][0] < 2e-3 and abs(o[2][0] - g[2][0]) < 1e-6      # both stopped at the same outer iteration
+
+
+def test_config1_translation_256(ctx, oracle):
+    """BASELINE config 1: 256x256 constant translation (1.5,-0.75), 1 level, 30 SOR iterations"""
+    w = h = 256
+    frames, af, sf = normalized_frames(oracle, w, h, 3)
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=5)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_UV, d
+    assert abs(g[0][32:-32, 32:w - 32].mean() - 1.5) < 0.05 and abs(g[1][32:-32, 32:w - 32].mean() + 0.75) < 0.05
+
+
+def test_pyramid_ops(ctx, oracle):
+    w, h = 130, 98
+    rng = np.random.default_rng(8)
+    src = noise_plane(rng, w, h, 0, 255)
+    a = oracle.gaussian_blur_cv(src, w, 0.745356)
+    b = ctx.gaussian_blur(c_(src), w, 0.745356)
+    assert np.array_equal(valid(a, w), valid(b, w))
+    for (dw, dh) in ((117, 88), (65, 49), (200, 150)):
+        a = oracle.resize_linear_cv(src, w, dw, dh)
+        b = ctx.resize_linear(c_(src), w, dw, dh)
+        assert np.array_equal(valid(a, dw), valid(b, dw))
+
+
+@pytest.mark.parametrize("layers", [3, 5])
+def test_variational_multilevel(ctx, oracle, layers):
+    w, h = 130, 98
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=11)
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, layers=layers, niter_outer=3)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h, level_only=False)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_UV, d
+    # the synthetic sequence moves by (2,1) px per frame
+    assert abs(np.median(valid(g[0], w)) - 2.0) < 0.2 and abs(np.median(valid(g[1], w)) - 1.0) < 0.2
+
+
+def test_variational_full_size_config2(ctx, oracle):
+    """BASELINE config 2 shape: 1024x436, 5 levels, 5 outer x 30 SOR, S=2, against the oracle (<= 1e-4)"""
+    w, h = 1024, 436
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=5)
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, layers=5, niter_outer=5)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h, level_only=False)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_UV, d
+
+
+def test_job_batch_equals_single(ctx, oracle):
+    """frame windows of a batch are independent: a lockstep batch gives each element what it gets alone"""
+    w, h = 96, 64
+    fa, af, sf = normalized_frames(oracle, w, h, 3, seed=1)
+    fb, _, _ = normalized_frames(oracle, w, h, 3, seed=2)
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, layers=2)
+    singles = []
+    for fr in (fa, fb):
+        j = sfa.Job(ctx, ps, w, h, 1)
+        j.upload(0, [c_(f) for f in fr])
+        j.run()
+        singles.append(j.download(0))
+        j.close()
+    j = sfa.Job(ctx, ps, w, h, 2)
+    j.upload(0, [c_(f) for f in fa]); j.upload(1, [c_(f) for f in fb])
+    j.run()
+    for b in range(2):
+        wx, wy, _ = j.download(b)
+        assert np.array_equal(wx, singles[b][0]) and np.array_equal(wy, singles[b][1])
+    j.run()   # re-running a resident job starts again from the uploaded initial flow
+    wx, wy, _ = j.download(0)
+    assert np.array_equal(wx, singles[0][0])
+    j.close()
+
+
+def test_normalize(ctx, oracle):
+    w, h = 67, 45
+    fo = [texture_frame(w, h, k) for k in range(3)]
+    fg = [c_(f).copy() for f in fo]
+    avg_o, std_o, _, _ = oracle.normalize(fo, w)
+    avg_g, std_g = ctx.normalize(fg, w)
+    assert np.allclose(avg_o, avg_g, rtol=1e-12) and np.allclose(std_o, std_g, rtol=1e-10)
+    for a, b in zip(fo, fg):
+        assert np.max(np.abs(valid(a, w) - valid(b, w))) <= 7e-5      # |I| ~ 700: 1 ulp = 6e-5

@@ -2,6 +2,7 @@
 (oracle/_ref, built by oracle/Makefile from the sources under /root/reference).  Runs only where
 that library exists; the committed fixtures in tests/golden cover the same ground elsewhere."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -180,3 +181,42 @@ def test_data_term_near_pinned(oracle, reflib):
         va, vb = valid(a, w), valid(b, w)
         scale = np.abs(vb).max()
         assert np.max(np.abs(va - vb)) <= 2e-6 * scale, n
+
+
+def test_expf_restatement():
+    """glibc's expf (called by the reference at variational_aux_mt.cpp:700) is not correctly rounded, so the device
+    code restates its published algorithm (slowflow_amd/csrc/kernels.hip expf_glibc).  The same restatement in numpy
+    must agree with this machine's libm bit for bit."""
+    import ctypes
+    import struct
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+    N = 32
+    T = []
+    for i in range(N):
+        v = float(Decimal(2) ** (Decimal(i) / Decimal(N)))
+        T.append((struct.unpack("<Q", struct.pack("<d", v))[0] - (i << 47)) & 0xFFFFFFFFFFFFFFFF)
+    T = np.array(T, dtype=np.uint64)
+    inv = float.fromhex("0x1.71547652b82fep+0") * N
+    C = [float.fromhex("0x1.c6af84b912394p-5") / N / N / N, float.fromhex("0x1.ebfce50fac4f3p-3") / N / N, float.fromhex("0x1.62e42ff0c52d6p-1") / N]
+    shift = float.fromhex("0x1.8p+52")
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-8, 0, 150000), rng.uniform(-0.01, 0, 25000), rng.uniform(-80, 5, 25000)]).astype(np.float32)
+    z = inv * x.astype(np.float64)
+    kd = z + shift
+    ki = kd.view(np.uint64)
+    kd = kd - shift
+    r = z - kd
+    t = T[(ki % N).astype(np.int64)] + (ki << np.uint64(47))
+    s = t.view(np.float64)
+    y = ((C[0] * r + C[1]) * (r * r) + (C[2] * r + 1)) * s
+    mine = y.astype(np.float32)
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    ref = np.array([libm.expf(float(v)) for v in x], dtype=np.float32)
+    assert (ref != mine).mean() < 1e-5     # 0 here; an FMA build of libm may flip ~1e-9 of them
+    # and the kernel's table is this table
+    src = open(os.path.join(os.path.dirname(__file__), "..", "slowflow_amd", "csrc", "kernels.hip")).read()
+    for v in T:
+        assert ("0x%016xull" % int(v)) in src
