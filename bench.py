@@ -39,11 +39,8 @@ def synth_window(seed, w=W, h=H, n=3):
     rng = np.random.default_rng(seed)
     stride = sfa.stride_of(w)
     pad = 16
-    base = rng.uniform(0, 1, size=(3, h + 2 * pad, w + 2 * pad))
-    k = np.exp(-0.5 * (np.arange(-6, 7) / 2.0) ** 2)
-    k /= k.sum()
-    for ax in (1, 2):
-        base = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, base)
+    from scipy.ndimage import gaussian_filter
+    base = gaussian_filter(rng.uniform(0, 1, size=(3, h + 2 * pad, w + 2 * pad)), sigma=(0, 2.0, 2.0), mode="nearest")
     base = (base - base.min()) / (base.max() - base.min()) * 255.0
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
     fu = 2.0 + 1.0 * np.sin(2 * np.pi * yy / h)          # |flow| <= 3 px
@@ -98,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="frame windows per GPU solved in lockstep (fwd/bwd of several jets)")
+    ap.add_argument("--batch", type=int, default=32, help="frame windows per GPU solved in lockstep (fwd/bwd of several jets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -138,7 +138,7 @@ void launch_normalize_apply(sfa_ctx *c, const Geo &g, float *frames3, const doub
 struct SorWorkspace {
     sfa_ctx *ctx = nullptr;
     int w = 0, h = 0, K = 0, nb = 0;
-    int NB = 0, RP = 0, ND = 0, G = 0, NS = 0, NCH = 0, ntasks = 0;
+    int NB = 0, NG = 0, RP = 0, ND = 0, G = 0, NS = 0, NCH = 0, ntasks = 0, F = 0, CHK = 0;
     long ent = 0;                 // entries per element (ND*RP)
     DevMem sa, sb, x, flags, order;
     int configure(sfa_ctx *ctx, int w, int h, int K, int nb);   // (re)allocates for this shape

@@ -5,14 +5,16 @@
 // sweeps); instead the SAME dependency graph is executed as a pipeline of hyperplanes:
 //
 //   * iteration k of row r is given the skewed row index rho = r + k.  64 consecutive rho form a band;
-//     task (band b, iteration k) is ONE wavefront, lane l <-> rho = 64 b + l, i.e. row r = 64 b + l - k.
-//   * at local step s the lane works on column c = s - l, so the whole wave sits on one anti-diagonal
-//     d = c + r = s + 64 b - k of the image: all its operands are 64 CONSECUTIVE entries of the
+//     a task (band b, group g) is ONE wavefront, lane l <-> rho = 64 b + l, that carries F consecutive
+//     iterations k0 = g F .. k0+F-1 FUSED: row r = 64 b - k0 + l - f for fused index f.
+//   * at local step s the lane works on column c = s - l - f, so for each f the whole wave sits on one
+//     anti-diagonal d = c + r of the image: all its operands are 64 CONSECUTIVE entries of the
 //     diagonal-major planes built by k_sor_prepare (entry (d, r) at (d+G)*RP + r+G) -> every load and
 //     store of the sweep is a coalesced 256-B..1-KB wave access.
-//   * with the skew, every dependency of (b,k) points to (b,k-1), (b-1,k) or (b-1,k-1): the left
-//     neighbour is the lane's own previous result, the top neighbour lane l-1's previous result (DPP
-//     wave_shr:1), right/bottom/self are iteration k-1 values read back from the in-place x plane.
+//   * with the skew, every dependency of (b,g) points to (b,g-1) or (b-1,g): the left neighbour is the
+//     lane's own previous result, the top neighbour lane l-1's previous result (DPP wave_shr:1), right /
+//     bottom / self of f >= 1 are the previous step's f-1 results (registers), and only f = 0 reads
+//     iteration k0-1 values back from the in-place x plane: x traffic and operand HBM traffic drop by F.
 //   * tasks hand over through write-through (sc1) stores + one progress word per task, polled with sc1
 //     loads (agent scope; placement independent); tickets are drawn from an atomic counter in an order
 //     in which every dependency has a smaller ticket, so the pipeline cannot deadlock whatever the
@@ -26,18 +28,20 @@
 
 namespace sfa {
 
-constexpr int CH = 8;               // steps per hand-over chunk (divides 64)
 constexpr unsigned kSpinLimit = 1u << 22;
+#ifndef SFA_PUBLISH_VMCNT
+#define SFA_PUBLISH_VMCNT (2 * CH - 1)
+#endif
 
 struct SorArgs {
     const float4 *sa;               // (inv11, inv12, inv22, b1)
     const float4 *sb;               // (b2, hp, vp, vt)
     unsigned long long *x;          // (du, dv) pairs, in place
-    unsigned *flags;                // [nb][K][NB] chunks completed; flags[nb*ntasks] = ticket
-    const int2 *order;              // ticket/nb -> (b, k)
+    unsigned *flags;                // [nb][NG][NB] chunks completed; flags[nb*ntasks] = ticket
+    const int2 *order;              // ticket/nb -> (band, group)
     unsigned *err;
     long ent;                       // entries per batch element
-    int W, H, K, NB, RP, G, NS, NCH, ntasks, nb;
+    int W, H, K, NB, NG, RP, G, NS, NCH, ntasks, nb;
     float omega;
 };
 
@@ -55,24 +59,135 @@ __device__ __forceinline__ unsigned long long ld_x(const unsigned long long *p) 
 __device__ __forceinline__ void st_x(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // global_store_dwordx2 sc1 (write-through)
 }
+__device__ __forceinline__ unsigned ld_flag(const unsigned *p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 
-// bounded relaxed poll of one progress word (wave-uniform)
-__device__ __forceinline__ bool wait_ge(const unsigned *p, unsigned target, unsigned *err) {
+// bounded relaxed poll of one progress word (wave-uniform); returns the value seen (>= target) or 0xffffffff on give-up
+__device__ __forceinline__ unsigned wait_ge(const unsigned *p, unsigned target, unsigned *err) {
     unsigned spins = 0;
     for (;;) {
-        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (v >= target) return true;
+        const unsigned v = ld_flag(p);
+        if (v >= target) return v;
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023u) == 0) {
-            const unsigned e = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const unsigned e = ld_flag(err);
             if (e || spins > kSpinLimit) {
                 if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
+                return 0xffffffffu;
             }
         }
     }
 }
 
+// One wave = task (band b, group g): 64 consecutive skewed rows rho = 64 b + l, iterations k0 = g*F .. k0+F-1 FUSED
+// (the host picks an F that divides K).
+// Lane l, fused index f, step s: row r = 64 b - k0 + l - f, column c = s - l - f, diagonal d = s + 64 b - k0 - 2 f.
+// Within a step the F updates are independent; they consume the previous step's results:
+//   left   = own result of f            top    = lane l-1's result of f      (DPP)
+//   bottom = own result of f-1          right  = lane l-1's result of f-1    (the same DPP value as top of f-1)
+//   self   = the previous step's right
+// and for f = 0 right / bottom / self are iteration k0-1 values read from the in-place x plane.  Only the last fused
+// iterate is stored by all lanes; lane 63 also stores its intermediate iterates, in place, where lane 0 of band b+1
+// reads its "lane -1" values.  Operands of f >= 1 are the entries that lane l-f loaded 2f steps earlier: L2 hits.
+//
+// Operands are consumed from a register ring of CH step-slots; slot j is refilled for the next chunk right after step j
+// has used it (prefetch distance = one chunk).  x values of the next chunk may only be fetched once the producers'
+// progress words allow it; those words are polled asynchronously (never a stalling load) and a task starts LAG chunks
+// behind its producers so that, at equal speed, the prefetch condition keeps holding; if it does not, the chunk falls
+// back to a blocking wait.  A chunk is published one chunk late behind a counted s_waitcnt (no drain of the prefetch).
+template <int F, int CH>
+struct SorWave {
+    static constexpr int LAG = 3;
+    // wave-uniform state
+    const float4 *pa[F];            // SA + U - f*FOFF
+    const float4 *pb[F];
+    unsigned long long *px;         // X + U
+    long STEP;
+    int lane, W, ch0;               // ch0: first step of the current chunk
+    bool row_ok[F], top_ok[F], bot_ok[F], has_up;
+    float omega;
+    // per-lane carried state
+    float2 res[F], selfv[F];
+    float hl[F];
+    // operand ring
+    float4 sa[F][CH], sb[F][CH];
+    unsigned long long xr[CH], xb[CH], tv, tv_next;
+    long tv_off;
+    bool tv_lane;
+
+    __device__ __forceinline__ void load_x_slot(int j, long step_off) {
+        xr[j] = ld_x(px + step_off + STEP + lane);                 // (c+1, r)   iteration k0-1
+        xb[j] = ld_x(px + step_off + STEP + 1 + lane);             // (c, r+1)   iteration k0-1
+    }
+    __device__ __forceinline__ void load_s_slot(int j, long step_off) {
+#pragma unroll
+        for (int f = 0; f < F; f++) { sa[f][j] = pa[f][step_off + lane]; sb[f][j] = pb[f][step_off + lane]; }
+    }
+
+    // CH dependent steps.  REFILL: operand slots are refilled for the next chunk; PRE: so are the x slots.
+    template <bool REFILL, bool PRE>
+    __device__ __forceinline__ void chunk() {
+        const unsigned long long tv_cur = tv;
+        if (PRE && tv_lane) tv = ld_x(px + (long)CH * STEP + tv_off);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int s = ch0 + j;
+            float2 sh[F];
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                float2 t0;
+                t0.x = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), f * CH + j));
+                t0.y = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), f * CH + j));
+                sh[f].x = lane_shr1(res[f].x, t0.x);
+                sh[f].y = lane_shr1(res[f].y, t0.y);
+            }
+            float2 nres[F];
+            const float2 right0 = u2f(xr[j]), bottom0 = u2f(xb[j]);
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const int c = s - lane - f;
+                const bool valid = row_ok[f] && (unsigned)c < (unsigned)W;
+                const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
+                const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
+                const float2 top = sh[f];
+                const float2 self = selfv[f];
+                const float a11 = sa[f][j].x, a12 = sa[f][j].y, a22 = sa[f][j].z, b1 = sa[f][j].w;
+                const float b2 = sb[f][j].x, hp = sb[f][j].y, vp = sb[f][j].z, vt = sb[f][j].w;
+                float s1 = hp * right.x, s2 = hp * right.y;                               // solver.c:337-338
+                if (top_ok[f]) { s1 = s1 + vt * top.x; s2 = s2 + vt * top.y; }
+                if (bot_ok[f]) { s1 = s1 + vp * bottom.x; s2 = s2 + vp * bottom.y; }
+                s1 = s1 + b1;
+                s2 = s2 + b2;
+                float B1 = s1, B2 = s2;
+                if (c > 0) { B1 = hl[f] * res[f].x + s1; B2 = hl[f] * res[f].y + s2; }  // solver.c:340-341
+                float2 xn;
+                xn.x = self.x + omega * (a11 * B1 + a12 * B2 - self.x);                   // solver.c:342
+                xn.y = self.y + omega * (a12 * B1 + a22 * B2 - self.y);                   // solver.c:343
+                // outside the image the iterate is 0: the right neighbour of the last column (f2[w-1] = 0, solver.c:84)
+                nres[f].x = valid ? xn.x : 0.0f;
+                nres[f].y = valid ? xn.y : 0.0f;
+                unsigned long long *dst = px - (long)f * (2 * STEP + 1) + lane;
+                if (f == F - 1) { if (valid) st_x(dst, f2u(xn.x, xn.y)); }
+                else if (lane == 63 && valid) st_x(dst, f2u(xn.x, xn.y));               // intermediate iterate for band b+1's lane 0
+                hl[f] = hp;
+                selfv[f] = right;
+            }
+#pragma unroll
+            for (int f = 0; f < F; f++) res[f] = nres[f];
+            if (REFILL) {
+                load_s_slot(j, (long)CH * STEP);
+                if (PRE) load_x_slot(j, (long)CH * STEP);
+            }
+#pragma unroll
+            for (int f = 0; f < F; f++) { pa[f] += STEP; pb[f] += STEP; }
+            px += STEP;
+        }
+        ch0 += CH;
+    }
+};
+
+template <int F, int CH>
 __global__ void __launch_bounds__(64) k_sor_solve(SorArgs a) {
     const int lane = threadIdx.x;
     unsigned t = 0;
@@ -80,86 +195,77 @@ __global__ void __launch_bounds__(64) k_sor_solve(SorArgs a) {
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= (unsigned)(a.nb * a.ntasks)) return;
     const int job = t % a.nb, idx = t / a.nb;
-    const int2 bk = a.order[idx];
-    const int b = bk.x, k = bk.y;
-
-    const float4 *__restrict__ SA = a.sa + (size_t)job * a.ent;
-    const float4 *__restrict__ SB = a.sb + (size_t)job * a.ent;
-    unsigned long long *X = a.x + (size_t)job * a.ent;
+    const int2 bg = a.order[idx];
+    const int b = __builtin_amdgcn_readfirstlane(bg.x), g = __builtin_amdgcn_readfirstlane(bg.y);
+    const int k0 = g * F;
     unsigned *jflags = a.flags + (size_t)job * a.ntasks;
-    unsigned *myflag = jflags + k * a.NB + b;
-    const unsigned *f_prev = jflags + (k - 1) * a.NB + b;     // (b, k-1), valid if k > 0
-    const unsigned *f_up = jflags + k * a.NB + (b - 1);       // (b-1, k), valid if b > 0
+    unsigned *myflag = jflags + g * a.NB + b;
+    const unsigned *f_prev = jflags + (g - 1) * a.NB + b;     // (b, g-1), valid if g > 0
+    const unsigned *f_up = jflags + g * a.NB + (b - 1);       // (b-1, g), valid if b > 0
+    const int NCH = a.NCH, RP = a.RP;
+    const int r0 = 64 * b - k0;
+    const long FOFF = 2L * RP + 1;
+    const long U = (long)(r0 + a.G) * RP + (r0 + a.G);         // entry of (step 0, f = 0, lane 0)
 
-    const int W = a.W, H = a.H, RP = a.RP;
-    const float omega = a.omega;
-    const int r0 = 64 * b - k;
-    const int r = r0 + lane;
-    const bool row_ok = r >= 0 && r < H;
-    const bool top_ok = r > 0, bot_ok = r < H - 1;
-    // entry of this lane at step s: d = s + r0  ->  e = (s + r0 + G)*RP + r + G
-    size_t e = (size_t)(r0 + a.G) * RP + (size_t)(r + a.G);
-
-    float2 self = make_float2(0.f, 0.f);    // x^(k-1)(c, r): the previous step's right neighbour
-    float2 xl = make_float2(0.f, 0.f);      // x^k(c-1, r): own previous result
-    float2 xprev = make_float2(0.f, 0.f);   // own previous result, source of the next step's top via DPP
-    float hl = 0.f;                         // hp(c-1, r)
-    bool first = true;
-
-    for (int ch = 0; ch < a.NCH; ch++) {
-        // ---- wait for the producers of this chunk ---------------------------------------------------
-        if (k > 0 && !wait_ge(f_prev, (unsigned)(ch + 1), a.err)) return;
-        if (b > 0) {
-            const int need = min(ch + 1 + 64 / CH, a.NCH);
-            if (!wait_ge(f_up, (unsigned)need, a.err)) return;
-        }
-        if (first) { self = u2f(ld_x(X + e)); first = false; }
-        // ---- issue every load of the chunk -----------------------------------------------------------
-        float4 sa[CH], sb[CH];
-        unsigned long long xr[CH], xb[CH], xt0[CH];
+    SorWave<F, CH> w;
+    w.lane = lane; w.W = a.W; w.ch0 = 0; w.STEP = RP; w.omega = a.omega; w.has_up = b > 0;
 #pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const size_t ej = e + (size_t)j * RP;
-            sa[j] = SA[ej];
-            sb[j] = SB[ej];
-            xr[j] = ld_x(X + ej + RP);            // (c+1, r)   old
-            xb[j] = ld_x(X + ej + RP + 1);        // (c, r+1)   old
-            xt0[j] = 0;
-            if (b > 0 && lane == 0) xt0[j] = ld_x(X + ej - RP - 1);   // (c, r-1) of band b-1, new
-        }
-        // ---- CH dependent steps ------------------------------------------------------------------------
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const int s = ch * CH + j;
-            const int c = s - lane;
-            const bool valid = row_ok && (unsigned)c < (unsigned)W;
-            const float2 right = u2f(xr[j]), bottom = u2f(xb[j]), t0 = u2f(xt0[j]);
-            float2 top;
-            top.x = lane_shr1(xprev.x, t0.x);
-            top.y = lane_shr1(xprev.y, t0.y);
-            const float a11 = sa[j].x, a12 = sa[j].y, a22 = sa[j].z, b1 = sa[j].w;
-            const float b2 = sb[j].x, hp = sb[j].y, vp = sb[j].z, vt = sb[j].w;
-            float s1 = hp * right.x, s2 = hp * right.y;                                   // solver.c:337-338
-            if (top_ok) { s1 = s1 + vt * top.x; s2 = s2 + vt * top.y; }
-            if (bot_ok) { s1 = s1 + vp * bottom.x; s2 = s2 + vp * bottom.y; }
-            s1 = s1 + b1;
-            s2 = s2 + b2;
-            float B1 = s1, B2 = s2;
-            if (c > 0) { B1 = hl * xl.x + s1; B2 = hl * xl.y + s2; }                      // solver.c:340-341
-            float2 xn;
-            xn.x = self.x + omega * (a11 * B1 + a12 * B2 - self.x);                       // solver.c:342
-            xn.y = self.y + omega * (a12 * B1 + a22 * B2 - self.y);                       // solver.c:343
-            if (valid) st_x(X + e, f2u(xn.x, xn.y));
-            xl = xn;
-            xprev = xn;
-            hl = hp;
-            self = right;
-            e += RP;
-        }
-        // ---- publish: every store of this wave drained, then one relaxed agent-scope flag store --------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(ch + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int f = 0; f < F; f++) {
+        w.pa[f] = a.sa + (size_t)job * a.ent + U - f * FOFF;
+        w.pb[f] = a.sb + (size_t)job * a.ent + U - f * FOFF;
+        const int r = r0 + lane - f;
+        w.row_ok[f] = r >= 0 && r < a.H;
+        w.top_ok[f] = r > 0;
+        w.bot_ok[f] = r < a.H - 1;
+        w.res[f] = make_float2(0.f, 0.f); w.selfv[f] = make_float2(0.f, 0.f); w.hl[f] = 0.f;
     }
+    w.px = a.x + (size_t)job * a.ent + U;
+    // lane t = f*CH + j fetches lane 0's top value of (f, step j of the chunk): entry U(s) - f*FOFF - RP - 1
+    w.tv_lane = b > 0 && lane < F * CH;
+    w.tv_off = (long)(lane % CH) * RP - (long)(lane / CH) * FOFF - RP - 1;
+    w.tv = 0;
+
+    unsigned known_prev = 0, known_up = 0;
+    // what chunk `ch` needs from its producers (in completed chunks)
+    auto need_prev = [&](int ch) { return (unsigned)min(ch + 1 + (F - 1 + CH - 1) / CH, NCH); };
+    auto need_up = [&](int ch) { return (unsigned)min(ch + 1 + (64 + CH - 1) / CH, NCH); };
+    auto ready = [&](int ch) { return (g == 0 || known_prev >= need_prev(ch)) && (b == 0 || known_up >= need_up(ch)); };
+
+    // ---- prologue: start LAG chunks behind the producers, fetch chunk 0 ----------------------------------
+    if (g > 0) { known_prev = wait_ge(f_prev, need_prev(SorWave<F, CH>::LAG), a.err); if (known_prev == 0xffffffffu) return; }
+    if (b > 0) { known_up = wait_ge(f_up, need_up(SorWave<F, CH>::LAG), a.err); if (known_up == 0xffffffffu) return; }
+    w.selfv[0] = u2f(ld_x(w.px + lane));
+#pragma unroll
+    for (int j = 0; j < CH; j++) { w.load_s_slot(j, (long)j * RP); w.load_x_slot(j, (long)j * RP); }
+    if (w.tv_lane) w.tv = ld_x(w.px + w.tv_off);
+
+    // progress words are polled asynchronously: the load issued at the top of chunk ch is consumed at the top of chunk
+    // ch+1, so a poll never stalls the wave (the view of the producers is one chunk stale)
+    unsigned pend_prev = 0, pend_up = 0;
+    for (int ch = 0; ch + 1 < NCH; ch++) {
+        if (g > 0) known_prev = max(known_prev, (unsigned)__builtin_amdgcn_readfirstlane(pend_prev));
+        if (b > 0) known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up));
+        if (g > 0) pend_prev = __hip_atomic_load(f_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b > 0) pend_up = __hip_atomic_load(f_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool pre = ready(ch + 1);
+        if (pre) w.template chunk<true, true>();
+        else     w.template chunk<true, false>();
+        // ---- publish the PREVIOUS chunk.  Its stores are older than the >= 2*CH operand loads this chunk's body has
+        // issued since (in-order vmcnt), so this counted wait covers them without draining the prefetch. ---------------
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SFA_PUBLISH_VMCNT) : "memory");
+        if (ch > 0 && lane == 0) __hip_atomic_store(myflag, (unsigned)ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!pre) {
+            // the producers were not far enough ahead: wait, then fetch the next chunk's x values
+            if (g > 0) { known_prev = wait_ge(f_prev, need_prev(ch + 1), a.err); if (known_prev == 0xffffffffu) return; }
+            if (b > 0) { known_up = wait_ge(f_up, need_up(ch + 1), a.err); if (known_up == 0xffffffffu) return; }
+#pragma unroll
+            for (int j = 0; j < CH; j++) w.load_x_slot(j, (long)j * RP);
+            if (w.tv_lane) w.tv = ld_x(w.px + w.tv_off);
+        }
+    }
+    w.template chunk<false, false>();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(myflag, (unsigned)NCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -248,29 +354,43 @@ __global__ void k_sor_readable(float *du_, float *dv_, const float *a11_, const 
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+// fused iterations per wave / steps per hand-over chunk (env SFA_SOR_F, SFA_SOR_CH override the default)
+static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
+    // few waves (a single solve): the pipeline is latency bound, one iteration per wave is the shortest critical path;
+    // many waves (batches): HBM bound, fusing two iterations halves the operand and x traffic
+    F = nwaves1 >= 900 ? 2 : 1; CHK = 8;
+    if (const char *e = getenv("SFA_SOR_F")) F = atoi(e);
+    if (const char *e = getenv("SFA_SOR_CH")) CHK = atoi(e);
+    if (!((F == 1 && CHK == 8) || (F == 2 && (CHK == 8 || CHK == 4)) || (F == 3 && CHK == 4))) { F = 2; CHK = 8; }
+    if (K % F != 0) { F = 1; CHK = 8; }                      // the fused kernel carries exactly F iterations per group
+}
+
 int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
-    if (ctx == c && w == w_ && h == h_ && K == K_ && nb == nb_) return SFA_OK;
-    ctx = c; w = w_; h = h_; K = K_; nb = nb_;
+    int F_, CH_;
+    sor_shape(K_, nb_ * ((h_ + K_ - 1 + 63) / 64) * K_, F_, CH_);
+    if (ctx == c && w == w_ && h == h_ && K == K_ && nb == nb_ && F == F_ && CHK == CH_) return SFA_OK;
+    ctx = c; w = w_; h = h_; K = K_; nb = nb_; F = F_; CHK = CH_;
     NB = (h + K - 1 + 63) / 64;
+    NG = (K + F - 1) / F;
     G = K + 64;
     RP = round_up(h + 2 * G, 16);
-    NS = w + 63;
-    NCH = (NS + CH - 1) / CH;
-    ND = w + 64 * NB + CH + 2 * G;
-    ntasks = NB * K;
+    NS = w + 63 + F - 1;
+    NCH = (NS + CHK - 1) / CHK;
+    ND = w + 64 * NB + 2 * CHK + F + 2 * G + 8;
+    ntasks = NB * NG;
     ent = (long)ND * RP;
     SFA_TRY(sa.alloc(c, (size_t)nb * ent * sizeof(float4)));
     SFA_TRY(sb.alloc(c, (size_t)nb * ent * sizeof(float4)));
     SFA_TRY(x.alloc(c, (size_t)nb * ent * sizeof(unsigned long long)));
     SFA_TRY(flags.alloc(c, ((size_t)nb * ntasks + 16) * sizeof(unsigned)));
     SFA_TRY(order.alloc(c, (size_t)ntasks * sizeof(int2)));
-    // ticket order: ascending 3*b + k; every dependency ((b,k-1): -1, (b-1,k): -3, (b-1,k-1): -4) is earlier
+    // ticket order: ascending 3*b + g; every dependency ((b,g-1): -1, (b-1,g): -3) has a smaller ticket
     std::vector<int2> ord;
     ord.reserve(ntasks);
-    for (int key = 0; key <= 3 * (NB - 1) + (K - 1); key++)
+    for (int key = 0; key <= 3 * (NB - 1) + (NG - 1); key++)
         for (int b = 0; b < NB; b++) {
-            const int k = key - 3 * b;
-            if (k >= 0 && k < K) ord.push_back(make_int2(b, k));
+            const int g = key - 3 * b;
+            if (g >= 0 && g < NG) ord.push_back(make_int2(b, g));
         }
     SFA_HIP(c, hipMemcpyAsync(order.p, ord.data(), ord.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
     SFA_HIP(c, hipStreamSynchronize(c->stream));
@@ -293,13 +413,17 @@ int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, fl
 
     SorArgs a;
     a.sa = p.sa; a.sb = p.sb; a.x = p.x; a.flags = p.flags; a.order = (const int2 *)ws.order.p; a.err = c->d_err;
-    a.ent = ws.ent; a.W = g.w; a.H = g.h; a.K = K; a.NB = ws.NB; a.RP = ws.RP; a.G = ws.G; a.NS = ws.NS; a.NCH = ws.NCH;
+    a.ent = ws.ent; a.W = g.w; a.H = g.h; a.K = K; a.NB = ws.NB; a.NG = ws.NG; a.RP = ws.RP; a.G = ws.G; a.NS = ws.NS; a.NCH = ws.NCH;
     a.ntasks = ws.ntasks; a.nb = g.nb; a.omega = omega;
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
-    if (prof) hipEventRecord(c->ev[c->ev_used], c->stream);
-    hipLaunchKernelGGL(k_sor_solve, dim3(g.nb * ws.ntasks), dim3(64), 0, c->stream, a);
+    if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+    const dim3 sgrid(g.nb * ws.ntasks), sblock(64);
+    if (ws.F == 1)                      hipLaunchKernelGGL((k_sor_solve<1, 8>), sgrid, sblock, 0, c->stream, a);
+    else if (ws.F == 2 && ws.CHK == 8)  hipLaunchKernelGGL((k_sor_solve<2, 8>), sgrid, sblock, 0, c->stream, a);
+    else if (ws.F == 2)                 hipLaunchKernelGGL((k_sor_solve<2, 4>), sgrid, sblock, 0, c->stream, a);
+    else                                hipLaunchKernelGGL((k_sor_solve<3, 4>), sgrid, sblock, 0, c->stream, a);
     if (prof) {
-        hipEventRecord(c->ev[c->ev_used + 1], c->stream);
+        (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
         c->ev_used += 2;
         c->sor_bytes += (44.0 * K + 12.0) * (double)g.w * g.h * g.nb;
     }
