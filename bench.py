@@ -143,14 +143,13 @@ def main():
     elapsed = time.perf_counter() - t0
     n_sor, sor_ms, sor_bytes = ctx.profile_read()
     ctx.profile_enable(False)
+    from slowflow_amd import shard
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)                       # the per-rank timings: the only exchange of the path
-        elapsed_max = max(float(x.item()) for x in gathered)
-    else:
-        elapsed_max = elapsed
+    elapsed_max = shard.max_over_ranks(dist, elapsed, device="cuda")
+    # the per-window timings of every rank: the only exchange of the path (a few hundred bytes over RCCL)
+    lo, hi = shard.partition(B * world, world, rank)
+    window_seconds = shard.gather_timings(dist, {i: elapsed / args.steps / B for i in range(lo, hi)}, B * world, device="cuda")
 
     # SOR-only: the metric's own kernel at 1024x436, same batch, HIP events on the launch stream
     from synth import sor_system
@@ -201,6 +200,7 @@ def main():
                                                  "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                  "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}},
             "sor_share_of_step": round(sor_ms / (elapsed * 1e3), 4),
+            "seconds_per_window": {"mean": round(float(window_seconds.mean()), 6), "max": round(float(window_seconds.max()), 6), "n": int(window_seconds.size)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -1,0 +1,113 @@
+// io.cpp -- see io.h
+#include "io.h"
+
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+int writeFlowFile(const char *filename, const image_t *fx, const image_t *fy) {
+    FILE *f = fopen(filename, "wb");
+    if (!f) { fprintf(stderr, "Error while opening %s\n", filename); return -1; }
+    const float tag = 202021.25f;
+    const int w = fx->width, h = fx->height;
+    fwrite(&tag, sizeof(float), 1, f);
+    fwrite(&w, sizeof(int), 1, f);
+    fwrite(&h, sizeof(int), 1, f);
+    std::vector<float> row(2 * (size_t)w);
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) { row[2 * x] = fx->data[(size_t)y * fx->stride + x]; row[2 * x + 1] = fy->data[(size_t)y * fy->stride + x]; }
+        fwrite(row.data(), sizeof(float), row.size(), f);
+    }
+    fclose(f);
+    return 0;
+}
+
+image_t **readFlowFile(const char *filename) {
+    FILE *f = fopen(filename, "rb");
+    if (!f) { fprintf(stderr, "readFlow() error: could not open file  %s\n", filename); return nullptr; }
+    float tag = 0;
+    int w = 0, h = 0;
+    if (fread(&tag, 4, 1, f) != 1 || fread(&w, 4, 1, f) != 1 || fread(&h, 4, 1, f) != 1 || tag != 202021.25f || w <= 0 || h <= 0) { fclose(f); return nullptr; }
+    image_t **flow = (image_t **)malloc(2 * sizeof(image_t *));
+    flow[0] = image_new(w, h);
+    flow[1] = image_new(w, h);
+    image_erase(flow[0]);
+    image_erase(flow[1]);
+    std::vector<float> row(2 * (size_t)w);
+    for (int y = 0; y < h; y++) {
+        if (fread(row.data(), sizeof(float), row.size(), f) != row.size()) break;
+        for (int x = 0; x < w; x++) { flow[0]->data[(size_t)y * flow[0]->stride + x] = row[2 * x]; flow[1]->data[(size_t)y * flow[1]->stride + x] = row[2 * x + 1]; }
+    }
+    fclose(f);
+    return flow;
+}
+
+static bool next_token(FILE *f, std::string &tok) {
+    tok.clear();
+    int c;
+    for (;;) {
+        c = fgetc(f);
+        if (c == EOF) return false;
+        if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+        if (!isspace(c)) break;
+    }
+    while (c != EOF && !isspace(c)) { tok.push_back((char)c); c = fgetc(f); }
+    return true;
+}
+
+color_image_t *color_image_load(const char *filename, int *maxval_out) {
+    FILE *f = fopen(filename, "rb");
+    if (!f) { fprintf(stderr, "could not open %s\n", filename); return nullptr; }
+    std::string magic, t;
+    if (!next_token(f, magic)) { fclose(f); return nullptr; }
+    color_image_t *im = nullptr;
+    if (magic == "P5" || magic == "P6") {
+        const int ch = magic == "P6" ? 3 : 1;
+        int w, h, maxv;
+        if (!next_token(f, t)) { fclose(f); return nullptr; }
+        w = atoi(t.c_str());
+        if (!next_token(f, t)) { fclose(f); return nullptr; }
+        h = atoi(t.c_str());
+        if (!next_token(f, t)) { fclose(f); return nullptr; }
+        maxv = atoi(t.c_str());                     // next_token consumed the single whitespace after maxval
+        if (w <= 0 || h <= 0 || maxv <= 0 || maxv > 65535) { fclose(f); return nullptr; }
+        const int bps = maxv > 255 ? 2 : 1;
+        std::vector<unsigned char> row((size_t)w * ch * bps);
+        im = color_image_new(w, h);
+        color_image_erase(im);
+        for (int y = 0; y < h; y++) {
+            if (fread(row.data(), 1, row.size(), f) != row.size()) { color_image_delete(im); fclose(f); return nullptr; }
+            for (int x = 0; x < w; x++)
+                for (int k = 0; k < 3; k++) {
+                    const size_t i = ((size_t)x * ch + (ch == 3 ? k : 0)) * bps;
+                    const float v = bps == 2 ? (float)((row[i] << 8) | row[i + 1]) : (float)row[i];
+                    (k == 0 ? im->c1 : k == 1 ? im->c2 : im->c3)[(size_t)y * im->stride + x] = v;
+                }
+        }
+        if (maxval_out) *maxval_out = maxv > 255 ? 65535 : 255;
+    } else if (magic == "PF" || magic == "Pf") {
+        const int ch = magic == "PF" ? 3 : 1;
+        int w, h;
+        if (!next_token(f, t)) { fclose(f); return nullptr; }
+        w = atoi(t.c_str());
+        if (!next_token(f, t)) { fclose(f); return nullptr; }
+        h = atoi(t.c_str());
+        if (!next_token(f, t)) { fclose(f); return nullptr; }
+        const double scale = atof(t.c_str());
+        if (w <= 0 || h <= 0 || scale >= 0) { fclose(f); return nullptr; }   // little-endian files only (negative scale)
+        std::vector<float> row((size_t)w * ch);
+        im = color_image_new(w, h);
+        color_image_erase(im);
+        for (int y = h - 1; y >= 0; y--) {          // pfm rows are stored bottom to top
+            if (fread(row.data(), sizeof(float), row.size(), f) != row.size()) { color_image_delete(im); fclose(f); return nullptr; }
+            for (int x = 0; x < w; x++)
+                for (int k = 0; k < 3; k++) (k == 0 ? im->c1 : k == 1 ? im->c2 : im->c3)[(size_t)y * im->stride + x] = row[(size_t)x * ch + (ch == 3 ? k : 0)];
+        }
+        if (maxval_out) *maxval_out = 1;
+    }
+    fclose(f);
+    return im;
+}

@@ -1,0 +1,127 @@
+// CPU-side checks of the host mirror (no GPU needed): ParameterList syntax and accessors, the cfg -> sfa_params
+// mapping of Variational_MT, the .flo wire format and the PPM/PGM/PFM loaders.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "image.h"
+#include "io.h"
+#include "parameter_list.h"
+#include "variational_mt.h"
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+
+int main(int argc, char **argv) {
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+    // ---- ParameterList --------------------------------------------------------------------------------------
+    {
+        const std::string cfg = tmp + "/t.cfg";
+        std::ofstream f(cfg.c_str());
+        f << "# comment line\n"
+          << "verbose\t\t1000\t\t# console\n"
+          << "file\t\t/seq/dir/frame_%04i.ppm\t# sequence\n"
+          << "output\t/out/dir\n"
+          << "Jets\t\t12\n"
+          << "start\t7\n"
+          << "center\t100,50\n"
+          << "slow_flow_S\t3\t\t\t\t# frames\n"
+          << "slow_flow_alpha\t4.5\n"
+          << "slow_flow_method\tforward\n"
+          << "slow_flow_layers\t(1,3,5)\t# grid\n"
+          << "missing_value\n"
+          << "slow_flow_robust_color\t2\n";
+        f.close();
+        ParameterList p(cfg);
+        CHECK(p.file == "/seq/dir/frame_%04i.ppm" && p.output == "/out/dir" && p.Jets == 12 && p.sequence_start == 7);
+        CHECK(p.center.x == 100 && p.center.y == 50);
+        CHECK(p.verbosity(VER_CMD) && !p.verbosity(VER_IN_GT) && !p.verbosity(99));
+        CHECK(p.parameter<int>("slow_flow_S") == 3);
+        CHECK(std::fabs(p.parameter<float>("slow_flow_alpha") - 4.5f) < 1e-6f);
+        CHECK(p.parameter("slow_flow_method") == "forward");
+        CHECK(!p.exists("missing_value") && !p.exists("file"));
+        CHECK(p.parameter<int>("nope", "42") == 42 && p.parameter<bool>("nope", "0") == false && p.parameter<bool>("nope", "1") == true);
+        CHECK(p.parameter<int>("nope") == 0);                       // error message + 0
+        CHECK(p.experiments() == 3 && p.parameter<int>("slow_flow_layers") == 1);
+        CHECK(p.nextExp() && p.parameter<int>("slow_flow_layers") == 3);
+        CHECK(p.nextExp() && p.parameter<int>("slow_flow_layers") == 5 && !p.hasNextExp());
+        p.reset();
+        CHECK(p.parameter<int>("slow_flow_layers") == 1);
+        p.insert("final", "0", true);
+        p.setParameter<int>("final", 1);
+        CHECK(p.parameter<int>("final") == 1);
+        p.insert("x", "1");
+        p.insert("x", "2");                                          // append -> a 2-valued grid
+        CHECK(p.experiments() == 6);
+        CHECK(p.splitParameter<int>("nope", "1,0").size() == 2 && p.splitParameter<int>("nope", "1,0")[0] == 1);
+        ParameterList q(p);                                          // copy per thread (slow_flow.cpp:708)
+        q.setParameter<int>("final", 0);
+        CHECK(p.parameter<int>("final") == 1 && q.parameter<int>("final") == 0);
+        // the 6-digit publish of normalize (variational_mt.cpp:71-84)
+        std::stringstream s;
+        s << 127.3464558342057;
+        CHECK(s.str() == "127.346");
+    }
+    // ---- cfg -> sfa_params --------------------------------------------------------------------------------------
+    {
+        ParameterList p;
+        const char *kv[][2] = {{"slow_flow_S", "3"}, {"slow_flow_niter_outer", "10"}, {"slow_flow_niter_inner", "1"}, {"slow_flow_niter_solver", "30"},
+                               {"slow_flow_thres_outer", "1e-5"}, {"slow_flow_thres_inner", "1e-5"}, {"slow_flow_sor_omega", "1.9"}, {"slow_flow_alpha", "4.0"},
+                               {"slow_flow_gamma", "6.0"}, {"slow_flow_delta", "1.0"}, {"slow_flow_robust_color", "1"}, {"slow_flow_robust_color_eps", "0.001"},
+                               {"slow_flow_robust_color_truncation", "0.5"}, {"slow_flow_robust_reg", "2"}, {"slow_flow_robust_reg_eps", "0.05"},
+                               {"slow_flow_robust_reg_truncation", "0.5"}, {"slow_flow_omega_1", "2"}, {"slow_flow_omega_0", "0"}, {"slow_flow_layers", "5"},
+                               {"slow_flow_p_scale", "0.9"}, {"slow_flow_img_norm_avg_2", "127.368"}, {"slow_flow_img_norm_std_3", "0.177831"}, {"16bit", "1"}};
+        for (auto &e : kv) p.insert(e[0], e[1], true);
+        sfa_params sp = sfa_params_from_cfg(p, false);
+        CHECK(sp.S == 3 && sp.niter_alter == 1 && sp.smoothing == 0 && sp.dataterm_norm == 1 && sp.one_direction == 0);   // library defaults of variational_mt.cpp
+        CHECK(sp.robust_grad.id == 1 && sp.robust_grad.eps == 0.001f && sp.robust_reg.id == 2);                             // grad falls back to color
+        CHECK(sp.rho[0] == 1.0f && sp.rho[1] == 1.0f && sp.omega[0] == 0.0f && sp.omega[1] == 2.0f);
+        CHECK(sp.norm_avg[0] == 0.0f && std::fabs(sp.norm_avg[1] - 127.368f) < 1e-4f && sp.norm_std[0] == 1.0f && std::fabs(sp.norm_std[2] - 0.177831f) < 1e-7f);
+        CHECK(sp.hbit == 1 && sp.occlusion_reasoning == 0 && sp.layers == 5 && sp.presmooth_sigma == 0.0f);
+        p.insert("slow_flow_method", "forward", true);
+        CHECK(sfa_params_from_cfg(p, false).one_direction == 1);
+    }
+    // ---- .flo and image files ---------------------------------------------------------------------------------------
+    {
+        image_t *u = image_new(5, 3), *v = image_new(5, 3);
+        for (int y = 0; y < 3; y++) for (int x = 0; x < 5; x++) { u->data[y * u->stride + x] = x + 10 * y + 0.25f; v->data[y * v->stride + x] = -(x * 0.5f) - y; }
+        CHECK(u->stride == 8);
+        const std::string flo = tmp + "/t.flo";
+        CHECK(writeFlowFile(flo.c_str(), u, v) == 0);
+        std::ifstream f(flo.c_str(), std::ios::binary);
+        float tag; int w, h; float first[2];
+        f.read((char *)&tag, 4); f.read((char *)&w, 4); f.read((char *)&h, 4); f.read((char *)first, 8);
+        CHECK(tag == 202021.25f && w == 5 && h == 3 && first[0] == 0.25f && first[1] == -0.0f);
+        f.seekg(0, std::ios::end);
+        CHECK((long)f.tellg() == 12 + 5 * 3 * 8);
+        image_t **r = readFlowFile(flo.c_str());
+        CHECK(r && r[0]->width == 5 && r[1]->data[2 * r[1]->stride + 4] == -4.0f && r[0]->data[1 * r[0]->stride + 3] == 13.25f);
+        // 16-bit PPM, 8-bit PGM
+        const std::string ppm = tmp + "/t.ppm";
+        { std::ofstream o(ppm.c_str(), std::ios::binary); o << "P6\n# c\n2 1\n65535\n"; const unsigned char d[12] = {0x01, 0x02, 0, 5, 0xff, 0xff, 0, 0, 0, 1, 0x10, 0}; o.write((const char *)d, 12); }
+        int maxv = 0;
+        color_image_t *c = color_image_load(ppm.c_str(), &maxv);
+        CHECK(c && maxv == 65535 && c->c1[0] == 258.0f && c->c2[0] == 5.0f && c->c3[0] == 65535.0f && c->c3[1] == 4096.0f);
+        const std::string pgm = tmp + "/t.pgm";
+        { std::ofstream o(pgm.c_str(), std::ios::binary); o << "P5 3 1 255\n"; const unsigned char d[3] = {7, 8, 9}; o.write((const char *)d, 3); }
+        color_image_t *gcol = color_image_load(pgm.c_str(), &maxv);
+        CHECK(gcol && maxv == 255 && gcol->c1[2] == 9.0f && gcol->c2[1] == 8.0f && gcol->c3[0] == 7.0f && gcol->c2 == gcol->c1 + gcol->stride);
+    }
+    // ---- without a GPU the drop-in must fail loudly ---------------------------------------------------------------------
+    if (sfa_device_count() == 0) {
+        bool threw = false;
+        try {
+            ParameterList p;
+            color_image_t *im = color_image_new(8, 8);
+            color_image_erase(im);
+            color_image_t *seq[1] = {im};
+            normalize(seq, 1, p);
+        } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("no HIP device") != std::string::npos; }
+        CHECK(threw);
+    }
+    printf(fails ? "host tests FAILED (%d)\n" : "host tests OK\n", fails);
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,109 @@
+"""Host side of the drop-in (C++): builds slowflow_amd/host and runs its CPU checks; on a GPU box also drives the
+slow_flow binary end to end over a synthetic PPM sequence and compares the .flo files with the Python binding."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "slowflow_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def host_build():
+    import slowflow_amd as sfa
+    if not os.path.exists(sfa.LIB_PATH):
+        sfa.build()
+    r = subprocess.run(["make", "-C", HOST], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return HOST
+
+
+def test_host_mirror_cpu(host_build, tmp_path):
+    exe = str(tmp_path / "test_host")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-pthread", "-I", HOST, os.path.join(ROOT, "tests", "host", "test_host.cpp"),
+                        os.path.join(HOST, "libslowflow_host.a"), "-L", os.path.join(ROOT, "slowflow_amd"), "-lslowflow_amd",
+                        "-Wl,-rpath," + os.path.join(ROOT, "slowflow_amd"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "host tests OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_driver_rejects_out_of_scope_inputs(host_build, tmp_path):
+    cfg = tmp_path / "a.cfg"
+    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t1\nstart\t1\nraw\t0\ndeep_matching\t1\n" % (tmp_path, tmp_path))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg)], capture_output=True, text=True)
+    assert r.returncode == 2 and "deep_matching" in r.stderr
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(tmp_path / "missing.cfg")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Couldn't find" in r.stderr
+
+
+def write_ppm(path, img):          # img: (3,h,w) float 0..255
+    h, w = img.shape[1:]
+    data = np.clip(np.round(img), 0, 255).astype(np.uint8).transpose(1, 2, 0).tobytes()
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(data)
+
+
+def read_flo(path):
+    with open(path, "rb") as f:
+        tag, w, h = struct.unpack("<fii", f.read(12))
+        assert tag == 202021.25
+        d = np.frombuffer(f.read(), dtype=np.float32).reshape(h, w, 2)
+    return d[..., 0], d[..., 1]
+
+
+@pytest.mark.gpu
+def test_slow_flow_driver_end_to_end(host_build, tmp_path):
+    """cfg + PPM frames -> ./slow_flow -> .flo, against the same windows refined through the Python binding"""
+    import slowflow_amd as sfa
+    from synth import texture_frame
+    w, h, jets, S = 96, 64, 3, 2
+    steps = S - 1
+    nframes = 1 + (jets + 2) * steps
+    frames = [np.clip(np.round(texture_frame(w, h, k)[:, :, :w]), 0, 255) for k in range(nframes)]
+    for k, f in enumerate(frames):
+        write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), f)
+    cfg = tmp_path / "run.cfg"
+    cfg.write_text(
+        "file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\n"
+        "slow_flow_S\t%d\nslow_flow_layers\t2\nslow_flow_niter_alter\t1\nslow_flow_niter_outer\t3\nslow_flow_occlusion_reasoning\t0\n"
+        "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\ngpu_batch\t4\n" % (tmp_path, tmp_path, jets, S))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Done!" in r.stdout
+    out = tmp_path / "out"
+    assert (out / "config.cfg").exists() and (out / "timings.json").exists()
+    # the same computation through the Python binding
+    ctx = sfa.Context(0)
+    stride = sfa.stride_of(w)
+    fr = []
+    for f in frames:
+        a = np.zeros((3, h, stride), np.float32)
+        a[:, :, :w] = f
+        fr.append(a)
+    avg, std = ctx.normalize(fr, w)
+    p = sfa.default_params()
+    p.S = S; p.layers = 2; p.niter_alter = 1; p.niter_outer = 3; p.occlusion_reasoning = 0; p.thres_outer = 0; p.thres_inner = 0
+    p.hbit = 0; p.smoothing = 1; p.rho[0] = 1; p.omega[0] = 0
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    for j in range(jets):
+        f0 = j * steps
+        for back in (False, True):
+            win = fr[f0:f0 + 2 * steps + 1] if not back else [fr[nframes - 1 - i] for i in range(nframes - 1 - f0 - 3 * steps, nframes - 1 - f0 - 3 * steps + 2 * steps + 1)]
+            wx, wy = np.zeros((h, stride), np.float32), np.zeros((h, stride), np.float32)
+            ctx.variational(p, wx, wy, win, w)
+            name = "f_%03d%s.flo" % ((10 + f0) if not back else (10 + f0 + steps), "_back" if back else "")
+            u, v = read_flo(str(out / name))
+            assert np.array_equal(u, wx[:, :w] * steps) and np.array_equal(v, wy[:, :w] * steps), name
+    # forward flows recover the synthetic translation (1.5, -0.75) px per frame
+    u, v = read_flo(str(out / "f_010.flo"))
+    assert abs(np.median(u) - 1.5) < 0.1 and abs(np.median(v) + 0.75) < 0.1
+    # -resume skips what exists
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-resume"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("already exist") == 2 * jets
+    ctx.close()
