@@ -135,7 +135,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     // occlusions: 0, or -1 with one_direction / occlusion reasoning (:216-220)
     {
         const float occ0 = (p.one_direction || p.occlusion_reasoning) ? -1.0f : 0.0f;
-        for (int b = 0; b < L.nb; b++) launch_fill(c, L.plane(P_OCC) + b * L.es, (size_t)L.pl, occ0);
+        launch_fill_planes(c, g, L.plane(P_OCC), 1, occ0);
     }
     float data_norm = 0;                                                                                     // :223-226
     for (int s = 0; s < ref; s++) data_norm += p.rho[s] + p.omega[s];
@@ -189,8 +189,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             g.active = active;
             if (outer > 0) get_derivatives(c, L, p, active, need_toref);                                    // :289-290
             launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);           // :293-320
-            for (int b = 0; b < L.nb; b++)
-                if ((active >> b) & 1) SFA_HIP(c, hipMemsetAsync(L.plane(P_DU) + b * L.es, 0, (size_t)2 * L.pl * sizeof(float), c->stream));   // :323-324
+            launch_zero_planes(c, g, L.plane(P_DU), 2);                                                      // :323-324 (du, dv adjacent)
             unsigned long long in_active = active;
             for (int inner = 0; inner < p.niter_inner; inner++) {
                 Geo gi = g;

@@ -751,6 +751,20 @@ void launch_copy_planes(sfa_ctx *c, const Geo &g, float *dst, const float *src, 
     hipLaunchKernelGGL(k_copy_planes, grid2d(g, nplanes), block2d(), 0, c->stream, dst, src, g, nplanes, dst_es, src_es);
 }
 
+// image_erase / fill_n on whole planes (padding lanes included) of every active element
+__global__ void k_fill_planes(float *__restrict__ p, Geo g, int nplanes, float v) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.pitch || y >= g.h) return;
+    p[b * g.es + pl * g.pl + (size_t)y * g.pitch + x] = v;
+}
+void launch_fill_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes, float v) {
+    dim3 grid((g.pitch + BX - 1) / BX, (g.h + BY - 1) / BY, g.nb * nplanes);
+    hipLaunchKernelGGL(k_fill_planes, grid, block2d(), 0, c->stream, p, g, nplanes, v);
+}
+void launch_zero_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes) { launch_fill_planes(c, g, p, nplanes, 0.0f); }
+
 // image_mul_scalar (image.c:49-57)
 __global__ void k_scale_plane(float *__restrict__ p, Geo g, float s) {
     const int b = blockIdx.z;

@@ -101,6 +101,8 @@ void launch_smoothness(sfa_ctx *c, const Geo &g, int method, float *sh, float *s
 void launch_sub_laplacian(sfa_ctx *c, const Geo &g, float *dst, const float *src, const float *wh, const float *wv);
 void launch_mask_weight(sfa_ctx *c, const Geo &g, float *masks, const float *occ, float data_norm, int ref, int one_direction);
 void launch_fill(sfa_ctx *c, float *p, size_t n, float v);
+void launch_fill_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes, float v);
+void launch_zero_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes);
 
 struct Term { long stack_off; long mask_off; float hd, hg, s; int is_ref; };
 struct AssembleArgs {

@@ -279,41 +279,56 @@ struct PrepArgs {
     long ent, es;
     int W, H, RP, ND, G, pitch, ntasks, nb, inv_out;
 };
+// One block = a 64-column x 16-row tile: row-major reads coalesced along the columns, the 10 operand floats staged in
+// LDS, then written along the tile's anti-diagonals: 16 consecutive entries (256 B of SA/SB) per diagonal.  Only valid
+// (c,r) entries are written; the zero guards are set once when the workspace is (re)shaped and never touched again.
+constexpr int PT_C = 64, PT_R = 16;
 __global__ void __launch_bounds__(256) k_sor_prepare(PrepArgs p) {
+    __shared__ float4 tA[PT_R][PT_C + 1];
+    __shared__ float4 tB[PT_R][PT_C + 1];
+    __shared__ float2 tX[PT_R][PT_C + 1];
     const int job = blockIdx.z;
-    const int rr = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dd = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int c0 = blockIdx.x * PT_C, r0 = blockIdx.y * PT_R;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         for (int i = threadIdx.x; i < p.ntasks; i += 256) p.flags[(size_t)job * p.ntasks + i] = 0;
         if (job == 0 && threadIdx.x == 0) p.flags[(size_t)p.nb * p.ntasks] = 0;      // ticket
     }
-    if (rr >= p.RP || dd >= p.ND) return;
-    const int r = rr - p.G, d = dd - p.G, c = d - r;
-    const size_t e = (size_t)job * p.ent + (size_t)dd * p.RP + rr;
-    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = make_float4(0.f, 0.f, 0.f, 0.f);
-    float xu = 0.f, xv = 0.f;
-    if (r >= 0 && r < p.H && c >= 0 && c < p.W) {
-        const size_t o = (size_t)job * p.es + (size_t)r * p.pitch + c;
-        const float hp = p.sh[o];
-        const float hl = c > 0 ? p.sh[o - 1] : 0.0f;                                      // f1[0] = 0, solver.c:82
-        const float vp = p.sv[o];
-        const float vt = r > 0 ? p.sv[o - p.pitch] : 0.0f;
-        float dpsis = hl + hp;                                                            // solver.c:101,159,214
-        if (r > 0) dpsis = dpsis + vt;
-        if (r < p.H - 1) dpsis = dpsis + vp;
-        const float m12 = p.a12[o];
-        const float A11 = p.a22[o] + dpsis, A22 = p.a11[o] + dpsis;                       // solver.c:102
-        const float det = A11 * A22 - m12 * m12;
-        const float i11 = __fdiv_rn(A11, det), i22 = __fdiv_rn(A22, det), i12 = __fdiv_rn(m12, -det);   // solver.c:104-106
-        A = make_float4(i11, i12, i22, p.b1[o]);
-        B = make_float4(p.b2[o], hp, vp, vt);
-        xu = p.du[o];
-        xv = p.dv[o];
-        if (p.inv_out) { p.a11[o] = i11; p.a12[o] = i12; p.a22[o] = i22; }
+#pragma unroll
+    for (int i = 0; i < PT_R / 4; i++) {
+        const int rl = ty + 4 * i, r = r0 + rl, c = c0 + tx;
+        if (r < p.H && c < p.W) {
+            const size_t o = (size_t)job * p.es + (size_t)r * p.pitch + c;
+            const float hp = p.sh[o];
+            const float hl = c > 0 ? p.sh[o - 1] : 0.0f;                                  // f1[0] = 0, solver.c:82
+            const float vp = p.sv[o];
+            const float vt = r > 0 ? p.sv[o - p.pitch] : 0.0f;
+            float dpsis = hl + hp;                                                        // solver.c:101,159,214
+            if (r > 0) dpsis = dpsis + vt;
+            if (r < p.H - 1) dpsis = dpsis + vp;
+            const float m12 = p.a12[o];
+            const float A11 = p.a22[o] + dpsis, A22 = p.a11[o] + dpsis;                   // solver.c:102
+            const float det = A11 * A22 - m12 * m12;
+            const float i11 = __fdiv_rn(A11, det), i22 = __fdiv_rn(A22, det), i12 = __fdiv_rn(m12, -det);   // solver.c:104-106
+            tA[rl][tx] = make_float4(i11, i12, i22, p.b1[o]);
+            tB[rl][tx] = make_float4(p.b2[o], hp, vp, vt);
+            tX[rl][tx] = make_float2(p.du[o], p.dv[o]);
+            if (p.inv_out) { p.a11[o] = i11; p.a12[o] = i12; p.a22[o] = i22; }
+        }
     }
-    p.sa[e] = A;
-    p.sb[e] = B;
-    p.x[e] = f2u(xu, xv);
+    __syncthreads();
+    // tile diagonals: dl = cl + rl in [0, PT_C + PT_R - 2]; 16 row slots per diagonal
+    for (int item = threadIdx.x; item < (PT_C + PT_R - 1) * PT_R; item += 256) {
+        const int dl = item / PT_R, rl = item % PT_R, cl = dl - rl;
+        if (cl < 0 || cl >= PT_C) continue;
+        const int r = r0 + rl, c = c0 + cl;
+        if (r >= p.H || c >= p.W) continue;
+        const size_t e = (size_t)job * p.ent + (size_t)(c + r + p.G) * p.RP + (r + p.G);
+        p.sa[e] = tA[rl][cl];
+        p.sb[e] = tB[rl][cl];
+        const float2 xv = tX[rl][cl];
+        p.x[e] = f2u(xv.x, xv.y);
+    }
 }
 
 __global__ void k_sor_finish(float *__restrict__ du, float *__restrict__ dv, const unsigned long long *__restrict__ x, long ent, long es, int W, int H,
@@ -384,6 +399,10 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     SFA_TRY(x.alloc(c, (size_t)nb * ent * sizeof(unsigned long long)));
     SFA_TRY(flags.alloc(c, ((size_t)nb * ntasks + 16) * sizeof(unsigned)));
     SFA_TRY(order.alloc(c, (size_t)ntasks * sizeof(int2)));
+    // guards (entries outside the image) must read as zero and are never written afterwards
+    SFA_HIP(c, hipMemsetAsync(sa.p, 0, (size_t)nb * ent * sizeof(float4), c->stream));
+    SFA_HIP(c, hipMemsetAsync(sb.p, 0, (size_t)nb * ent * sizeof(float4), c->stream));
+    SFA_HIP(c, hipMemsetAsync(x.p, 0, (size_t)nb * ent * sizeof(unsigned long long), c->stream));
     // ticket order: ascending 3*b + g; every dependency ((b,g-1): -1, (b-1,g): -3) has a smaller ticket
     std::vector<int2> ord;
     ord.reserve(ntasks);
@@ -409,7 +428,7 @@ int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, fl
     p.du = du; p.dv = dv; p.b1 = b1; p.b2 = b2; p.sh = sh; p.sv = sv; p.a11 = a11; p.a12 = a12; p.a22 = a22;
     p.ent = ws.ent; p.es = g.es; p.W = g.w; p.H = g.h; p.RP = ws.RP; p.ND = ws.ND; p.G = ws.G; p.pitch = g.pitch;
     p.ntasks = ws.ntasks; p.nb = g.nb; p.inv_out = inv_out ? 1 : 0;
-    hipLaunchKernelGGL(k_sor_prepare, dim3((ws.RP + 63) / 64, (ws.ND + 3) / 4, g.nb), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(k_sor_prepare, dim3((g.w + PT_C - 1) / PT_C, (g.h + PT_R - 1) / PT_R, g.nb), dim3(256), 0, c->stream, p);
 
     SorArgs a;
     a.sa = p.sa; a.sb = p.sb; a.x = p.x; a.flags = p.flags; a.order = (const int2 *)ws.order.p; a.err = c->d_err;
