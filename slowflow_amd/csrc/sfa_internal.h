@@ -142,7 +142,9 @@ struct SorWorkspace {
     int w = 0, h = 0, K = 0, nb = 0;
     int NB = 0, NG = 0, RP = 0, ND = 0, G = 0, NS = 0, NCH = 0, ntasks = 0, F = 0, CHK = 0;
     long ent = 0;                 // entries per element (ND*RP)
-    DevMem sa, sb, x, flags, order;
+    int band = 0, Wp = 0, EP = 0;   // band kernel: fused sweeps per wave (0 = task kernel), edge row pitch / left pad
+    long edge_job = 0;
+    DevMem sa, sb, x, flags, order, edge;
     int configure(sfa_ctx *ctx, int w, int h, int K, int nb);   // (re)allocates for this shape
 };
 // planes: row-major device planes of element 0 (+es).  inv_out: write the inverted blocks back to a11/a12/a22

@@ -269,6 +269,225 @@ __global__ void __launch_bounds__(64) k_sor_solve(SorArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_sor_band: ALL K sweeps of one band in one workgroup.
+//
+// Workgroup = band b (64 skewed rows); its NW = K/F wavefronts are the pipeline stages: wave w carries the fused
+// iterations k0 = w F .. k0+F-1 exactly as a k_sor_solve task does, but hands its last iterate to wave w+1 through an
+// LDS ring (one 512-B slot per step) instead of the x plane, and learns the progress of wave w-1 from an LDS word.
+// Only three things touch HBM: the operand planes (wave 0 pulls them in, waves 1.. hit L1/L2 a few steps later),
+// the initial x (wave 0) / final x (wave NW-1), and lane 63's iterates of every sweep, which lane 0 of band b+1
+// needs ("edge" rows, write-through + progress words as in k_sor_solve).  HBM traffic per solve drops from
+// (44 K + 12) to about 52 bytes per pixel: the sweep is no longer bandwidth bound.
+// Bands depend only on the band above; tickets are handed out band-major, so any residency is deadlock free.
+// ---------------------------------------------------------------------------------------------------
+struct BandArgs {
+    const float4 *sa; const float4 *sb; unsigned long long *x;
+    unsigned long long *edge;      // [nb][NB][K][Wp]  lane-63 iterates of every sweep
+    unsigned *gflags;              // [nb][NB][NW] chunks whose edge stores are complete; gflags[nb*NB*NW] = ticket
+    unsigned *err;
+    long ent, edge_job;            // entries per batch element (diag planes / edge rows)
+    int W, H, K, NB, NW, RP, G, NS, NCH, nb, Wp, EP;
+    float omega;
+};
+
+__device__ __forceinline__ bool wait_lds_ge(unsigned *p, unsigned target, unsigned *err) {
+    unsigned spins = 0;
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 4095u) == 0) {
+            if (ld_flag(err) || spins > (kSpinLimit << 2)) {
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+template <int F, int MAXW, int CH, int RING>
+__global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NW = a.NW;                                          // K / F pipeline stages (waves)
+    unsigned long long(*ring)[RING][64] = reinterpret_cast<unsigned long long(*)[RING][64]>(smem);   // [NW-1][RING][64]
+    unsigned *lprog = reinterpret_cast<unsigned *>(smem + (size_t)(NW - 1) * RING * 64 * 8);          // steps completed by each wave
+    unsigned &s_ticket = lprog[NW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * NW, 1u);
+    if (threadIdx.x < NW) lprog[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
+    if (t >= (unsigned)(a.nb * a.NB)) return;
+    const int job = t % a.nb, b = t / a.nb;                     // band-major tickets
+    const int k0 = wave * F;
+    const int W = a.W, H = a.H, RP = a.RP, NCH = a.NCH, NS = a.NS;
+    const float omega = a.omega;
+    const int r0 = 64 * b - k0;
+    const long STEP = RP, FOFF = 2L * RP + 1;
+    const long U0 = (long)(r0 + a.G) * RP + (r0 + a.G);
+
+    const float4 *pa[F], *pb[F];
+    bool row_ok[F], top_ok[F], bot_ok[F];
+    float2 res[F], selfv[F];
+    float hl[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) {
+        pa[f] = a.sa + (size_t)job * a.ent + U0 - f * FOFF;
+        pb[f] = a.sb + (size_t)job * a.ent + U0 - f * FOFF;
+        const int r = r0 + lane - f;
+        row_ok[f] = r >= 0 && r < H;
+        top_ok[f] = r > 0;
+        bot_ok[f] = r < H - 1;
+        res[f] = make_float2(0.f, 0.f); selfv[f] = make_float2(0.f, 0.f); hl[f] = 0.f;
+    }
+    unsigned long long *px = a.x + (size_t)job * a.ent + U0;
+    // edge rows: this band's (written by lane 63) and the band above (read for lane 0)
+    unsigned long long *e_mine = a.edge + (size_t)job * a.edge_job + ((size_t)b * a.K + k0) * a.Wp + a.EP;
+    const unsigned long long *e_up = a.edge + (size_t)job * a.edge_job + ((size_t)(b - 1) * a.K + k0) * a.Wp + a.EP;
+    unsigned *gmine = a.gflags + ((size_t)job * a.NB + b) * NW + wave;
+    const unsigned *g_up = a.gflags + ((size_t)job * a.NB + (b - 1)) * NW + wave;         // (b-1, w)
+    const unsigned *g_up2 = g_up - 1;                                                      // (b-1, w-1)
+    const bool has_up = b > 0, publishes = b + 1 < a.NB;
+    // lane t = fi*CH + j fetches lane 0's "lane -1" value: fi = 0: right of f = 0 (sweep k0-1, column s+1);
+    // fi = f+1: top of f (sweep k0+f, column s-f)
+    const int tfi = lane / CH, tj = lane % CH;
+    const bool tv_lane = has_up && lane < (F + 1) * CH && (tfi > 0 || wave > 0);
+    const long tv_off = tfi == 0 ? (long)(-1) * a.Wp + tj + 1 : (long)(tfi - 1) * a.Wp + tj - (tfi - 1);
+
+    float4 sa[F][CH], sb[F][CH];
+    unsigned long long xb[CH], xr[CH], tv = 0;
+
+    unsigned known_up = 0, known_up2 = 0, pend_up = 0, pend_up2 = 0;
+    auto need_up = [&](int ch) { return (unsigned)min(ch + 1 + (64 + CH - 1) / CH, NCH); };
+    auto need_up2 = [&](int ch) { return (unsigned)min(ch + 1 + (64 + F + CH - 1) / CH, NCH); };
+    auto ready = [&](int ch) { return !has_up || (known_up >= need_up(ch) && (wave == 0 || known_up2 >= need_up2(ch))); };
+
+    // ---- prologue ---------------------------------------------------------------------------------------
+    if (has_up) {
+        known_up = wait_ge(g_up, need_up(1), a.err);
+        if (known_up == 0xffffffffu) return;
+        if (wave > 0) { known_up2 = wait_ge(g_up2, need_up2(1), a.err); if (known_up2 == 0xffffffffu) return; }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+#pragma unroll
+        for (int f = 0; f < F; f++) { sa[f][j] = pa[f][(long)j * STEP + lane]; sb[f][j] = pb[f][(long)j * STEP + lane]; }
+    if (wave > 0 && has_up && lane == 0) selfv[0] = u2f(ld_x(e_up - a.Wp));      // x^(k0-1)(0, r0): band above, lane 63, column 0
+    if (wave == 0) {
+        selfv[0] = u2f(px[lane]);
+#pragma unroll
+        for (int j = 0; j < CH; j++) { xr[j] = px[(long)j * STEP + STEP + lane]; xb[j] = px[(long)j * STEP + STEP + 1 + lane]; }
+    }
+    if (tv_lane) tv = ld_x(e_up + tv_off);
+
+    int s0 = 0;
+    for (int ch = 0; ch < NCH; ch++, s0 += CH) {
+        const bool last = ch + 1 >= NCH;
+        // ---- band above: asynchronous view of its progress -----------------------------------------------
+        if (has_up) {
+            known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up));
+            if (wave > 0) known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2));
+            if (!last) {
+                pend_up = __hip_atomic_load(g_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wave > 0) pend_up2 = __hip_atomic_load(g_up2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        const bool pre = !last && ready(ch + 1);
+        const unsigned long long tv_cur = tv;
+        if (pre && tv_lane) tv = ld_x(e_up + (s0 + CH) + tv_off);
+        // ---- the previous stage of this band: last iterate of wave-1 through the LDS ring --------------------
+        if (wave > 0) {
+            const unsigned need = (unsigned)min(s0 + CH - 1 + F, NS);                    // steps completed by wave-1
+            if (!wait_lds_ge(&lprog[wave - 1], need, a.err)) return;
+#pragma unroll
+            for (int j = 0; j < CH; j++) xb[j] = ring[wave - 1][(s0 + j + F - 1) % RING][lane];
+        }
+        // ---- back-pressure: do not overrun the ring slots wave+1 has not read yet ---------------------------
+        if (wave + 1 < NW) {
+            const int need = s0 + CH - 1 - RING - F + 2;
+            if (need > 0 && !wait_lds_ge(&lprog[wave + 1], (unsigned)need, a.err)) return;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int s = s0 + j;
+            float2 sh[F], right0, bottom0;
+            bottom0 = u2f(xb[j]);
+            if (wave == 0) right0 = u2f(xr[j]);
+            else {
+                const float fx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), j));
+                const float fy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), j));
+                right0.x = lane_shr1(bottom0.x, fx);
+                right0.y = lane_shr1(bottom0.y, fy);
+            }
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const float fx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), (f + 1) * CH + j));
+                const float fy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), (f + 1) * CH + j));
+                sh[f].x = lane_shr1(res[f].x, fx);
+                sh[f].y = lane_shr1(res[f].y, fy);
+            }
+            float2 nres[F];
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const int c = s - lane - f;
+                const bool valid = row_ok[f] && (unsigned)c < (unsigned)W;
+                const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
+                const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
+                const float2 top = sh[f];
+                const float2 self = selfv[f];
+                const float a11 = sa[f][j].x, a12 = sa[f][j].y, a22 = sa[f][j].z, b1 = sa[f][j].w;
+                const float b2 = sb[f][j].x, hp = sb[f][j].y, vp = sb[f][j].z, vt = sb[f][j].w;
+                float s1 = hp * right.x, s2 = hp * right.y;                               // solver.c:337-338
+                if (top_ok[f]) { s1 = s1 + vt * top.x; s2 = s2 + vt * top.y; }
+                if (bot_ok[f]) { s1 = s1 + vp * bottom.x; s2 = s2 + vp * bottom.y; }
+                s1 = s1 + b1;
+                s2 = s2 + b2;
+                float B1 = s1, B2 = s2;
+                if (c > 0) { B1 = hl[f] * res[f].x + s1; B2 = hl[f] * res[f].y + s2; }  // solver.c:340-341
+                float2 xn;
+                xn.x = self.x + omega * (a11 * B1 + a12 * B2 - self.x);                   // solver.c:342
+                xn.y = self.y + omega * (a12 * B1 + a22 * B2 - self.y);                   // solver.c:343
+                nres[f].x = valid ? xn.x : 0.0f;                                          // 0 outside the image (solver.c:84)
+                nres[f].y = valid ? xn.y : 0.0f;
+                if (publishes && lane == 63 && valid) st_x(e_mine + (long)f * a.Wp + c, f2u(xn.x, xn.y));   // for band b+1's lane 0
+                if (f == F - 1) {
+                    if (wave + 1 < NW) ring[wave][s % RING][lane] = f2u(nres[f].x, nres[f].y);
+                    else if (valid) px[-(long)f * FOFF + lane] = f2u(xn.x, xn.y);          // final iterate
+                }
+                hl[f] = hp;
+                selfv[f] = right;
+            }
+#pragma unroll
+            for (int f = 0; f < F; f++) res[f] = nres[f];
+            if (!last) {
+#pragma unroll
+                for (int f = 0; f < F; f++) { sa[f][j] = pa[f][(long)CH * STEP + lane]; sb[f][j] = pb[f][(long)CH * STEP + lane]; }
+                if (wave == 0) { xr[j] = px[(long)CH * STEP + STEP + lane]; xb[j] = px[(long)CH * STEP + STEP + 1 + lane]; }
+            }
+#pragma unroll
+            for (int f = 0; f < F; f++) { pa[f] += STEP; pb[f] += STEP; }
+            px += STEP;
+        }
+        // ---- tell wave+1 (LDS, in order behind the ring writes) and, one chunk late, band b+1 (HBM) -----------
+        __hip_atomic_store(&lprog[wave], (unsigned)min(s0 + CH, NS), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (publishes && !last) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH - 1) : "memory");            // as in k_sor_solve
+            if (ch > 0 && lane == 0) __hip_atomic_store(gmine, (unsigned)ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!last && !pre) {
+            known_up = wait_ge(g_up, need_up(ch + 1), a.err);
+            if (known_up == 0xffffffffu) return;
+            if (wave > 0) { known_up2 = wait_ge(g_up2, need_up2(ch + 1), a.err); if (known_up2 == 0xffffffffu) return; }
+            if (tv_lane) tv = ld_x(e_up + (s0 + CH) + tv_off);
+        }
+    }
+    if (publishes) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(gmine, (unsigned)NCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // prepare: row-major planes -> diagonal-major operands; first-sweep 2x2 block inversion (solver.c:183-188
 // with the row variants :101,159,214); zero guards; reset the progress words.
 // ---------------------------------------------------------------------------------------------------
@@ -369,6 +588,23 @@ __global__ void k_sor_readable(float *du_, float *dv_, const float *a11_, const 
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+// band kernel (all K sweeps of a band in one workgroup): F fused sweeps per wave, NW = K/F waves; 0 = not applicable
+static int band_shape(int K) {
+    int F = 0;
+    const char *e = getenv("SFA_SOR_BAND");                     // opt-in while the task kernel is still faster
+    if (!e) return 0;
+    F = atoi(e);
+    if (F <= 0 || F > 3) return 0;
+    auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f >= 1 && K / f <= (f == 3 ? 10 : 16); };
+    if (F && fits(F)) return F;
+    if (fits(3)) return 3;
+    if (fits(2)) return 2;
+    if (fits(1)) return 1;
+    return 0;
+}
+constexpr int kBandCH = 4;
+static int band_ring(int F) { return F == 3 ? 32 : 20; }     // LDS ring slots per wave pair (144 KB / 140 KB / 150 KB at most)
+
 // fused iterations per wave / steps per hand-over chunk (env SFA_SOR_F, SFA_SOR_CH override the default)
 static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
     // few waves (a single solve): the pipeline is latency bound, one iteration per wave is the shortest critical path;
@@ -382,9 +618,11 @@ static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
 
 int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     int F_, CH_;
-    sor_shape(K_, nb_ * ((h_ + K_ - 1 + 63) / 64) * K_, F_, CH_);
-    if (ctx == c && w == w_ && h == h_ && K == K_ && nb == nb_ && F == F_ && CHK == CH_) return SFA_OK;
-    ctx = c; w = w_; h = h_; K = K_; nb = nb_; F = F_; CHK = CH_;
+    const int band_ = band_shape(K_);
+    if (band_) { F_ = band_; CH_ = kBandCH; }
+    else sor_shape(K_, nb_ * ((h_ + K_ - 1 + 63) / 64) * K_, F_, CH_);
+    if (ctx == c && w == w_ && h == h_ && K == K_ && nb == nb_ && F == F_ && CHK == CH_ && band == band_) return SFA_OK;
+    ctx = c; w = w_; h = h_; K = K_; nb = nb_; F = F_; CHK = CH_; band = band_;
     NB = (h + K - 1 + 63) / 64;
     NG = (K + F - 1) / F;
     G = K + 64;
@@ -392,8 +630,15 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     NS = w + 63 + F - 1;
     NCH = (NS + CHK - 1) / CHK;
     ND = w + 64 * NB + 2 * CHK + F + 2 * G + 8;
-    ntasks = NB * NG;
+    ntasks = NB * NG;                                           // band kernel: NG = NW waves per band workgroup
     ent = (long)ND * RP;
+    if (band) {
+        EP = 8;
+        Wp = round_up(EP + NS + 2 * CHK + 8, 8);
+        edge_job = (long)NB * K * Wp;
+        SFA_TRY(edge.alloc(c, (size_t)nb * edge_job * sizeof(unsigned long long)));
+        SFA_HIP(c, hipMemsetAsync(edge.p, 0, (size_t)nb * edge_job * sizeof(unsigned long long), c->stream));
+    }
     SFA_TRY(sa.alloc(c, (size_t)nb * ent * sizeof(float4)));
     SFA_TRY(sb.alloc(c, (size_t)nb * ent * sizeof(float4)));
     SFA_TRY(x.alloc(c, (size_t)nb * ent * sizeof(unsigned long long)));
@@ -436,11 +681,23 @@ int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, fl
     a.ntasks = ws.ntasks; a.nb = g.nb; a.omega = omega;
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
     if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+    if (ws.band) {
+        BandArgs ba;
+        ba.sa = p.sa; ba.sb = p.sb; ba.x = p.x; ba.edge = (unsigned long long *)ws.edge.p; ba.gflags = p.flags; ba.err = c->d_err;
+        ba.ent = ws.ent; ba.edge_job = ws.edge_job; ba.W = g.w; ba.H = g.h; ba.K = K; ba.NB = ws.NB; ba.NW = ws.NG; ba.RP = ws.RP; ba.G = ws.G;
+        ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
+        const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
+        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + (ws.NG + 1) * sizeof(unsigned) + 16;
+        if (ws.F == 3)      hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, 32>), bgrid, bblock, lds, c->stream, ba);
+        else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, kBandCH, 20>), bgrid, bblock, lds, c->stream, ba);
+        else                hipLaunchKernelGGL((k_sor_band<1, 16, kBandCH, 20>), bgrid, bblock, lds, c->stream, ba);
+    } else {
     const dim3 sgrid(g.nb * ws.ntasks), sblock(64);
     if (ws.F == 1)                      hipLaunchKernelGGL((k_sor_solve<1, 8>), sgrid, sblock, 0, c->stream, a);
     else if (ws.F == 2 && ws.CHK == 8)  hipLaunchKernelGGL((k_sor_solve<2, 8>), sgrid, sblock, 0, c->stream, a);
     else if (ws.F == 2)                 hipLaunchKernelGGL((k_sor_solve<2, 4>), sgrid, sblock, 0, c->stream, a);
     else                                hipLaunchKernelGGL((k_sor_solve<3, 4>), sgrid, sblock, 0, c->stream, a);
+    }
     if (prof) {
         (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
         c->ev_used += 2;
