@@ -22,6 +22,8 @@
 //
 // Per point the arithmetic is the fast solver's, operation for operation (solver.c:183-196), so the
 // result is numerically identical to the reference's lexicographic sweep.
+#include <type_traits>
+
 #include "sfa_internal.h"
 
 #pragma clang fp contract(off)
@@ -34,8 +36,8 @@ constexpr unsigned kSpinLimit = 1u << 22;
 #endif
 
 struct SorArgs {
-    const float4 *sa;               // (inv11, inv12, inv22, b1)
-    const float4 *sb;               // (b2, hp, vp, vt)
+    const float4 *sa;               // (inv11, inv12, inv22, vt)
+    const float4 *sb;               // (b1, b2, hp, vp)
     unsigned long long *x;          // (du, dv) pairs, in place
     unsigned *flags;                // [nb][NG][NB] chunks completed; flags[nb*ntasks] = ticket
     const int2 *order;              // ticket/nb -> (band, group)
@@ -47,6 +49,26 @@ struct SorArgs {
 
 __device__ __forceinline__ float2 u2f(unsigned long long v) { return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))); }
 __device__ __forceinline__ unsigned long long f2u(float a, float b) { return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32); }
+
+// The SOR point update on (du, dv) pairs, the fast solver's operations in the fast solver's order (solver.c:337-343):
+//   s = ((hp*x_right + vt*x_top) + vp*x_bottom) + b;  B = hl*x_left + s;  x += w*((a11*B1 + a12*B2) - x) (and the dv row)
+// written on 2-vectors so that it compiles to v_pk_mul_f32 / v_pk_add_f32 (one rounding per operation, no FMA).
+// Absent neighbours are not skipped with selects: their edge weight is exactly 0 (vt at row 0, vp at the last row, hl at
+// column 0 -- k_sor_prepare) and their value is a finite 0 (zero guards), so the term contributes +-0 and the sum is
+// unchanged (IEEE ==; at most the sign of an exact zero differs).  Likewise a point outside the image has all-zero
+// operands and a zero "self", so its update is exactly 0 without forcing it.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f f2v(float2 a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ v2f sor_point(v2f self, v2f right, v2f top, v2f bottom, v2f left, float hl, const float4 &SA, const float4 &SB, float omega) {
+    // SA = (inv11, inv12, inv22, vt)   SB = (b1, b2, hp, vp)
+    v2f s = SB.z * right;
+    s = s + SA.w * top;
+    s = s + SB.w * bottom;
+    s = s + (v2f){SB.x, SB.y};
+    const v2f B = hl * left + s;
+    const v2f t = (v2f){SA.x, SA.y} * B.x + (v2f){SA.y, SA.z} * B.y;
+    return self + omega * (t - self);
+}
 
 // value of lane-1 (lane 0 receives `fill`): DPP wave_shr:1, no LDS
 __device__ __forceinline__ float lane_shr1(float v, float fill) {
@@ -150,27 +172,12 @@ struct SorWave {
                 const bool valid = row_ok[f] && (unsigned)c < (unsigned)W;
                 const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
                 const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
-                const float2 top = sh[f];
-                const float2 self = selfv[f];
-                const float a11 = sa[f][j].x, a12 = sa[f][j].y, a22 = sa[f][j].z, b1 = sa[f][j].w;
-                const float b2 = sb[f][j].x, hp = sb[f][j].y, vp = sb[f][j].z, vt = sb[f][j].w;
-                float s1 = hp * right.x, s2 = hp * right.y;                               // solver.c:337-338
-                if (top_ok[f]) { s1 = s1 + vt * top.x; s2 = s2 + vt * top.y; }
-                if (bot_ok[f]) { s1 = s1 + vp * bottom.x; s2 = s2 + vp * bottom.y; }
-                s1 = s1 + b1;
-                s2 = s2 + b2;
-                float B1 = s1, B2 = s2;
-                if (c > 0) { B1 = hl[f] * res[f].x + s1; B2 = hl[f] * res[f].y + s2; }  // solver.c:340-341
-                float2 xn;
-                xn.x = self.x + omega * (a11 * B1 + a12 * B2 - self.x);                   // solver.c:342
-                xn.y = self.y + omega * (a12 * B1 + a22 * B2 - self.y);                   // solver.c:343
-                // outside the image the iterate is 0: the right neighbour of the last column (f2[w-1] = 0, solver.c:84)
-                nres[f].x = valid ? xn.x : 0.0f;
-                nres[f].y = valid ? xn.y : 0.0f;
+                const v2f xn = sor_point(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hl[f], sa[f][j], sb[f][j], omega);
+                nres[f] = make_float2(xn.x, xn.y);
                 unsigned long long *dst = px - (long)f * (2 * STEP + 1) + lane;
                 if (f == F - 1) { if (valid) st_x(dst, f2u(xn.x, xn.y)); }
                 else if (lane == 63 && valid) st_x(dst, f2u(xn.x, xn.y));               // intermediate iterate for band b+1's lane 0
-                hl[f] = hp;
+                hl[f] = sb[f][j].z;
                 selfv[f] = right;
             }
 #pragma unroll
@@ -285,8 +292,10 @@ struct BandArgs {
     unsigned long long *edge;      // [nb][NB][K][Wp]  lane-63 iterates of every sweep
     unsigned *gflags;              // [nb][NB][NW] chunks whose edge stores are complete; gflags[nb*NB*NW] = ticket
     unsigned *err;
+    unsigned long long *trace;     // debug (SFA_SOR_TRACE): [nb*NB][NW][4] wall-clock stamps, or null
     long ent, edge_job;            // entries per batch element (diag planes / edge rows)
     int W, H, K, NB, NW, RP, G, NS, NCH, nb, Wp, EP;
+    int lead;                      // steps a stage may run ahead of the next one (<= ring slots)
     float omega;
 };
 
@@ -304,7 +313,197 @@ __device__ __forceinline__ bool wait_lds_ge(unsigned *p, unsigned target, unsign
     return true;
 }
 
-template <int F, int MAXW, int CH, int RING>
+// ROLE of a wave in the band pipeline: 0 first stage (reads the initial x), 1 middle, 2 last (stores the final x),
+// 3 the only stage (K == F).  The role is a template parameter so that the per-step code carries no role branches.
+// Two granularities: operands are refilled and the LDS hand-over to the next stage happens every CH steps; the
+// (slower) HBM hand-over to the band below -- progress words, lane-0 values -- every MC steps.
+template <int F, int CH, int MC, int RING, int ROLE>
+__device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long (*ring)[RING][64], unsigned *lprog, int job, int b, int wave, int lane) {
+    constexpr bool FIRST = ROLE == 0 || ROLE == 3, LASTW = ROLE == 2 || ROLE == 3;
+    constexpr int NQ = MC / CH;
+    const int k0 = wave * F;
+    const int W = a.W, H = a.H, RP = a.RP, NMC = a.NCH, NSP = a.NS;   // NS: steps padded to a multiple of MC
+    const float omega = a.omega;
+    const int r0 = 64 * b - k0;
+    const long FOFF = 2L * RP + 1;
+    const long U0 = (long)(r0 + a.G) * RP + (r0 + a.G);
+    // wave-uniform byte bases (SGPR pairs); the per-step advance lives in ONE 32-bit lane offset per element size
+    const char *ba[F], *bb[F];
+    bool row_ok_last = false;
+    float2 res[F], selfv[F];
+    float hl[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) {
+        ba[f] = reinterpret_cast<const char *>(a.sa + (size_t)job * a.ent + U0 - f * FOFF);
+        bb[f] = reinterpret_cast<const char *>(a.sb + (size_t)job * a.ent + U0 - f * FOFF);
+        res[f] = make_float2(0.f, 0.f); selfv[f] = make_float2(0.f, 0.f); hl[f] = 0.f;
+    }
+    { const int r = r0 + lane - (F - 1); row_ok_last = r >= 0 && r < H; }
+    char *bx = reinterpret_cast<char *>(a.x + (size_t)job * a.ent + U0);
+    unsigned vo16 = lane * 16u, vo8 = lane * 8u;                  // + step * RP * {16, 8}
+    const unsigned st16 = RP * 16u, st8 = RP * 8u;
+    unsigned long long *e_mine = a.edge + (size_t)job * a.edge_job + ((size_t)b * a.K + k0) * a.Wp + a.EP;
+    const unsigned long long *e_up = a.edge + (size_t)job * a.edge_job + ((size_t)(b - 1) * a.K + k0) * a.Wp + a.EP;
+    unsigned *gmine = a.gflags + ((size_t)job * a.NB + b) * a.NW + wave;
+    const unsigned *g_up = a.gflags + ((size_t)job * a.NB + (b - 1)) * a.NW + wave;      // (b-1, w)
+    const unsigned *g_up2 = g_up - 1;                                                    // (b-1, w-1)
+    const bool has_up = b > 0, publishes = b + 1 < a.NB;
+    // lane t = fi*MC + j fetches lane 0's "lane -1" value of step j of the macro chunk: fi = 0: right of f = 0 (sweep
+    // k0-1, column s+1); fi = f+1: top of f (sweep k0+f, column s-f)
+    const int tfi = lane / MC, tj = lane % MC;
+    const bool tv_lane = has_up && lane < (F + 1) * MC && (tfi > 0 || !FIRST);
+    const long tv_off = tfi == 0 ? (long)(-1) * a.Wp + tj + 1 : (long)(tfi - 1) * a.Wp + tj - (tfi - 1);
+
+    float4 sa[F][CH], sb[F][CH];
+    unsigned long long xb[CH], xr[CH], tv = 0;
+    unsigned known_up = 0, known_up2 = 0, pend_up = 0, pend_up2 = 0;
+    auto need_up = [&](int m) { return (unsigned)min(m + 1 + (64 + MC - 1) / MC, NMC); };
+    auto need_up2 = [&](int m) { return (unsigned)min(m + 1 + (64 + F + MC - 1) / MC, NMC); };
+    auto ready = [&](int m) { return !has_up || (known_up >= need_up(m) && (FIRST || known_up2 >= need_up2(m))); };
+
+#ifdef SFA_BUILD_TRACE
+    unsigned long long *tr = a.trace ? a.trace + (((size_t)b * a.nb + job) * a.NW + wave) * 4 : nullptr;
+    if (tr && lane == 0) tr[0] = wall_clock64();
+    unsigned nblock = 0;
+#endif
+    // ---- prologue ---------------------------------------------------------------------------------------
+    if (has_up) {
+        // start one macro chunk further behind the band above than strictly needed: its progress is seen one macro chunk
+        // stale and published one late; at equal speed the lag of the start is the lag of the whole run
+        known_up = wait_ge(g_up, need_up(2), a.err);
+        if (known_up == 0xffffffffu) return;
+        if (!FIRST) { known_up2 = wait_ge(g_up2, need_up2(2), a.err); if (known_up2 == 0xffffffffu) return; }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; j++)
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            sa[f][j] = *reinterpret_cast<const float4 *>(ba[f] + (vo16 + j * st16));
+            sb[f][j] = *reinterpret_cast<const float4 *>(bb[f] + (vo16 + j * st16));
+        }
+    if (FIRST) {
+        selfv[0] = u2f(*reinterpret_cast<const unsigned long long *>(bx + vo8));
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            xr[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (j + 1) * st8));
+            xb[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (j + 1) * st8 + 8));
+        }
+    } else if (has_up && lane == 0) selfv[0] = u2f(ld_x(e_up - a.Wp));                  // x^(k0-1)(0, r0): band above, lane 63
+    if (tv_lane) tv = ld_x(e_up + tv_off);
+#ifdef SFA_BUILD_TRACE
+    if (tr && lane == 0) tr[1] = wall_clock64();
+#endif
+
+    int s0 = 0;
+    for (int m = 0; m < NMC; m++) {
+        const bool last = m + 1 >= NMC;
+        bool pre = false;
+        if (has_up) {
+            known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up));
+            if (!FIRST) known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2));
+            if (!last) {
+                pend_up = __hip_atomic_load(g_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!FIRST) pend_up2 = __hip_atomic_load(g_up2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            pre = !last && ready(m + 1);
+        }
+        const unsigned long long tv_cur = tv;
+        if (pre && tv_lane) tv = ld_x(e_up + (s0 + MC) + tv_off);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if (!FIRST) {                                        // the previous stage: its last iterate through the LDS ring
+                const unsigned need = (unsigned)min(s0 + CH - 1 + F, NSP);
+                if (!wait_lds_ge(&lprog[wave - 1], need, a.err)) return;
+#pragma unroll
+                for (int j = 0; j < CH; j++) xb[j] = ring[wave - 1][(s0 + j + F - 1) & (RING - 1)][lane];
+            }
+            if (!LASTW) {                                        // back-pressure: do not overrun slots wave+1 has not read
+                const int need = s0 + CH - 1 - a.lead - F + 2;
+                if (need > 0 && !wait_lds_ge(&lprog[wave + 1], (unsigned)need, a.err)) return;
+            }
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const int s = s0 + j, jj = q * CH + j;
+                float2 sh[F], right0, bottom0;
+                bottom0 = u2f(xb[j]);
+                if (FIRST) right0 = u2f(xr[j]);
+                else {
+                    const float fx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), jj));
+                    const float fy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), jj));
+                    right0.x = lane_shr1(bottom0.x, fx);
+                    right0.y = lane_shr1(bottom0.y, fy);
+                }
+#pragma unroll
+                for (int f = 0; f < F; f++) {
+                    const float fx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), (f + 1) * MC + jj));
+                    const float fy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), (f + 1) * MC + jj));
+                    sh[f].x = lane_shr1(res[f].x, fx);
+                    sh[f].y = lane_shr1(res[f].y, fy);
+                }
+                float2 nres[F];
+#pragma unroll
+                for (int f = 0; f < F; f++) {
+                    const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
+                    const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
+                    const v2f xn = sor_point(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hl[f], sa[f][j], sb[f][j], omega);
+                    nres[f] = make_float2(xn.x, xn.y);
+                    // lane 63's iterate of every sweep is band b+1's lane-0 input (zeros outside the image land in the row pads)
+                    if (publishes && lane == 63) st_x(e_mine + (long)f * a.Wp + (s - 63 - f), f2u(xn.x, xn.y));
+                    if (f == F - 1) {
+                        if (!LASTW) ring[wave][s & (RING - 1)][lane] = f2u(xn.x, xn.y);
+                        else if (row_ok_last && (unsigned)(s - lane - f) < (unsigned)W)
+                            *reinterpret_cast<unsigned long long *>(bx - (long)f * FOFF * 8 + vo8) = f2u(xn.x, xn.y);   // final iterate
+                    }
+                    hl[f] = sb[f][j].z;
+                    selfv[f] = right;
+                }
+#pragma unroll
+                for (int f = 0; f < F; f++) res[f] = nres[f];
+                // refill slot j for step s + CH (beyond the last step this reads zero guards)
+#ifndef SFA_EXPERIMENT_NOLOAD
+#pragma unroll
+                for (int f = 0; f < F; f++) {
+                    sa[f][j] = *reinterpret_cast<const float4 *>(ba[f] + (vo16 + CH * st16));
+                    sb[f][j] = *reinterpret_cast<const float4 *>(bb[f] + (vo16 + CH * st16));
+                }
+#endif
+                if (FIRST) {
+                    xr[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8));
+                    xb[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8 + 8));
+                }
+                vo16 += st16;
+                vo8 += st8;
+            }
+            s0 += CH;
+            // tell wave+1 / wave-1 (LDS words are written in order behind the ring writes)
+            __hip_atomic_store(&lprog[wave], (unsigned)s0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // ---- one macro chunk late, band b+1 (HBM): the previous macro chunk's lane-63 stores are older than the >= 16
+        // operand loads issued since (in-order vmcnt), so this counted wait covers them without draining the prefetch ----
+        if (publishes && !last) {
+            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            if (m > 0 && lane == 0) __hip_atomic_store(gmine, (unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (has_up && !last && !pre) {
+#ifdef SFA_BUILD_TRACE
+            nblock++;
+#endif
+            known_up = wait_ge(g_up, need_up(m + 1), a.err);
+            if (known_up == 0xffffffffu) return;
+            if (!FIRST) { known_up2 = wait_ge(g_up2, need_up2(m + 1), a.err); if (known_up2 == 0xffffffffu) return; }
+            if (tv_lane) tv = ld_x(e_up + s0 + tv_off);
+        }
+    }
+#ifdef SFA_BUILD_TRACE
+    if (tr && lane == 0) { tr[2] = wall_clock64(); tr[3] = nblock; }
+#endif
+    if (publishes) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(gmine, (unsigned)NMC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int F, int MAXW, int CH, int MC, int RING>
 __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NW = a.NW;                                          // K / F pipeline stages (waves)
@@ -319,172 +518,10 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;                     // band-major tickets
-    const int k0 = wave * F;
-    const int W = a.W, H = a.H, RP = a.RP, NCH = a.NCH, NS = a.NS;
-    const float omega = a.omega;
-    const int r0 = 64 * b - k0;
-    const long STEP = RP, FOFF = 2L * RP + 1;
-    const long U0 = (long)(r0 + a.G) * RP + (r0 + a.G);
-
-    const float4 *pa[F], *pb[F];
-    bool row_ok[F], top_ok[F], bot_ok[F];
-    float2 res[F], selfv[F];
-    float hl[F];
-#pragma unroll
-    for (int f = 0; f < F; f++) {
-        pa[f] = a.sa + (size_t)job * a.ent + U0 - f * FOFF;
-        pb[f] = a.sb + (size_t)job * a.ent + U0 - f * FOFF;
-        const int r = r0 + lane - f;
-        row_ok[f] = r >= 0 && r < H;
-        top_ok[f] = r > 0;
-        bot_ok[f] = r < H - 1;
-        res[f] = make_float2(0.f, 0.f); selfv[f] = make_float2(0.f, 0.f); hl[f] = 0.f;
-    }
-    unsigned long long *px = a.x + (size_t)job * a.ent + U0;
-    // edge rows: this band's (written by lane 63) and the band above (read for lane 0)
-    unsigned long long *e_mine = a.edge + (size_t)job * a.edge_job + ((size_t)b * a.K + k0) * a.Wp + a.EP;
-    const unsigned long long *e_up = a.edge + (size_t)job * a.edge_job + ((size_t)(b - 1) * a.K + k0) * a.Wp + a.EP;
-    unsigned *gmine = a.gflags + ((size_t)job * a.NB + b) * NW + wave;
-    const unsigned *g_up = a.gflags + ((size_t)job * a.NB + (b - 1)) * NW + wave;         // (b-1, w)
-    const unsigned *g_up2 = g_up - 1;                                                      // (b-1, w-1)
-    const bool has_up = b > 0, publishes = b + 1 < a.NB;
-    // lane t = fi*CH + j fetches lane 0's "lane -1" value: fi = 0: right of f = 0 (sweep k0-1, column s+1);
-    // fi = f+1: top of f (sweep k0+f, column s-f)
-    const int tfi = lane / CH, tj = lane % CH;
-    const bool tv_lane = has_up && lane < (F + 1) * CH && (tfi > 0 || wave > 0);
-    const long tv_off = tfi == 0 ? (long)(-1) * a.Wp + tj + 1 : (long)(tfi - 1) * a.Wp + tj - (tfi - 1);
-
-    float4 sa[F][CH], sb[F][CH];
-    unsigned long long xb[CH], xr[CH], tv = 0;
-
-    unsigned known_up = 0, known_up2 = 0, pend_up = 0, pend_up2 = 0;
-    auto need_up = [&](int ch) { return (unsigned)min(ch + 1 + (64 + CH - 1) / CH, NCH); };
-    auto need_up2 = [&](int ch) { return (unsigned)min(ch + 1 + (64 + F + CH - 1) / CH, NCH); };
-    auto ready = [&](int ch) { return !has_up || (known_up >= need_up(ch) && (wave == 0 || known_up2 >= need_up2(ch))); };
-
-    // ---- prologue ---------------------------------------------------------------------------------------
-    if (has_up) {
-        known_up = wait_ge(g_up, need_up(1), a.err);
-        if (known_up == 0xffffffffu) return;
-        if (wave > 0) { known_up2 = wait_ge(g_up2, need_up2(1), a.err); if (known_up2 == 0xffffffffu) return; }
-    }
-#pragma unroll
-    for (int j = 0; j < CH; j++)
-#pragma unroll
-        for (int f = 0; f < F; f++) { sa[f][j] = pa[f][(long)j * STEP + lane]; sb[f][j] = pb[f][(long)j * STEP + lane]; }
-    if (wave > 0 && has_up && lane == 0) selfv[0] = u2f(ld_x(e_up - a.Wp));      // x^(k0-1)(0, r0): band above, lane 63, column 0
-    if (wave == 0) {
-        selfv[0] = u2f(px[lane]);
-#pragma unroll
-        for (int j = 0; j < CH; j++) { xr[j] = px[(long)j * STEP + STEP + lane]; xb[j] = px[(long)j * STEP + STEP + 1 + lane]; }
-    }
-    if (tv_lane) tv = ld_x(e_up + tv_off);
-
-    int s0 = 0;
-    for (int ch = 0; ch < NCH; ch++, s0 += CH) {
-        const bool last = ch + 1 >= NCH;
-        // ---- band above: asynchronous view of its progress -----------------------------------------------
-        if (has_up) {
-            known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up));
-            if (wave > 0) known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2));
-            if (!last) {
-                pend_up = __hip_atomic_load(g_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (wave > 0) pend_up2 = __hip_atomic_load(g_up2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        const bool pre = !last && ready(ch + 1);
-        const unsigned long long tv_cur = tv;
-        if (pre && tv_lane) tv = ld_x(e_up + (s0 + CH) + tv_off);
-        // ---- the previous stage of this band: last iterate of wave-1 through the LDS ring --------------------
-        if (wave > 0) {
-            const unsigned need = (unsigned)min(s0 + CH - 1 + F, NS);                    // steps completed by wave-1
-            if (!wait_lds_ge(&lprog[wave - 1], need, a.err)) return;
-#pragma unroll
-            for (int j = 0; j < CH; j++) xb[j] = ring[wave - 1][(s0 + j + F - 1) % RING][lane];
-        }
-        // ---- back-pressure: do not overrun the ring slots wave+1 has not read yet ---------------------------
-        if (wave + 1 < NW) {
-            const int need = s0 + CH - 1 - RING - F + 2;
-            if (need > 0 && !wait_lds_ge(&lprog[wave + 1], (unsigned)need, a.err)) return;
-        }
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const int s = s0 + j;
-            float2 sh[F], right0, bottom0;
-            bottom0 = u2f(xb[j]);
-            if (wave == 0) right0 = u2f(xr[j]);
-            else {
-                const float fx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), j));
-                const float fy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), j));
-                right0.x = lane_shr1(bottom0.x, fx);
-                right0.y = lane_shr1(bottom0.y, fy);
-            }
-#pragma unroll
-            for (int f = 0; f < F; f++) {
-                const float fx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), (f + 1) * CH + j));
-                const float fy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), (f + 1) * CH + j));
-                sh[f].x = lane_shr1(res[f].x, fx);
-                sh[f].y = lane_shr1(res[f].y, fy);
-            }
-            float2 nres[F];
-#pragma unroll
-            for (int f = 0; f < F; f++) {
-                const int c = s - lane - f;
-                const bool valid = row_ok[f] && (unsigned)c < (unsigned)W;
-                const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
-                const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
-                const float2 top = sh[f];
-                const float2 self = selfv[f];
-                const float a11 = sa[f][j].x, a12 = sa[f][j].y, a22 = sa[f][j].z, b1 = sa[f][j].w;
-                const float b2 = sb[f][j].x, hp = sb[f][j].y, vp = sb[f][j].z, vt = sb[f][j].w;
-                float s1 = hp * right.x, s2 = hp * right.y;                               // solver.c:337-338
-                if (top_ok[f]) { s1 = s1 + vt * top.x; s2 = s2 + vt * top.y; }
-                if (bot_ok[f]) { s1 = s1 + vp * bottom.x; s2 = s2 + vp * bottom.y; }
-                s1 = s1 + b1;
-                s2 = s2 + b2;
-                float B1 = s1, B2 = s2;
-                if (c > 0) { B1 = hl[f] * res[f].x + s1; B2 = hl[f] * res[f].y + s2; }  // solver.c:340-341
-                float2 xn;
-                xn.x = self.x + omega * (a11 * B1 + a12 * B2 - self.x);                   // solver.c:342
-                xn.y = self.y + omega * (a12 * B1 + a22 * B2 - self.y);                   // solver.c:343
-                nres[f].x = valid ? xn.x : 0.0f;                                          // 0 outside the image (solver.c:84)
-                nres[f].y = valid ? xn.y : 0.0f;
-                if (publishes && lane == 63 && valid) st_x(e_mine + (long)f * a.Wp + c, f2u(xn.x, xn.y));   // for band b+1's lane 0
-                if (f == F - 1) {
-                    if (wave + 1 < NW) ring[wave][s % RING][lane] = f2u(nres[f].x, nres[f].y);
-                    else if (valid) px[-(long)f * FOFF + lane] = f2u(xn.x, xn.y);          // final iterate
-                }
-                hl[f] = hp;
-                selfv[f] = right;
-            }
-#pragma unroll
-            for (int f = 0; f < F; f++) res[f] = nres[f];
-            if (!last) {
-#pragma unroll
-                for (int f = 0; f < F; f++) { sa[f][j] = pa[f][(long)CH * STEP + lane]; sb[f][j] = pb[f][(long)CH * STEP + lane]; }
-                if (wave == 0) { xr[j] = px[(long)CH * STEP + STEP + lane]; xb[j] = px[(long)CH * STEP + STEP + 1 + lane]; }
-            }
-#pragma unroll
-            for (int f = 0; f < F; f++) { pa[f] += STEP; pb[f] += STEP; }
-            px += STEP;
-        }
-        // ---- tell wave+1 (LDS, in order behind the ring writes) and, one chunk late, band b+1 (HBM) -----------
-        __hip_atomic_store(&lprog[wave], (unsigned)min(s0 + CH, NS), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (publishes && !last) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH - 1) : "memory");            // as in k_sor_solve
-            if (ch > 0 && lane == 0) __hip_atomic_store(gmine, (unsigned)ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!last && !pre) {
-            known_up = wait_ge(g_up, need_up(ch + 1), a.err);
-            if (known_up == 0xffffffffu) return;
-            if (wave > 0) { known_up2 = wait_ge(g_up2, need_up2(ch + 1), a.err); if (known_up2 == 0xffffffffu) return; }
-            if (tv_lane) tv = ld_x(e_up + (s0 + CH) + tv_off);
-        }
-    }
-    if (publishes) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(gmine, (unsigned)NCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, job, b, wave, lane);
+    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, job, b, wave, lane);
+    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, job, b, wave, lane);
+    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, job, b, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -529,8 +566,8 @@ __global__ void __launch_bounds__(256) k_sor_prepare(PrepArgs p) {
             const float A11 = p.a22[o] + dpsis, A22 = p.a11[o] + dpsis;                   // solver.c:102
             const float det = A11 * A22 - m12 * m12;
             const float i11 = __fdiv_rn(A11, det), i22 = __fdiv_rn(A22, det), i12 = __fdiv_rn(m12, -det);   // solver.c:104-106
-            tA[rl][tx] = make_float4(i11, i12, i22, p.b1[o]);
-            tB[rl][tx] = make_float4(p.b2[o], hp, vp, vt);
+            tA[rl][tx] = make_float4(i11, i12, i22, vt);                                  // vt = 0 at row 0
+            tB[rl][tx] = make_float4(p.b1[o], p.b2[o], hp, r < p.H - 1 ? vp : 0.0f);      // no bottom edge in the last row
             tX[rl][tx] = make_float2(p.du[o], p.dv[o]);
             if (p.inv_out) { p.a11[o] = i11; p.a12[o] = i12; p.a22[o] = i22; }
         }
@@ -589,21 +626,21 @@ __global__ void k_sor_readable(float *du_, float *dv_, const float *a11_, const 
 // host side
 // ---------------------------------------------------------------------------------------------------
 // band kernel (all K sweeps of a band in one workgroup): F fused sweeps per wave, NW = K/F waves; 0 = not applicable
-static int band_shape(int K) {
-    int F = 0;
-    const char *e = getenv("SFA_SOR_BAND");                     // opt-in while the task kernel is still faster
-    if (!e) return 0;
-    F = atoi(e);
+static int band_shape(int K, int nb) {
+    // default: batches (>= 16 systems in lockstep) take the band kernel, single solves the task kernel whose K stages
+    // spread over K CUs (shorter critical path); SFA_SOR_BAND = 0 (never) / 1..3 (always, that many fused sweeps)
+    int F = nb >= 16 ? 3 : 0;
+    if (const char *e = getenv("SFA_SOR_BAND")) F = atoi(e);
     if (F <= 0 || F > 3) return 0;
-    auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f >= 1 && K / f <= (f == 3 ? 10 : 16); };
-    if (F && fits(F)) return F;
+    auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f <= (f == 3 ? 10 : 16); };
+    if (fits(F)) return F;
     if (fits(3)) return 3;
     if (fits(2)) return 2;
     if (fits(1)) return 1;
     return 0;
 }
-constexpr int kBandCH = 4;
-static int band_ring(int F) { return F == 3 ? 32 : 20; }     // LDS ring slots per wave pair (144 KB / 140 KB / 150 KB at most)
+constexpr int kBandCH = 2, kBandMC = 8;        // operand ring / LDS hand-over every 2 steps, HBM hand-over every 8
+static int band_ring(int F) { return F == 3 ? 32 : 16; }     // LDS ring slots per wave pair, power of two (144 KB / 112 KB / 120 KB at most)
 
 // fused iterations per wave / steps per hand-over chunk (env SFA_SOR_F, SFA_SOR_CH override the default)
 static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
@@ -618,8 +655,8 @@ static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
 
 int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     int F_, CH_;
-    const int band_ = band_shape(K_);
-    if (band_) { F_ = band_; CH_ = kBandCH; }
+    const int band_ = band_shape(K_, nb_);
+    if (band_) { F_ = band_; CH_ = kBandMC; }
     else sor_shape(K_, nb_ * ((h_ + K_ - 1 + 63) / 64) * K_, F_, CH_);
     if (ctx == c && w == w_ && h == h_ && K == K_ && nb == nb_ && F == F_ && CHK == CH_ && band == band_) return SFA_OK;
     ctx = c; w = w_; h = h_; K = K_; nb = nb_; F = F_; CHK = CH_; band = band_;
@@ -629,15 +666,17 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     RP = round_up(h + 2 * G, 16);
     NS = w + 63 + F - 1;
     NCH = (NS + CHK - 1) / CHK;
+    if (band) NS = NCH * CHK;                                   // the band kernel runs whole macro chunks
     ND = w + 64 * NB + 2 * CHK + F + 2 * G + 8;
     ntasks = NB * NG;                                           // band kernel: NG = NW waves per band workgroup
     ent = (long)ND * RP;
     if (band) {
-        EP = 8;
+        EP = 72;                                                    // columns s-63-f >= -66 of the unconditional lane-63 stores
         Wp = round_up(EP + NS + 2 * CHK + 8, 8);
         edge_job = (long)NB * K * Wp;
         SFA_TRY(edge.alloc(c, (size_t)nb * edge_job * sizeof(unsigned long long)));
         SFA_HIP(c, hipMemsetAsync(edge.p, 0, (size_t)nb * edge_job * sizeof(unsigned long long), c->stream));
+        if (getenv("SFA_SOR_TRACE")) SFA_TRY(trace.alloc(c, (size_t)nb * NB * NG * 4 * sizeof(unsigned long long)));
     }
     SFA_TRY(sa.alloc(c, (size_t)nb * ent * sizeof(float4)));
     SFA_TRY(sb.alloc(c, (size_t)nb * ent * sizeof(float4)));
@@ -685,12 +724,15 @@ int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, fl
         BandArgs ba;
         ba.sa = p.sa; ba.sb = p.sb; ba.x = p.x; ba.edge = (unsigned long long *)ws.edge.p; ba.gflags = p.flags; ba.err = c->d_err;
         ba.ent = ws.ent; ba.edge_job = ws.edge_job; ba.W = g.w; ba.H = g.h; ba.K = K; ba.NB = ws.NB; ba.NW = ws.NG; ba.RP = ws.RP; ba.G = ws.G;
+        ba.trace = (unsigned long long *)ws.trace.p;
+        ba.lead = band_ring(ws.F);
+        if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(kBandCH + 2, std::min(atoi(e), band_ring(ws.F)));
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
         const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + (ws.NG + 1) * sizeof(unsigned) + 16;
-        if (ws.F == 3)      hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, 32>), bgrid, bblock, lds, c->stream, ba);
-        else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, kBandCH, 20>), bgrid, bblock, lds, c->stream, ba);
-        else                hipLaunchKernelGGL((k_sor_band<1, 16, kBandCH, 20>), bgrid, bblock, lds, c->stream, ba);
+        if (ws.F == 3)      hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, kBandMC, 32>), bgrid, bblock, lds, c->stream, ba);
+        else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
+        else                hipLaunchKernelGGL((k_sor_band<1, 16, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
     } else {
     const dim3 sgrid(g.nb * ws.ntasks), sblock(64);
     if (ws.F == 1)                      hipLaunchKernelGGL((k_sor_solve<1, 8>), sgrid, sblock, 0, c->stream, a);

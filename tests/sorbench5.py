@@ -1,0 +1,20 @@
+import sys
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import numpy as np, slowflow_amd as sfa
+from synth import sor_system
+ctx=sfa.Context(0)
+K=30
+B=int(sys.argv[1]) if len(sys.argv)>1 else 32
+for (W,H) in [(1024,436),(512,218),(256,109),(128,54),(64,27)]:
+    rng=np.random.default_rng(0)
+    s=sor_system(rng,W,H)
+    planes=[np.ascontiguousarray(s[k]) for k in ("du","dv","a11","a12","a22","b1","b2","sh","sv")]
+    sb=sfa.SorBatch(ctx,W,H,B)
+    for b in range(B): sb.upload(b,*planes)
+    sb.run(K,1.9); ctx.sync()
+    ctx.profile_enable(True)
+    for _ in range(10): sb.run(K,1.9)
+    n,ms,by=ctx.profile_read(); ctx.profile_enable(False)
+    per=ms/n
+    print(f"{W}x{H} batch {B:3d}: {per*1e3:8.1f} us/launch  {per*1e3/B:6.1f} us/solve  {by/n/(per*1e-3)/1e9:7.0f} GB/s alg", flush=True)
+    sb.close()

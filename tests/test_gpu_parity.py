@@ -250,6 +250,34 @@ def test_sor_full_size_and_batch(ctx, oracle):
     sb.close()
 
 
+SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1"}, "task_f2": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "2"},
+                "task_f3": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "3", "SFA_SOR_CH": "4"},
+                "band_f1": {"SFA_SOR_BAND": "1"}, "band_f2": {"SFA_SOR_BAND": "2"}, "band_f3": {"SFA_SOR_BAND": "3"}}
+
+
+@pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))
+@pytest.mark.parametrize("w,h,K", [(67, 45, 6), (130, 98, 12), (300, 70, 30), (64, 200, 6), (1024, 436, 30), (2, 2, 6), (700, 5, 30)])
+def test_sor_kernel_variants(ctx, oracle, monkeypatch, variant, w, h, K):
+    """every solver kernel (task pipeline with 1/2/3 fused sweeps per wave, band pipeline with 1/2/3) gives the
+    raster-order result bit for bit, for each element of a batch of two different systems"""
+    for k, v in SOR_VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(w + 3 * h + K)
+    systems = [sor_system(rng, w, h) for _ in range(2)]
+    for s in systems:
+        s["du"][:, :w] = rng.uniform(-.2, .2, (h, w)); s["dv"][:, :w] = rng.uniform(-.2, .2, (h, w))
+    sb = sfa.SorBatch(ctx, w, h, 2)
+    for b, s in enumerate(systems):
+        sb.upload(b, *[c_(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb.run(K, 1.9)
+    for b, s in enumerate(systems):
+        a = copy_sys(s)
+        oracle.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, K, 1.9)
+        du, dv = sb.download(b)
+        assert np.array_equal(valid(a["du"], w), valid(du, w)) and np.array_equal(valid(a["dv"], w), valid(dv, w))
+    sb.close()
+
+
 def test_sor_fixed_point_property(ctx):
     """size-independent property: started from the converged solution one more sweep changes nothing beyond rounding,
     and the residual of the original system is small"""
