@@ -67,53 +67,54 @@ static PenaltyDev pen(const sfa_penalty &p) { return PenaltyDev{p.id, p.eps, p.t
 // Element arena layout (floats, per batch element), PL = pitch*h:
 //   planes : wx wy uu vv du dv odu odv sh sv a11 a12 a22 b1 b2 occ dpsis   (17 PL)
 //   masks  : 2*ref PL
-//   warped : w_s (3 PL), w_sp1 (3 PL)
-//   stacks : [slot][succ|toref][24 PL]
+//   warped : [slot][w_s|w_sp1] (3 PL each); a factor-0 warp is the frame itself and is not materialised
+//   stacks : [slot][succ|toref][24 PL] -- only in the unfused form (SFA_UNFUSED=1, kept to cross-check the fused kernel)
 //   frames : F x 3 PL
 // ---------------------------------------------------------------------------------------------------
 enum { P_WX = 0, P_WY, P_UU, P_VV, P_DU, P_DV, P_ODU, P_ODV, P_SH, P_SV, P_A11, P_A12, P_A22, P_B1, P_B2, P_OCC, P_DPSIS, P_COUNT };
 
 struct Level {
     int w = 0, h = 0, pitch = 0, lstride = 0, ref = 0, F = 0, nb = 0;
+    bool fused = true;
     long pl = 0, es = 0;
-    long off_masks = 0, off_ws = 0, off_wsp1 = 0, off_stacks = 0, off_frames = 0, off_tmp = 0;
+    long off_masks = 0, off_warp = 0, off_stacks = 0, off_frames = 0, off_tmp = 0;
     float *base = nullptr;    // element 0
     float *plane(int i) const { return base + (long)i * pl; }
     float *mask(int s) const { return base + off_masks + (long)s * pl; }
     float *stack(int s, int toref) const { return base + off_stacks + ((long)s * 2 + toref) * 24 * pl; }
+    float *warp(int s, int sp1) const { return base + off_warp + ((long)s * 2 + sp1) * 3 * pl; }
     float *frame(int f) const { return base + off_frames + (long)f * 3 * pl; }
     Geo geo(unsigned long long active = ~0ull) const { return Geo{w, h, pitch, pl, es, nb, active}; }
-    static long elem_floats(int pitch, int h, int ref) {
+    static long elem_floats(int pitch, int h, int ref, bool fused) {
         const long pl = (long)pitch * h;
-        return pl * (P_COUNT + 2 * ref + 6 + 2L * ref * 2 * 24 + (2L * ref + 1) * 3 + 6 /* tmp colour images for the pyramid */);
+        return pl * (P_COUNT + 2 * ref + 2L * ref * 6 + (fused ? 0 : 2L * ref * 2 * 24) + (2L * ref + 1) * 3 + 6 /* tmp colour images for the pyramid */);
     }
-    void layout(float *b, int w_, int h_, int lstride_, int ref_, int nb_, long es_) {
-        base = b; w = w_; h = h_; pitch = dev_pitch(w_); lstride = lstride_; ref = ref_; F = 2 * ref_ + 1; nb = nb_; es = es_;
+    void layout(float *b, int w_, int h_, int lstride_, int ref_, int nb_, long es_, bool fused_) {
+        base = b; w = w_; h = h_; pitch = dev_pitch(w_); lstride = lstride_; ref = ref_; F = 2 * ref_ + 1; nb = nb_; es = es_; fused = fused_;
         pl = (long)pitch * h;
         off_masks = (long)P_COUNT * pl;
-        off_ws = off_masks + 2L * ref * pl;
-        off_wsp1 = off_ws + 3 * pl;
-        off_stacks = off_wsp1 + 3 * pl;
-        off_frames = off_stacks + 2L * ref * 2 * 24 * pl;
+        off_warp = off_masks + 2L * ref * pl;
+        off_stacks = off_warp + 2L * ref * 6 * pl;
+        off_frames = off_stacks + (fused ? 0 : 2L * ref * 2 * 24 * pl);
         off_tmp = off_frames + (long)F * 3 * pl;
     }
 };
 
 struct ChannelWeights { const float *dev = nullptr; long pl = 0, es = 0; int pitch = 0, stride0 = 0; };
 
-// get_derivatives (variational_mt.cpp:87-166)
+// the image pair of slot s (variational_mt.cpp:98-110): frames s, s+1 warped by (s-ref), (s-ref+1) flow steps
+static const float *pair_image(const Level &L, int s, int sp1) { return (s + sp1 - L.ref == 0) ? L.frame(s + sp1) : L.warp(s, sp1); }
+
+// get_derivatives (variational_mt.cpp:87-166).  Fused form: only the warps; the filters run inside the assembly kernel.
 static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, unsigned long long active, const bool need_toref[2 * SFA_MAX_REF]) {
     const Geo g = L.geo(active);
     const int ref = L.ref;
-    float *w_s = L.base + L.off_ws, *w_sp1 = L.base + L.off_wsp1;
     for (int s = p.one_direction ? ref : 0; s < 2 * ref; s++) {
-        if (s < ref) {
-            launch_warp(c, g, w_s, L.mask(s), L.frame(s), L.plane(P_WX), L.plane(P_WY), s - ref, L.es);           // :100
-            launch_warp(c, g, w_sp1, nullptr, L.frame(s + 1), L.plane(P_WX), L.plane(P_WY), s - ref + 1, L.es);  // :103
-        } else {
-            launch_warp(c, g, w_s, nullptr, L.frame(s), L.plane(P_WX), L.plane(P_WY), s - ref, L.es);            // :106
-            launch_warp(c, g, w_sp1, L.mask(s), L.frame(s + 1), L.plane(P_WX), L.plane(P_WY), s - ref + 1, L.es); // :109
-        }
+        // the warp that also yields the slot's mask: w_s backwards (:100), w_sp1 forwards (:109); a zero-step warp is a copy (:723-728)
+        if (s - ref != 0) launch_warp(c, g, L.warp(s, 0), s < ref ? L.mask(s) : nullptr, L.frame(s), L.plane(P_WX), L.plane(P_WY), s - ref, L.es);
+        if (s - ref + 1 != 0) launch_warp(c, g, L.warp(s, 1), s < ref ? nullptr : L.mask(s), L.frame(s + 1), L.plane(P_WX), L.plane(P_WY), s - ref + 1, L.es);
+        if (L.fused) continue;
+        const float *w_s = pair_image(L, s, 0), *w_sp1 = pair_image(L, s, 1);
         launch_deriv_stack(c, g, L.stack(s, 0), w_s, w_sp1, L.es, L.es);                                        // :113-133
         // the to-reference stack (:136-161) only feeds add_data_and_match_ref (omega > 0) and optimizeOcc
         if (need_toref[s]) {
@@ -167,6 +168,14 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             need_toref[ref + s] = true;
         }
     }
+    for (int t = 0; t < aa.n; t++) {                                     // slot and image pair of each term
+        Term &T = aa.t[t];
+        const int slot = (int)((T.mask_off - L.off_masks) / L.pl);
+        const float *i1 = pair_image(L, slot, 0), *i2 = pair_image(L, slot, 1);
+        if (T.is_ref) { if (slot < ref) i2 = L.frame(ref); else i1 = L.frame(ref); }                         // :139-144
+        T.i1_off = i1 - L.base; T.i2_off = i2 - L.base; T.backward = slot < ref;
+    }
+    aa.data_norm = data_norm; aa.one_direction = p.one_direction;
     for (int t = 0; t < aa.n; t++)
         if (aa.t[t].is_ref && aa.t[t].s == 0) return set_error(c, SFA_ERR_REF_FRAME, "Frame compared to reference frame is the reference frame itself!");
     aa.dt_norm = p.dataterm_norm;
@@ -188,7 +197,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
         for (int outer = 0; outer < p.niter_outer; outer++) {
             g.active = active;
             if (outer > 0) get_derivatives(c, L, p, active, need_toref);                                    // :289-290
-            launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);           // :293-320
+            if (!L.fused) launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);   // :293-320
             launch_zero_planes(c, g, L.plane(P_DU), 2);                                                      // :323-324 (du, dv adjacent)
             unsigned long long in_active = active;
             for (int inner = 0; inner < p.niter_inner; inner++) {
@@ -197,8 +206,12 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                    // :329-330
                 launch_smoothness(c, gi, p.smoothing, L.plane(P_SH), L.plane(P_SV), L.plane(P_UU), L.plane(P_VV), L.plane(P_DPSIS), p.alpha,
                                   pen(p.robust_reg));                                                       // :333
-                launch_assemble(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
-                                L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV));   // :336-365
+                if (L.fused)
+                    launch_assemble_images(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
+                                           L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV), L.plane(P_OCC));   // :293-365
+                else
+                    launch_assemble(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
+                                    L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV));   // :336-365
                 if (in_active == all) {
                     SFA_TRY(sor_run(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1),
                                     L.plane(P_B2), L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega, false));   // :368
@@ -308,10 +321,11 @@ struct sfa_job {
     double mpix_iters = 0;
     Level level(int l) const {
         Level Lv;
-        Lv.layout(arena.f() + level_off[l], ws[l], hs[l], l == 0 ? host_stride0 : host_stride(ws[l]), ref, nb, es);
+        Lv.layout(arena.f() + level_off[l], ws[l], hs[l], l == 0 ? host_stride0 : host_stride(ws[l]), ref, nb, es, fused);
         return Lv;
     }
     int host_stride0 = 0;
+    bool fused = true;                 // false: SFA_UNFUSED=1 at creation (stack planes materialised; cross-check only)
 };
 
 extern "C" {
@@ -706,11 +720,12 @@ int sfa_job_create(sfa_ctx *ctx, const sfa_params *p, int w, int h, int batch, s
     j->ctx = ctx; j->p = *p; j->w = w; j->h = h; j->nb = batch; j->ref = p->S - 1; j->F = 2 * j->ref + 1;
     j->L = pyramid_sizes(w, h, p->layers, p->p_scale, j->ws, j->hs);
     CHECK_ARGS(j->L >= 1, "image too small for even one pyramid level");
+    { const char *e = getenv("SFA_UNFUSED"); j->fused = !(e && atoi(e)); }
     j->level_off.resize(j->L);
     long off = 0;
     for (int l = 0; l < j->L; l++) {
         j->level_off[l] = off;
-        off += Level::elem_floats(dev_pitch(j->ws[l]), j->hs[l], j->ref);
+        off += Level::elem_floats(dev_pitch(j->ws[l]), j->hs[l], j->ref, j->fused);
     }
     j->es = off;
     j->host_stride0 = host_stride(w);

@@ -144,48 +144,70 @@ void launch_warp(sfa_ctx *c, const Geo &g, float *dst3, float *mask, const float
 
 // ---------------------------------------------------------------------------------------------------
 // K2/K3 derivative stack of get_derivatives (variational_mt.cpp:113-133)
-//   pass 1: Iz = I1 - I2, Ix = D5x(M), Iy = D5y(M) with M = .5*(I2 + I1) formed on the fly
-//   pass 2: Ixx = D5x(Ix), Ixy = D5y(Ix), Iyy = D5y(Iy), Ixz = D5x(Iz), Iyz = D5y(Iz)
+//   stage 1: Iz = I1 - I2, Ix = D5x(M), Iy = D5y(M) with M = .5*(I2 + I1) formed on the fly
+//   stage 2: Ixx = D5x(Ix), Ixy = D5y(Ix), Iyy = D5y(Iy), Ixz = D5x(Iz), Iyz = D5y(Iz)
 // out24 plane order: Ix,Iy,Iz,Ixx,Ixy,Iyy,Ixz,Iyz, 3 channels each.
 // ---------------------------------------------------------------------------------------------------
-struct MeanAcc {
-    const float *a, *b; int pitch;   // a = I1, b = I2
-    __device__ __forceinline__ float operator()(int x, int y) const {
-        const size_t o = (size_t)y * pitch + x;
-        return 0.5f * (b[o] + a[o]);                                 // :120
-    }
-};
 
-__global__ void k_deriv1(float *__restrict__ out24, const float *__restrict__ I1, const float *__restrict__ I2, Geo g, long es1, long es2) {
+// One block = a 64x16 output tile of one (element, channel).  M and Iz are staged in LDS with a halo of 4, Ix/Iy are
+// formed there with a halo of 2, and all eight planes leave in one pass: 2 plane reads + 8 plane writes per pixel
+// instead of 5 + 8 through two kernels that lean on the caches for the vertical taps.  Border handling is the
+// reference's (replicated columns, folded row coefficients), applied per stage exactly as the two-pass form does:
+// clamped taps always land inside the image, hence inside the staged halo.
+constexpr int DT_X = 64, DT_Y = 16, DT_H = 4, DT_W = DT_X + 2 * DT_H, DT_R = DT_Y + 2 * DT_H;
+struct TileAcc {
+    const float *t; int x0, y0;      // global coordinates of the tile's LDS origin
+    __device__ __forceinline__ float operator()(int x, int y) const { return t[(y - y0) * DT_W + (x - x0)]; }
+};
+__global__ void __launch_bounds__(256) k_deriv_stack(float *__restrict__ out24, const float *__restrict__ I1, const float *__restrict__ I2, Geo g, long es1, long es2) {
+    __shared__ float sM[DT_R * DT_W], sZ[DT_R * DT_W], sX[DT_R * DT_W], sY[DT_R * DT_W];
     const int b = blockIdx.z / 3, ch = blockIdx.z % 3;
     if (!elem_active(g.active, b)) return;
-    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
-    if (x >= g.w || y >= g.h) return;
+    const int x0 = blockIdx.x * DT_X - DT_H, y0 = blockIdx.y * DT_Y - DT_H;
     const float *a = I1 + b * es1 + ch * g.pl, *bb = I2 + b * es2 + ch * g.pl;
+    for (int i = threadIdx.x; i < DT_R * DT_W; i += 256) {
+        const int x = x0 + i % DT_W, y = y0 + i / DT_W;
+        if (x >= 0 && x < g.w && y >= 0 && y < g.h) {
+            const size_t o = (size_t)y * g.pitch + x;
+            const float va = a[o], vb = bb[o];
+            sM[i] = 0.5f * (vb + va);                                 // :120
+            sZ[i] = va - vb;                                          // Iz  :122
+        }
+    }
+    __syncthreads();
+    const TileAcc m{sM, x0, y0};
+    constexpr int W1 = DT_X + 4, R1 = DT_Y + 4;                       // halo of 2
+    for (int i = threadIdx.x; i < R1 * W1; i += 256) {
+        const int lx = 2 + i % W1, ly = 2 + i / W1;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= 0 && x < g.w && y >= 0 && y < g.h) {
+            sX[ly * DT_W + lx] = d5x(m, x, y, g.w);                   // Ix  :127
+            sY[ly * DT_W + lx] = d5y(m, x, y, g.h);                   // Iy  :128
+        }
+    }
+    __syncthreads();
+    const TileAcc ix{sX, x0, y0}, iy{sY, x0, y0}, iz{sZ, x0, y0};
     float *o24 = out24 + b * g.es;
-    const size_t o = (size_t)y * g.pitch + x;
-    MeanAcc m{a, bb, g.pitch};
-    o24[(0 * 3 + ch) * g.pl + o] = d5x(m, x, y, g.w);                 // Ix  :127
-    o24[(1 * 3 + ch) * g.pl + o] = d5y(m, x, y, g.h);                 // Iy  :128
-    o24[(2 * 3 + ch) * g.pl + o] = a[o] - bb[o];                      // Iz  :122
-}
-__global__ void k_deriv2(float *__restrict__ out24, Geo g) {
-    const int b = blockIdx.z / 3, ch = blockIdx.z % 3;
-    if (!elem_active(g.active, b)) return;
-    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
-    if (x >= g.w || y >= g.h) return;
-    float *o24 = out24 + b * g.es;
-    const size_t o = (size_t)y * g.pitch + x;
-    PlaneAcc ix{o24 + (0 * 3 + ch) * g.pl, g.pitch}, iy{o24 + (1 * 3 + ch) * g.pl, g.pitch}, iz{o24 + (2 * 3 + ch) * g.pl, g.pitch};
-    o24[(3 * 3 + ch) * g.pl + o] = d5x(ix, x, y, g.w);                // Ixx :129
-    o24[(4 * 3 + ch) * g.pl + o] = d5y(ix, x, y, g.h);                // Ixy :130
-    o24[(5 * 3 + ch) * g.pl + o] = d5y(iy, x, y, g.h);                // Iyy :131
-    o24[(6 * 3 + ch) * g.pl + o] = d5x(iz, x, y, g.w);                // Ixz :132
-    o24[(7 * 3 + ch) * g.pl + o] = d5y(iz, x, y, g.h);                // Iyz :133
+    const int tx = threadIdx.x & 63;
+    const int x = x0 + DT_H + tx;
+    if (x >= g.w) return;
+#pragma unroll
+    for (int k = 0; k < DT_Y / 4; k++) {
+        const int y = y0 + DT_H + (threadIdx.x >> 6) + 4 * k;
+        if (y >= g.h) break;
+        const size_t o = (size_t)y * g.pitch + x;
+        o24[(0 * 3 + ch) * g.pl + o] = ix(x, y);
+        o24[(1 * 3 + ch) * g.pl + o] = iy(x, y);
+        o24[(2 * 3 + ch) * g.pl + o] = iz(x, y);
+        o24[(3 * 3 + ch) * g.pl + o] = d5x(ix, x, y, g.w);            // Ixx :129
+        o24[(4 * 3 + ch) * g.pl + o] = d5y(ix, x, y, g.h);            // Ixy :130
+        o24[(5 * 3 + ch) * g.pl + o] = d5y(iy, x, y, g.h);            // Iyy :131
+        o24[(6 * 3 + ch) * g.pl + o] = d5x(iz, x, y, g.w);            // Ixz :132
+        o24[(7 * 3 + ch) * g.pl + o] = d5y(iz, x, y, g.h);            // Iyz :133
+    }
 }
 void launch_deriv_stack(sfa_ctx *c, const Geo &g, float *out24, const float *I1, const float *I2, long es1, long es2) {
-    hipLaunchKernelGGL(k_deriv1, grid2d(g, 3), block2d(), 0, c->stream, out24, I1, I2, g, es1, es2);
-    hipLaunchKernelGGL(k_deriv2, grid2d(g, 3), block2d(), 0, c->stream, out24, g);
+    hipLaunchKernelGGL(k_deriv_stack, dim3((g.w + DT_X - 1) / DT_X, (g.h + DT_Y - 1) / DT_Y, g.nb * 3), dim3(256), 0, c->stream, out24, I1, I2, g, es1, es2);
 }
 
 // generic single-filter convolution (stage API: convolve_horiz / convolve_vert, image.c:400-526)
@@ -636,6 +658,182 @@ __global__ void __launch_bounds__(BX *BY) k_assemble(AssembleArgs a, const float
 void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                      const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv) {
     hipLaunchKernelGGL(k_assemble, grid2d(g), block2d(), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, g);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K6 fused: the derivative stack of every term is formed in LDS from its image pair (stage 1/2 of k_deriv_stack)
+// and consumed on the spot by the term arithmetic above -- the 24-plane stacks never exist in HBM.  One block = a
+// 64x16 pixel tile of one element; per term and channel M (halo 4) is staged, Ix/Iy/Iz (halo 2) kept for the three
+// channels, then each thread runs the term for its 4 pixels.  Mask weights (variational_mt.cpp:293-320) are applied
+// on the fly from the occlusion plane.  Same operations in the same order as the unfused kernels: bit-identical.
+// ---------------------------------------------------------------------------------------------------
+constexpr int AT_W1 = DT_X + 4;                                      // halo-2 planes
+struct Tile2Acc {
+    const float *t; int x0, y0;      // global coordinates of the halo-2 origin
+    __device__ __forceinline__ float operator()(int x, int y) const { return t[(y - y0) * AT_W1 + (x - x0)]; }
+};
+// interior taps at fixed LDS offsets (the generic accessors cost more in index arithmetic than the filter itself)
+template <int W>
+__device__ __forceinline__ float d5x_in(const float *t, int c) { return tap5(t[c - 2], t[c - 1], t[c], t[c + 1], t[c + 2]); }
+template <int W>
+__device__ __forceinline__ float d5y_in(const float *t, int c) { return tap5(t[c - 2 * W], t[c - W], t[c], t[c + W], t[c + 2 * W]); }
+
+// TY rows x 64 columns per block of NT threads (NT/64 rows in flight, TY*64/NT pixels per thread).
+// Column borders: the staged planes carry REPLICATED columns outside the image, so the clamped taps of image.c:501-516
+// become fixed LDS offsets.  Row borders use folded coefficients (different expressions, image.c:433-457): rows are
+// wave-uniform here, so that is a scalar branch.
+template <int TY, int NT, int MINB>
+__global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, const float *__restrict__ base, float *__restrict__ a11, float *__restrict__ a12,
+                                                              float *__restrict__ a22, float *__restrict__ b1, float *__restrict__ b2,
+                                                              const float *__restrict__ du, const float *__restrict__ dv, const float *__restrict__ uu,
+                                                              const float *__restrict__ vv, const float *__restrict__ sh, const float *__restrict__ sv,
+                                                              const float *__restrict__ occ, Geo g) {
+    constexpr int TR = TY + 2 * DT_H, AT_R1 = TY + 4, NR = NT / 64, NP = TY / NR;
+    __shared__ float sM[TR * DT_W];
+    __shared__ float sX[3][AT_R1 * AT_W1], sY[3][AT_R1 * AT_W1], sZ[3][AT_R1 * AT_W1];
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int x0 = blockIdx.x * DT_X - DT_H, y0 = blockIdx.y * TY - DT_H;       // origin of the halo-4 tile
+    const long eb = b * g.es;
+    const int tx = threadIdx.x & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // one row per wave
+    const int x = x0 + DT_H + tx;
+    Acc A[NP];
+    float u[NP], v[NP], wk[NP][3], fwd[NP], bwd[NP];
+    bool ok[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const int y = y0 + DT_H + ty + NR * k;
+        ok[k] = x < g.w && y < g.h;
+        A[k].a11 = A[k].a12 = A[k].a22 = A[k].b1 = A[k].b2 = 0.0f;                    // image_erase, variational_mt.cpp:336-340
+        u[k] = v[k] = 0.0f; fwd[k] = bwd[k] = 0.0f;
+        wk[k][0] = wk[k][1] = wk[k][2] = 1.0f;
+        if (!ok[k]) continue;
+        const size_t o = (size_t)y * g.pitch + x;
+        u[k] = du[eb + o]; v[k] = dv[eb + o];
+        if (a.chw) {                                                                   // see k_assemble
+            const long lin = (long)y * a.lstride + x;
+            const long r0 = lin / a.chw_stride0, c0 = lin % a.chw_stride0;
+            const float *cw = a.chw + b * a.chw_es + r0 * a.chw_pitch + c0;
+            wk[k][0] = cw[0]; wk[k][1] = cw[a.chw_pl]; wk[k][2] = cw[2 * a.chw_pl];
+        }
+        const float oc = occ[eb + o];                                                  // k_mask_weight
+        float factor = (oc == 0.0f) ? 1.0f : 0.0f;
+        factor = (1 + factor) * a.data_norm;
+        bwd[k] = __fdiv_rn((oc >= 0.0f) ? 1.0f : 0.0f, factor);
+        fwd[k] = __fdiv_rn((oc <= 0.0f) ? 1.0f : 0.0f, factor);
+    }
+    const TileAcc m4{sM, x0, y0};
+    // this thread's staging columns: tile column tx (and 64 + tx for the first lanes), source column clamped into the image
+    const int gxa = clampi(x0 + tx, 0, g.w - 1), gxb = clampi(x0 + 64 + tx, 0, g.w - 1);
+    // stage-1 columns of the halo-2 region; sM index shift that realises X(clamp(x), y) for columns outside the image
+    const int sxa = clampi(x0 + 2 + tx, 0, g.w - 1) - (x0 + 2 + tx), sxb = clampi(x0 + 66 + tx, 0, g.w - 1) - (x0 + 66 + tx);
+    for (int t = 0; t < a.n; t++) {
+        const Term &T = a.t[t];
+        for (int ch = 0; ch < 3; ch++) {
+            const float *pa = base + eb + T.i1_off + ch * g.pl, *pb = base + eb + T.i2_off + ch * g.pl;
+            __syncthreads();                                       // sM / this channel's planes are free again
+            // stage 0: M (halo 4), Iz (halo 2); rows outside the image are never read
+            for (int ly = ty; ly < TR; ly += NR) {
+                const int gy = y0 + ly;
+                if (gy < 0 || gy >= g.h) continue;
+                const size_t orow = (size_t)gy * g.pitch;
+                const bool zrow = ly >= 2 && ly < TR - 2;
+                {
+                    const float va = pa[orow + gxa], vb = pb[orow + gxa];
+                    sM[ly * DT_W + tx] = 0.5f * (vb + va);                             // variational_mt.cpp:120
+                    if (zrow && tx >= 2) sZ[ch][(ly - 2) * AT_W1 + (tx - 2)] = va - vb;                 // :122
+                }
+                if (tx < DT_W - 64) {
+                    const float va = pa[orow + gxb], vb = pb[orow + gxb];
+                    sM[ly * DT_W + 64 + tx] = 0.5f * (vb + va);
+                    if (zrow && tx < DT_W - 66) sZ[ch][(ly - 2) * AT_W1 + (62 + tx)] = va - vb;
+                }
+            }
+            __syncthreads();
+            // stage 1: Ix, Iy on the halo-2 region
+            for (int ly = ty; ly < AT_R1; ly += NR) {
+                const int gy = y0 + 2 + ly;
+                if (gy < 0 || gy >= g.h) continue;
+                const bool y_in = gy >= 2 && gy + 2 < g.h;
+                const int c = (ly + 2) * DT_W + 2;
+                sX[ch][ly * AT_W1 + tx] = d5x_in<DT_W>(sM, c + tx + sxa);                                // :127
+                if (tx < AT_W1 - 64) sX[ch][ly * AT_W1 + 64 + tx] = d5x_in<DT_W>(sM, c + 64 + tx + sxb);
+                if (y_in) {                                                                               // :128
+                    sY[ch][ly * AT_W1 + tx] = d5y_in<DT_W>(sM, c + tx);
+                    if (tx < AT_W1 - 64) sY[ch][ly * AT_W1 + 64 + tx] = d5y_in<DT_W>(sM, c + 64 + tx);
+                } else {
+                    sY[ch][ly * AT_W1 + tx] = d5y(m4, clampi(x0 + 2 + tx, 0, g.w - 1), gy, g.h);
+                    if (tx < AT_W1 - 64) sY[ch][ly * AT_W1 + 64 + tx] = d5y(m4, clampi(x0 + 66 + tx, 0, g.w - 1), gy, g.h);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int y = y0 + DT_H + ty + NR * k;
+            if (y >= g.h) break;
+            const bool y_in = y >= 2 && y + 2 < g.h;
+            const int c = (ty + NR * k + 2) * AT_W1 + (tx + 2);
+            Px p;
+            if (y_in) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    p.ixy[ch] = d5y_in<AT_W1>(sX[ch], c);                              // :130
+                    p.iyy[ch] = d5y_in<AT_W1>(sY[ch], c);                              // :131
+                    p.iyz[ch] = d5y_in<AT_W1>(sZ[ch], c);                              // :133
+                }
+            } else {
+                const int xc = x < g.w ? x : g.w - 1;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const Tile2Acc X{sX[ch], x0 + 2, y0 + 2}, Y{sY[ch], x0 + 2, y0 + 2}, Z{sZ[ch], x0 + 2, y0 + 2};
+                    p.ixy[ch] = d5y(X, xc, y, g.h);
+                    p.iyy[ch] = d5y(Y, xc, y, g.h);
+                    p.iyz[ch] = d5y(Z, xc, y, g.h);
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                p.wk[ch] = wk[k][ch];
+                p.ix[ch] = sX[ch][c]; p.iy[ch] = sY[ch][c]; p.iz[ch] = sZ[ch][c];
+                p.ixx[ch] = d5x_in<AT_W1>(sX[ch], c);                                  // :129
+                p.ixz[ch] = d5x_in<AT_W1>(sZ[ch], c);                                  // :132
+            }
+            if (!ok[k]) continue;
+            float m = base[eb + T.mask_off + (size_t)y * g.pitch + x];
+            if (!a.one_direction || !T.backward) m = T.backward ? 1.0f * bwd[k] * m : 1.0f * fwd[k] * m;   // :314,316
+            if (T.is_ref) term_ref(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
+            else          term_succ(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        if (!ok[k]) continue;
+        const int y = y0 + DT_H + ty + NR * k;
+        const size_t o = (size_t)y * g.pitch + x;
+        if (a.do_laplacian) {                                                            // variational_mt.cpp:364-365
+            PlaneAcc U{uu + eb, g.pitch}, V{vv + eb, g.pitch}, H{sh + eb, g.pitch}, W{sv + eb, g.pitch};
+            A[k].b1 = laplacian_gather(A[k].b1, U, H, W, x, y, g.w, g.h);
+            A[k].b2 = laplacian_gather(A[k].b2, V, H, W, x, y, g.w, g.h);
+        }
+        a11[eb + o] = A[k].a11; a12[eb + o] = A[k].a12; a22[eb + o] = A[k].a22; b1[eb + o] = A[k].b1; b2[eb + o] = A[k].b2;
+    }
+}
+void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
+                            const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
+    static const int shape = getenv("SFA_ASSEMBLE_SHAPE") ? atoi(getenv("SFA_ASSEMBLE_SHAPE")) : 0;
+#define SFA_LAUNCH_AI(TY, NT, MINB)                                                                                                                       \
+    hipLaunchKernelGGL((k_assemble_images<TY, NT, MINB>), dim3((g.w + DT_X - 1) / DT_X, (g.h + TY - 1) / TY, g.nb), dim3(NT), 0, c->stream, a, base, a11, a12, a22, \
+                       b1, b2, du, dv, uu, vv, sh, sv, occ, g)
+    switch (shape) {
+    case 1: SFA_LAUNCH_AI(8, 256, 2); break;
+    case 2: SFA_LAUNCH_AI(8, 256, 4); break;
+    case 3: SFA_LAUNCH_AI(16, 1024, 4); break;
+    case 5: SFA_LAUNCH_AI(8, 512, 4); break;
+    default: SFA_LAUNCH_AI(16, 512, 4); break;
+    }
+#undef SFA_LAUNCH_AI
 }
 
 // ---------------------------------------------------------------------------------------------------

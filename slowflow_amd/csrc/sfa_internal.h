@@ -104,7 +104,12 @@ void launch_fill(sfa_ctx *c, float *p, size_t n, float v);
 void launch_fill_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes, float v);
 void launch_zero_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes);
 
-struct Term { long stack_off; long mask_off; float hd, hg, s; int is_ref; };
+struct Term {
+    long stack_off; long mask_off; float hd, hg, s; int is_ref;
+    // fused form (launch_assemble_images): the image pair the derivative stack is taken of, arena offsets like mask_off;
+    // backward: the mask is weighted with the backward (slot < ref) or forward occlusion factor
+    long i1_off, i2_off; int backward;
+};
 struct AssembleArgs {
     Term t[kMaxTerms];
     int n;
@@ -114,9 +119,16 @@ struct AssembleArgs {
     const float *chw; long chw_pl; long chw_es; int chw_pitch; int chw_stride0; int lstride;
     int accumulate;      // 1: add to existing a11.. (stage API), 0: start from zero
     int do_laplacian;    // apply sub_laplacian(b1,uu), (b2,vv) at the end
+    // fused form only: occlusion / direction weighting of the masks (variational_mt.cpp:293-320) applied on the fly
+    float data_norm; int one_direction;
 };
 void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base /*element arena of batch 0*/, float *a11, float *a12,
                      float *a22, float *b1, float *b2, const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv);
+
+// The same system from the warped image pairs directly: derivative stacks formed in LDS tiles, never stored
+// (get_derivatives' 8 filters + :293-320 mask weights + :336-365 in one pass).  occ: occlusion plane.
+void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
+                            const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ);
 
 // du/dv -> uu,vv, zero padding, L1 change norms (variational_mt.cpp:371-402); red = per-element 2 doubles (sum|old_du-du|, sum|old_dv-dv|)
 void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const float *du, const float *dv,

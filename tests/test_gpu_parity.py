@@ -395,6 +395,29 @@ def test_level_variants(ctx, oracle, kw):
     assert d <= tol, (kw, d, tol)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(), dict(one_direction=1), dict(dataterm_norm=0), dict(delta=0.0), dict(occlusion_reasoning=1, niter_alter=1), dict(niter_inner=3),
+    dict(robust_color=(3, 0.001, 0.5), robust_grad=(4, 0.05, 0.5)),
+])
+@pytest.mark.parametrize("w,h", [(67, 45), (200, 37), (64, 16), (129, 70)])
+def test_fused_assembly_is_the_unfused_pipeline(ctx, oracle, monkeypatch, kw, w, h):
+    """the image->system kernel (derivative filters in LDS, mask weights on the fly) against the materialised form
+    (warp copies, 24-plane stacks, mask-weight pass, per-pixel assembly): the same bits, every term kind, with
+    channel weights, across tile borders (sizes off the 64x8 tile grid)"""
+    frames, af, sf = normalized_frames(oracle, w, h, 5, seed=3)
+    rng = np.random.default_rng(1)
+    chw = [noise_plane(rng, w, h, 0.5, 1.5) for _ in range(3)]
+    _, ps = mk_params(oracle, S=3, rho=[1, 0.5], omega=[0.5, 2], norm_avg=af, norm_std=sf, niter_outer=2, **kw)
+    out = []
+    for unfused in ("1", "0"):
+        monkeypatch.setenv("SFA_UNFUSED", unfused)
+        wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
+        ch, _ = ctx.compute_one_level(ps, wx, wy, [c_(f) for f in frames], w, [c_(x) for x in chw])
+        out.append((wx, wy, ch))
+    assert np.array_equal(valid(out[0][0], w), valid(out[1][0], w)) and np.array_equal(valid(out[0][1], w), valid(out[1][1], w))
+    assert tuple(out[0][2]) == tuple(out[1][2])
+
+
 def test_level_channel_weights_and_initial_flow(ctx, oracle):
     w, h = 67, 45
     frames, af, sf = normalized_frames(oracle, w, h, 3, seed=9)
