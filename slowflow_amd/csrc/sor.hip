@@ -318,7 +318,7 @@ __device__ __forceinline__ bool wait_lds_ge(unsigned *p, unsigned target, unsign
 // Two granularities: operands are refilled and the LDS hand-over to the next stage happens every CH steps; the
 // (slower) HBM hand-over to the band below -- progress words, lane-0 values -- every MC steps.
 template <int F, int CH, int MC, int RING, int ROLE>
-__device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long (*ring)[RING][64], unsigned *lprog, int job, int b, int wave, int lane) {
+__device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long (*ring)[RING][64], unsigned *lprog, unsigned char *win, int job, int b, int wave, int lane) {
     constexpr bool FIRST = ROLE == 0 || ROLE == 3, LASTW = ROLE == 2 || ROLE == 3;
     constexpr int NQ = MC / CH;
     const int k0 = wave * F;
@@ -327,16 +327,32 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     const int r0 = 64 * b - k0;
     const long FOFF = 2L * RP + 1;
     const long U0 = (long)(r0 + a.G) * RP + (r0 + a.G);
-    // wave-uniform byte bases (SGPR pairs); the per-step advance lives in ONE 32-bit lane offset per element size
-    const char *ba[F], *bb[F];
+    // wave-uniform byte bases (SGPR pairs); the per-step advance lives in ONE 32-bit lane offset per element size.
+    // Only sweep f = 0 reads its operands from HBM.  Sweep f at step s works on what f = 0 worked on at step s - 2f, one
+    // row up per sweep (FOFF): the wave keeps its last 2(F-1) operand rows in LDS and sweeps f >= 1 read them back at
+    // lane offset -f.  Rows r0-(F-1) .. r0-1 (positions 0 .. F-2 of a window row) come through a third, 8-lane load.
+    (void)FOFF;
+    constexpr int NSLOT = F > 1 ? 2 * (F - 1) : 1, WP = 64 + F - 1;      // window rows (steps) / positions per row
+    const char *ba0 = reinterpret_cast<const char *>(a.sa + (size_t)job * a.ent + U0);
+    const char *bb0 = reinterpret_cast<const char *>(a.sb + (size_t)job * a.ent + U0);
+    float4 *winA = reinterpret_cast<float4 *>(win), *winB = winA + NSLOT * WP;   // [NSLOT][WP] each
+    // extras: lanes [0, 2(F-1)) fetch 8 B each of SA's entries U0-(F-1) .. U0-1, lanes [2(F-1), 4(F-1)) the same of SB
+    const bool ex_lane = F > 1 && lane < 4 * (F - 1);
+    const bool ex_b = lane >= 2 * (F - 1);
+    const char *bex = (ex_b ? bb0 : ba0) - (F - 1) * 16 + (lane - (ex_b ? 2 * (F - 1) : 0)) * 8 - lane * 16;   // + vo16
+    float2 *wex = reinterpret_cast<float2 *>(ex_b ? winB : winA) + (lane - (ex_b ? 2 * (F - 1) : 0));         // + slot * WP * 2
     bool row_ok_last = false;
     float2 res[F], selfv[F];
     float hl[F];
 #pragma unroll
-    for (int f = 0; f < F; f++) {
-        ba[f] = reinterpret_cast<const char *>(a.sa + (size_t)job * a.ent + U0 - f * FOFF);
-        bb[f] = reinterpret_cast<const char *>(a.sb + (size_t)job * a.ent + U0 - f * FOFF);
-        res[f] = make_float2(0.f, 0.f); selfv[f] = make_float2(0.f, 0.f); hl[f] = 0.f;
+    for (int f = 0; f < F; f++) { res[f] = make_float2(0.f, 0.f); selfv[f] = make_float2(0.f, 0.f); hl[f] = 0.f; }
+    if (F > 1) {
+        // window rows of the steps before the start: columns < 0 (zero guards in HBM) except at the extra positions, whose
+        // rows sit further up the diagonal (lane < 0: column s - lane can be >= 0 for s < 0)
+        for (int i = lane; i < 2 * NSLOT * WP; i += 64) winA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ex_lane)
+            for (int t = 1; t <= NSLOT; t++)
+                wex[((NSLOT - t) & (NSLOT - 1)) * WP * 2] = *reinterpret_cast<const float2 *>(bex + ((long)lane * 16 - (long)t * RP * 16));
     }
     { const int r = r0 + lane - (F - 1); row_ok_last = r >= 0 && r < H; }
     char *bx = reinterpret_cast<char *>(a.x + (size_t)job * a.ent + U0);
@@ -347,14 +363,21 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     unsigned *gmine = a.gflags + ((size_t)job * a.NB + b) * a.NW + wave;
     const unsigned *g_up = a.gflags + ((size_t)job * a.NB + (b - 1)) * a.NW + wave;      // (b-1, w)
     const unsigned *g_up2 = g_up - 1;                                                    // (b-1, w-1)
+#if defined(SFA_EXPERIMENT_NODEP)
+    const bool has_up = false, publishes = false;                 // timing experiment: bands as independent problems (wrong results)
+#elif defined(SFA_EXPERIMENT_NOPUB)
+    const bool has_up = false, publishes = b + 1 < a.NB;          // timing experiment: edge stores but nobody waits
+#else
     const bool has_up = b > 0, publishes = b + 1 < a.NB;
+#endif
     // lane t = fi*MC + j fetches lane 0's "lane -1" value of step j of the macro chunk: fi = 0: right of f = 0 (sweep
     // k0-1, column s+1); fi = f+1: top of f (sweep k0+f, column s-f)
     const int tfi = lane / MC, tj = lane % MC;
     const bool tv_lane = has_up && lane < (F + 1) * MC && (tfi > 0 || !FIRST);
     const long tv_off = tfi == 0 ? (long)(-1) * a.Wp + tj + 1 : (long)(tfi - 1) * a.Wp + tj - (tfi - 1);
 
-    float4 sa[F][CH], sb[F][CH];
+    float4 sa0[CH], sb0[CH];
+    float2 ex[CH];
     unsigned long long xb[CH], xr[CH], tv = 0;
     unsigned known_up = 0, known_up2 = 0, pend_up = 0, pend_up2 = 0;
     auto need_up = [&](int m) { return (unsigned)min(m + 1 + (64 + MC - 1) / MC, NMC); };
@@ -375,12 +398,12 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
         if (!FIRST) { known_up2 = wait_ge(g_up2, need_up2(2), a.err); if (known_up2 == 0xffffffffu) return; }
     }
 #pragma unroll
-    for (int j = 0; j < CH; j++)
-#pragma unroll
-        for (int f = 0; f < F; f++) {
-            sa[f][j] = *reinterpret_cast<const float4 *>(ba[f] + (vo16 + j * st16));
-            sb[f][j] = *reinterpret_cast<const float4 *>(bb[f] + (vo16 + j * st16));
-        }
+    for (int j = 0; j < CH; j++) {
+        sa0[j] = *reinterpret_cast<const float4 *>(ba0 + (vo16 + j * st16));
+        sb0[j] = *reinterpret_cast<const float4 *>(bb0 + (vo16 + j * st16));
+        ex[j] = make_float2(0.f, 0.f);
+        if (ex_lane) ex[j] = *reinterpret_cast<const float2 *>(bex + (vo16 + j * st16));
+    }
     if (FIRST) {
         selfv[0] = u2f(*reinterpret_cast<const unsigned long long *>(bx + vo8));
 #pragma unroll
@@ -440,12 +463,30 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                     sh[f].x = lane_shr1(res[f].x, fx);
                     sh[f].y = lane_shr1(res[f].y, fy);
                 }
+                // operands of the trailing sweeps: the window row written 2f steps ago, f positions down
+                float4 oa[F], ob[F];
+                oa[0] = sa0[j]; ob[0] = sb0[j];
+#pragma unroll
+                for (int f = 1; f < F; f++) {
+                    const int slot = (jj - 2 * f + 4 * NSLOT) & (NSLOT - 1);
+                    oa[f] = winA[slot * WP + lane + (F - 1 - f)];
+                    ob[f] = winB[slot * WP + lane + (F - 1 - f)];
+#ifdef SFA_DEBUG_WINDOW
+                    {
+                        const float4 ra = *reinterpret_cast<const float4 *>(ba0 - (long)f * FOFF * 16 + vo16);
+                        const float4 rb = *reinterpret_cast<const float4 *>(bb0 - (long)f * FOFF * 16 + vo16);
+                        const bool bad = __float_as_uint(ra.x) != __float_as_uint(oa[f].x) || __float_as_uint(ra.w) != __float_as_uint(oa[f].w) ||
+                                         __float_as_uint(rb.x) != __float_as_uint(ob[f].x) || __float_as_uint(rb.w) != __float_as_uint(ob[f].w);
+                        if (bad) atomicCAS(a.err, 0u, 0x10000000u | (b << 24) | (wave << 20) | (f << 16) | (lane << 8) | (s & 255));
+                    }
+#endif
+                }
                 float2 nres[F];
 #pragma unroll
                 for (int f = 0; f < F; f++) {
                     const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
                     const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
-                    const v2f xn = sor_point(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hl[f], sa[f][j], sb[f][j], omega);
+                    const v2f xn = sor_point(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hl[f], oa[f], ob[f], omega);
                     nres[f] = make_float2(xn.x, xn.y);
                     // lane 63's iterate of every sweep is band b+1's lane-0 input (zeros outside the image land in the row pads)
                     if (publishes && lane == 63) st_x(e_mine + (long)f * a.Wp + (s - 63 - f), f2u(xn.x, xn.y));
@@ -454,18 +495,22 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                         else if (row_ok_last && (unsigned)(s - lane - f) < (unsigned)W)
                             *reinterpret_cast<unsigned long long *>(bx - (long)f * FOFF * 8 + vo8) = f2u(xn.x, xn.y);   // final iterate
                     }
-                    hl[f] = sb[f][j].z;
+                    hl[f] = ob[f].z;
                     selfv[f] = right;
                 }
 #pragma unroll
                 for (int f = 0; f < F; f++) res[f] = nres[f];
+                if (F > 1) {                                      // this step's operands become window row s
+                    const int slot = jj & (NSLOT - 1);
+                    winA[slot * WP + lane + (F - 1)] = sa0[j];
+                    winB[slot * WP + lane + (F - 1)] = sb0[j];
+                    if (ex_lane) wex[slot * WP * 2] = ex[j];
+                }
                 // refill slot j for step s + CH (beyond the last step this reads zero guards)
 #ifndef SFA_EXPERIMENT_NOLOAD
-#pragma unroll
-                for (int f = 0; f < F; f++) {
-                    sa[f][j] = *reinterpret_cast<const float4 *>(ba[f] + (vo16 + CH * st16));
-                    sb[f][j] = *reinterpret_cast<const float4 *>(bb[f] + (vo16 + CH * st16));
-                }
+                sa0[j] = *reinterpret_cast<const float4 *>(ba0 + (vo16 + CH * st16));
+                sb0[j] = *reinterpret_cast<const float4 *>(bb0 + (vo16 + CH * st16));
+                if (ex_lane) ex[j] = *reinterpret_cast<const float2 *>(bex + (vo16 + CH * st16));
 #endif
                 if (FIRST) {
                     xr[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8));
@@ -509,6 +554,8 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     const int NW = a.NW;                                          // K / F pipeline stages (waves)
     unsigned long long(*ring)[RING][64] = reinterpret_cast<unsigned long long(*)[RING][64]>(smem);   // [NW-1][RING][64]
     unsigned *lprog = reinterpret_cast<unsigned *>(smem + (size_t)(NW - 1) * RING * 64 * 8);          // steps completed by each wave
+    constexpr int WINB = F > 1 ? 2 * (F - 1) * (64 + F - 1) * 32 : 0;                                // operand window per wave (bytes)
+    unsigned char *win0 = smem + (size_t)(NW - 1) * RING * 64 * 8 + 256;                             // 16-byte aligned behind the progress words
     unsigned &s_ticket = lprog[NW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -518,10 +565,10 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;                     // band-major tickets
-    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, job, b, wave, lane);
-    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, job, b, wave, lane);
-    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, job, b, wave, lane);
-    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, job, b, wave, lane);
+    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, job, b, wave, lane);
+    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, job, b, wave, lane);
+    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, job, b, wave, lane);
+    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, win0 + (size_t)wave * WINB, job, b, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -640,7 +687,8 @@ static int band_shape(int K, int nb) {
     return 0;
 }
 constexpr int kBandCH = 2, kBandMC = 8;        // operand ring / LDS hand-over every 2 steps, HBM hand-over every 8
-static int band_ring(int F) { return F == 3 ? 32 : 16; }     // LDS ring slots per wave pair, power of two (144 KB / 112 KB / 120 KB at most)
+static int band_ring(int F) { return F == 2 ? 8 : 16; }      // LDS ring slots per wave pair, power of two
+static size_t band_window(int F) { return F > 1 ? (size_t)2 * (F - 1) * (64 + F - 1) * 32 : 0; }   // operand window bytes per wave
 
 // fused iterations per wave / steps per hand-over chunk (env SFA_SOR_F, SFA_SOR_CH override the default)
 static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
@@ -729,9 +777,9 @@ int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, fl
         if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(kBandCH + 2, std::min(atoi(e), band_ring(ws.F)));
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
-        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + (ws.NG + 1) * sizeof(unsigned) + 16;
-        if (ws.F == 3)      hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, kBandMC, 32>), bgrid, bblock, lds, c->stream, ba);
-        else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
+        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F);
+        if (ws.F == 3)      hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
+        else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, kBandCH, kBandMC, 8>), bgrid, bblock, lds, c->stream, ba);
         else                hipLaunchKernelGGL((k_sor_band<1, 16, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
     } else {
     const dim3 sgrid(g.nb * ws.ntasks), sblock(64);
