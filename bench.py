@@ -90,13 +90,58 @@ def cpu_baseline(budget_s=12.0):
             "sample": f"{n} sor_coupled calls, {SWEEPS} sweeps each, {W}x{H}, one thread ({t_total:.1f} s)"}
 
 
+def measured_traffic(batch):
+    """HBM-side bytes per SOR launch from the PMC passes of profiles/collect_traffic.sh (FETCH_SIZE x2 on gfx950 for wide
+    reads + WRITE_SIZE, separate passes; MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process,
+    so the committed measurement of the same command is reported, and only when it was taken at this batch size."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if int(t["batch"]) == int(batch):
+            return t["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, python bench.py --path-only)"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
+def sor_only(ctx, B, rank):
+    from synth import sor_system
+    sb = sfa.SorBatch(ctx, W, H, B)
+    rng = np.random.default_rng(7 + rank)
+    for b in range(B):
+        s = sor_system(rng, W, H)
+        sb.upload(b, *[np.ascontiguousarray(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb.run(SWEEPS, 1.9); ctx.sync()
+    ctx.profile_enable(True)
+    reps = 20
+    for _ in range(reps):
+        sb.run(SWEEPS, 1.9)
+    n1, ms1, by1 = ctx.profile_read()
+    ctx.profile_enable(False)
+    # single-solve latency (batch of one)
+    sb1 = sfa.SorBatch(ctx, W, H, 1)
+    s = sor_system(rng, W, H)
+    sb1.upload(0, *[np.ascontiguousarray(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb1.run(SWEEPS, 1.9); ctx.sync()
+    ctx.profile_enable(True)
+    for _ in range(reps):
+        sb1.run(SWEEPS, 1.9)
+    n2, ms2, by2 = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    sb.close(); sb1.close()
+    return n1, ms1, by1, n2, ms2, by2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="frame windows per GPU solved in lockstep (fwd/bwd of several jets)")
+    ap.add_argument("--batch", type=int, default=64, help="frame windows per GPU solved in lockstep (fwd/bwd of several jets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path-only", action="store_true", help="skip the SOR-only section (used for the PMC passes: every SOR dispatch then belongs to the path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,34 +197,14 @@ def main():
     window_seconds = shard.gather_timings(dist, {i: elapsed / args.steps / B for i in range(lo, hi)}, B * world, device="cuda")
 
     # SOR-only: the metric's own kernel at 1024x436, same batch, HIP events on the launch stream
-    from synth import sor_system
-    sb = sfa.SorBatch(ctx, W, H, B)
-    rng = np.random.default_rng(7 + rank)
-    for b in range(B):
-        s = sor_system(rng, W, H)
-        sb.upload(b, *[np.ascontiguousarray(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
-    sb.run(SWEEPS, 1.9); ctx.sync()
-    ctx.profile_enable(True)
-    reps = 20
-    for _ in range(reps):
-        sb.run(SWEEPS, 1.9)
-    n1, ms1, by1 = ctx.profile_read()
-    ctx.profile_enable(False)
-    # single-solve latency (batch of one)
-    sb1 = sfa.SorBatch(ctx, W, H, 1)
-    s = sor_system(rng, W, H)
-    sb1.upload(0, *[np.ascontiguousarray(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
-    sb1.run(SWEEPS, 1.9); ctx.sync()
-    ctx.profile_enable(True)
-    for _ in range(reps):
-        sb1.run(SWEEPS, 1.9)
-    n2, ms2, by2 = ctx.profile_read()
-    ctx.profile_enable(False)
-
+    n1 = ms1 = by1 = n2 = ms2 = by2 = 0
+    if not args.path_only:
+        n1, ms1, by1, n2, ms2, by2 = sor_only(ctx, B, rank)
     if rank == 0:
         total = mpix_iters * args.steps * world
         value = total / elapsed_max
         achieved = sor_bytes / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(B)
         out = {
             "metric": "Mpix*solver-iters/s at 1024x436 (whole coarse-to-fine path)", "value": round(value, 1), "unit": "Mpix*solver-iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
@@ -188,24 +213,27 @@ def main():
                                    "symmetric window, modified-L1 penalties, thresholds off",
                        "frame_windows_per_gpu": B, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
                        "parallelism": f"frame-window data parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_sor_band<3,10,2,8,32> (batched lockstep solves; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_sor_band<3,10,2,8,16> (batched lockstep solves; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
                          "algorithmic_bytes_per_launch": round(sor_bytes / max(n_sor, 1)),
+                         "traffic_source": traffic_src,
                          "note": "over the timed region: sum of (44*K+12)*w*h*batch ALGORITHMIC bytes of every SOR launch (all 5 levels) / sum of HIP-event durations; the kernel fuses all K sweeps of a 64-row band in one workgroup (x stays in registers/LDS), so its real HBM traffic is far below the algorithmic bytes and frac can exceed 1",
-                         "sor_1024x436_batch": {"batch": B, "avg_launch_ms": round(ms1 / max(n1, 1), 4), "achieved": round(by1 / (ms1 * 1e-3) / 1e9, 1),
-                                                "frac": round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                "mpix_iters_per_s": round(W * H * SWEEPS * B * n1 / 1e6 / (ms1 * 1e-3), 1)},
-                         "sor_1024x436_single": {"batch": 1, "avg_launch_ms": round(ms2 / max(n2, 1), 4), "achieved": round(by2 / (ms2 * 1e-3) / 1e9, 1),
-                                                 "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                 "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}},
+                         },
             "sor_share_of_step": round(sor_ms / (elapsed * 1e3), 4),
             "seconds_per_window": {"mean": round(float(window_seconds.mean()), 6), "max": round(float(window_seconds.max()), 6), "n": int(window_seconds.size)},
         }
+        if n1:
+            out["roofline"]["sor_1024x436_batch"] = {"batch": B, "avg_launch_ms": round(ms1 / n1, 4), "achieved": round(by1 / (ms1 * 1e-3) / 1e9, 1),
+                                                     "frac": round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                     "mpix_iters_per_s": round(W * H * SWEEPS * B * n1 / 1e6 / (ms1 * 1e-3), 1)}
+            out["roofline"]["sor_1024x436_single"] = {"batch": 1, "avg_launch_ms": round(ms2 / n2, 4), "achieved": round(by2 / (ms2 * 1e-3) / 1e9, 1),
+                                                      "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                      "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    sb.close(); sb1.close(); job.close(); ctx.close()
+    job.close(); ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

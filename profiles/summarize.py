@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of profiles/collect.sh (under gpurun_out/) into the files kept in profiles/:
+   <tag>_kernel_stats.csv   per-kernel totals of the bench command (rocprofv3 --kernel-trace --stats)
+   <tag>_sor_by_level.csv   SOR kernel: dispatches / average duration per pyramid level
+   <tag>_traffic.json       HBM-side bytes per SOR launch: 2 x FETCH_SIZE (gfx950 tallies 128-B reads at 64 B) + WRITE_SIZE
+usage: python profiles/summarize.py r01 [batch]"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go = os.path.join(root, "gpurun_out")
+out = os.path.join(root, "profiles")
+
+
+def find(d, suffix):
+    for base, _, files in os.walk(os.path.join(go, d)):
+        for f in files:
+            if f.endswith(suffix):
+                return os.path.join(base, f)
+    raise FileNotFoundError((d, suffix))
+
+
+shutil.copy(find(f"{tag}_stats", "kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(go, f"{tag}_stats.json"), os.path.join(out, f"{tag}_bench_under_rocprof.json"))
+
+# SOR kernel per level from the trace
+rows = list(csv.DictReader(open(find(f"{tag}_stats", "kernel_trace.csv"))))
+acc = collections.defaultdict(list)
+for r in rows:
+    if "k_sor_band" in r["Kernel_Name"] or "k_sor_solve" in r["Kernel_Name"]:
+        acc[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+with open(os.path.join(out, f"{tag}_sor_by_level.csv"), "w") as f:
+    f.write("kernel,grid_threads,dispatches,avg_us,min_us,max_us\n")
+    for (k, g), v in sorted(acc.items(), key=lambda kv: -kv[0][1]):
+        f.write(f"\"{k}\",{g},{len(v)},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f}\n")
+
+
+def pmc(d, counter):
+    rows = list(csv.DictReader(open(find(d, "counter_collection.csv"))))
+    per = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] == counter:
+            per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return per
+
+
+fetch, write = pmc(f"{tag}_fetch", "FETCH_SIZE"), pmc(f"{tag}_write", "WRITE_SIZE")
+res = {"batch": batch, "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B by rocprofv3; x2 on FETCH_SIZE per MI355X_MICROARCH.md (gfx950)",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith("void sfa::") and not k.startswith("sfa::"):
+        continue
+    fz = fetch.get(k, [])
+    wz = write.get(k, [])
+    fb = 2 * 1024 * sum(fz) / max(len(fz), 1)
+    wb = 1024 * sum(wz) / max(len(wz), 1)
+    res["kernels"][k] = {"dispatches": len(fz), "fetch_bytes_per_launch_x2": round(fb), "write_bytes_per_launch": round(wb), "traffic_bytes_per_launch": round(fb + wb)}
+sor = [k for k in res["kernels"] if "k_sor_band" in k]
+if sor:
+    res["traffic_bytes_per_launch"] = res["kernels"][sor[0]]["traffic_bytes_per_launch"]
+    res["kernel"] = sor[0]
+json.dump(res, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
+for k, v in res["kernels"].items():
+    print(f"{k[:60]:60s} n={v['dispatches']:5d} fetch(x2) {v['fetch_bytes_per_launch_x2'] / 1e6:10.1f} MB  write {v['write_bytes_per_launch'] / 1e6:10.1f} MB")

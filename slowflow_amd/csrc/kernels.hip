@@ -663,8 +663,8 @@ void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const floa
 // ---------------------------------------------------------------------------------------------------
 // K6 fused: the derivative stack of every term is formed in LDS from its image pair (stage 1/2 of k_deriv_stack)
 // and consumed on the spot by the term arithmetic above -- the 24-plane stacks never exist in HBM.  One block = a
-// 64x16 pixel tile of one element; per term and channel M (halo 4) is staged, Ix/Iy/Iz (halo 2) kept for the three
-// channels, then each thread runs the term for its 4 pixels.  Mask weights (variational_mt.cpp:293-320) are applied
+// 64 x TY pixel tile of one element; per term M (halo 4) of the three channels is staged, then Ix/Iy/Iz (halo 2), then
+// each thread runs the term for its pixel(s): three barriers per term.  Mask weights (variational_mt.cpp:293-320) are applied
 // on the fly from the occlusion plane.  Same operations in the same order as the unfused kernels: bit-identical.
 // ---------------------------------------------------------------------------------------------------
 constexpr int AT_W1 = DT_X + 4;                                      // halo-2 planes
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                                                               const float *__restrict__ vv, const float *__restrict__ sh, const float *__restrict__ sv,
                                                               const float *__restrict__ occ, Geo g) {
     constexpr int TR = TY + 2 * DT_H, AT_R1 = TY + 4, NR = NT / 64, NP = TY / NR;
-    __shared__ float sM[TR * DT_W];
+    __shared__ float sM[3][TR * DT_W];
     __shared__ float sX[3][AT_R1 * AT_W1], sY[3][AT_R1 * AT_W1], sZ[3][AT_R1 * AT_W1];
     const int b = blockIdx.z;
     if (!elem_active(g.active, b)) return;
@@ -723,46 +723,57 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         bwd[k] = __fdiv_rn((oc >= 0.0f) ? 1.0f : 0.0f, factor);
         fwd[k] = __fdiv_rn((oc <= 0.0f) ? 1.0f : 0.0f, factor);
     }
-    const TileAcc m4{sM, x0, y0};
     // this thread's staging columns: tile column tx (and 64 + tx for the first lanes), source column clamped into the image
     const int gxa = clampi(x0 + tx, 0, g.w - 1), gxb = clampi(x0 + 64 + tx, 0, g.w - 1);
     // stage-1 columns of the halo-2 region; sM index shift that realises X(clamp(x), y) for columns outside the image
     const int sxa = clampi(x0 + 2 + tx, 0, g.w - 1) - (x0 + 2 + tx), sxb = clampi(x0 + 66 + tx, 0, g.w - 1) - (x0 + 66 + tx);
     for (int t = 0; t < a.n; t++) {
         const Term &T = a.t[t];
-        for (int ch = 0; ch < 3; ch++) {
-            const float *pa = base + eb + T.i1_off + ch * g.pl, *pb = base + eb + T.i2_off + ch * g.pl;
-            __syncthreads();                                       // sM / this channel's planes are free again
-            // stage 0: M (halo 4), Iz (halo 2); rows outside the image are never read
-            for (int ly = ty; ly < TR; ly += NR) {
-                const int gy = y0 + ly;
-                if (gy < 0 || gy >= g.h) continue;
-                const size_t orow = (size_t)gy * g.pitch;
-                const bool zrow = ly >= 2 && ly < TR - 2;
-                {
-                    const float va = pa[orow + gxa], vb = pb[orow + gxa];
-                    sM[ly * DT_W + tx] = 0.5f * (vb + va);                             // variational_mt.cpp:120
-                    if (zrow && tx >= 2) sZ[ch][(ly - 2) * AT_W1 + (tx - 2)] = va - vb;                 // :122
-                }
-                if (tx < DT_W - 64) {
-                    const float va = pa[orow + gxb], vb = pb[orow + gxb];
-                    sM[ly * DT_W + 64 + tx] = 0.5f * (vb + va);
-                    if (zrow && tx < DT_W - 66) sZ[ch][(ly - 2) * AT_W1 + (62 + tx)] = va - vb;
+        const float *pa = base + eb + T.i1_off, *pb = base + eb + T.i2_off;
+        __syncthreads();                                           // the staged planes are free again
+        // stage 0: M (halo 4), Iz (halo 2) of the three channels; rows outside the image are never read
+        for (int ly = ty; ly < TR; ly += NR) {
+            const int gy = y0 + ly;
+            if (gy < 0 || gy >= g.h) continue;
+            const size_t orow = (size_t)gy * g.pitch;
+            const bool zrow = ly >= 2 && ly < TR - 2;
+            float va[3], vb[3], wa[3], wb[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) { va[ch] = pa[ch * g.pl + orow + gxa]; vb[ch] = pb[ch * g.pl + orow + gxa]; }
+            if (tx < DT_W - 64) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) { wa[ch] = pa[ch * g.pl + orow + gxb]; wb[ch] = pb[ch * g.pl + orow + gxb]; }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                sM[ch][ly * DT_W + tx] = 0.5f * (vb[ch] + va[ch]);                     // variational_mt.cpp:120
+                if (zrow && tx >= 2) sZ[ch][(ly - 2) * AT_W1 + (tx - 2)] = va[ch] - vb[ch];             // :122
+            }
+            if (tx < DT_W - 64) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    sM[ch][ly * DT_W + 64 + tx] = 0.5f * (wb[ch] + wa[ch]);
+                    if (zrow && tx < DT_W - 66) sZ[ch][(ly - 2) * AT_W1 + (62 + tx)] = wa[ch] - wb[ch];
                 }
             }
-            __syncthreads();
-            // stage 1: Ix, Iy on the halo-2 region
-            for (int ly = ty; ly < AT_R1; ly += NR) {
-                const int gy = y0 + 2 + ly;
-                if (gy < 0 || gy >= g.h) continue;
-                const bool y_in = gy >= 2 && gy + 2 < g.h;
-                const int c = (ly + 2) * DT_W + 2;
-                sX[ch][ly * AT_W1 + tx] = d5x_in<DT_W>(sM, c + tx + sxa);                                // :127
-                if (tx < AT_W1 - 64) sX[ch][ly * AT_W1 + 64 + tx] = d5x_in<DT_W>(sM, c + 64 + tx + sxb);
+        }
+        __syncthreads();
+        // stage 1: Ix, Iy on the halo-2 region
+        for (int ly = ty; ly < AT_R1; ly += NR) {
+            const int gy = y0 + 2 + ly;
+            if (gy < 0 || gy >= g.h) continue;
+            const bool y_in = gy >= 2 && gy + 2 < g.h;
+            const int c = (ly + 2) * DT_W + 2;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float *M = sM[ch];
+                sX[ch][ly * AT_W1 + tx] = d5x_in<DT_W>(M, c + tx + sxa);                                  // :127
+                if (tx < AT_W1 - 64) sX[ch][ly * AT_W1 + 64 + tx] = d5x_in<DT_W>(M, c + 64 + tx + sxb);
                 if (y_in) {                                                                               // :128
-                    sY[ch][ly * AT_W1 + tx] = d5y_in<DT_W>(sM, c + tx);
-                    if (tx < AT_W1 - 64) sY[ch][ly * AT_W1 + 64 + tx] = d5y_in<DT_W>(sM, c + 64 + tx);
+                    sY[ch][ly * AT_W1 + tx] = d5y_in<DT_W>(M, c + tx);
+                    if (tx < AT_W1 - 64) sY[ch][ly * AT_W1 + 64 + tx] = d5y_in<DT_W>(M, c + 64 + tx);
                 } else {
+                    const TileAcc m4{M, x0, y0};
                     sY[ch][ly * AT_W1 + tx] = d5y(m4, clampi(x0 + 2 + tx, 0, g.w - 1), gy, g.h);
                     if (tx < AT_W1 - 64) sY[ch][ly * AT_W1 + 64 + tx] = d5y(m4, clampi(x0 + 66 + tx, 0, g.w - 1), gy, g.h);
                 }
@@ -830,8 +841,8 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, con
     case 1: SFA_LAUNCH_AI(8, 256, 2); break;
     case 2: SFA_LAUNCH_AI(8, 256, 4); break;
     case 3: SFA_LAUNCH_AI(16, 1024, 4); break;
-    case 5: SFA_LAUNCH_AI(8, 512, 4); break;
-    default: SFA_LAUNCH_AI(16, 512, 4); break;
+    case 4: SFA_LAUNCH_AI(16, 512, 4); break;
+    default: SFA_LAUNCH_AI(8, 512, 4); break;
     }
 #undef SFA_LAUNCH_AI
 }
