@@ -206,13 +206,20 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                    // :329-330
                 launch_smoothness(c, gi, p.smoothing, L.plane(P_SH), L.plane(P_SV), L.plane(P_UU), L.plane(P_VV), L.plane(P_DPSIS), p.alpha,
                                   pen(p.robust_reg));                                                       // :333
+                // the fused assembly can leave the solver's operands directly (no a11 .. b2 planes, no prepare pass) when the
+                // whole batch is solved in one launch
+                const bool direct = L.fused && in_active == all && !getenv("SFA_NO_DIRECT_OPERANDS");
+                aa.op = SorOperandOut();
+                if (direct) SFA_TRY(sor_operand_target(c, sorws, gi, p.niter_solver, &aa.op));
                 if (L.fused)
                     launch_assemble_images(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
                                            L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV), L.plane(P_OCC));   // :293-365
                 else
                     launch_assemble(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
                                     L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV));   // :336-365
-                if (in_active == all) {
+                if (direct) {
+                    SFA_TRY(sor_run_prepared(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), p.niter_solver, p.sor_omega));   // :368
+                } else if (in_active == all) {
                     SFA_TRY(sor_run(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1),
                                     L.plane(P_B2), L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega, false));   // :368
                 } else {

@@ -689,8 +689,14 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                                                               const float *__restrict__ vv, const float *__restrict__ sh, const float *__restrict__ sv,
                                                               const float *__restrict__ occ, Geo g) {
     constexpr int TR = TY + 2 * DT_H, AT_R1 = TY + 4, NR = NT / 64, NP = TY / NR;
-    __shared__ float sM[3][TR * DT_W];
-    __shared__ float sX[3][AT_R1 * AT_W1], sY[3][AT_R1 * AT_W1], sZ[3][AT_R1 * AT_W1];
+    // one LDS block: staged planes during the terms, the operand tile of the solver afterwards
+    constexpr int NM = TR * DT_W, N1 = AT_R1 * AT_W1;
+    __shared__ __attribute__((aligned(16))) float lds[3 * NM + 9 * N1];
+    float(*sM)[NM] = reinterpret_cast<float(*)[NM]>(lds);
+    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 3 * NM);
+    float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 3 * NM + 3 * N1);
+    float(*sZ)[N1] = reinterpret_cast<float(*)[N1]>(lds + 3 * NM + 6 * N1);
+    static_assert(TY * 65 * 10 <= 3 * NM + 9 * N1, "operand tile must fit the staging block");
     const int b = blockIdx.z;
     if (!elem_active(g.active, b)) return;
     const int x0 = blockIdx.x * DT_X - DT_H, y0 = blockIdx.y * TY - DT_H;       // origin of the halo-4 tile
@@ -818,17 +824,60 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             else          term_succ(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
         }
     }
+    float4(*tA)[65] = reinterpret_cast<float4(*)[65]>(lds);                     // [TY][65] each; live after the last barrier below
+    float4(*tB)[65] = tA + TY;
+    float2(*tX)[65] = reinterpret_cast<float2(*)[65]>(tB + TY);
+    if (a.op.sa) __syncthreads();                                   // every thread is done with the staged planes
 #pragma unroll
     for (int k = 0; k < NP; k++) {
         if (!ok[k]) continue;
-        const int y = y0 + DT_H + ty + NR * k;
+        const int yl = ty + NR * k, y = y0 + DT_H + yl;
         const size_t o = (size_t)y * g.pitch + x;
         if (a.do_laplacian) {                                                            // variational_mt.cpp:364-365
             PlaneAcc U{uu + eb, g.pitch}, V{vv + eb, g.pitch}, H{sh + eb, g.pitch}, W{sv + eb, g.pitch};
             A[k].b1 = laplacian_gather(A[k].b1, U, H, W, x, y, g.w, g.h);
             A[k].b2 = laplacian_gather(A[k].b2, V, H, W, x, y, g.w, g.h);
         }
-        a11[eb + o] = A[k].a11; a12[eb + o] = A[k].a12; a22[eb + o] = A[k].a22; b1[eb + o] = A[k].b1; b2[eb + o] = A[k].b2;
+        if (!a.op.sa) {
+            a11[eb + o] = A[k].a11; a12[eb + o] = A[k].a12; a22[eb + o] = A[k].a22; b1[eb + o] = A[k].b1; b2[eb + o] = A[k].b2;
+            continue;
+        }
+        // k_sor_prepare's per-pixel part (solver.c:101-106,159,214): neighbour weights, inverted 2x2 block
+        const float hp = sh[eb + o];
+        const float hl = x > 0 ? sh[eb + o - 1] : 0.0f;                                  // f1[0] = 0, solver.c:82
+        const float vp = sv[eb + o];
+        const float vt = y > 0 ? sv[eb + o - g.pitch] : 0.0f;
+        float dpsis = hl + hp;
+        if (y > 0) dpsis = dpsis + vt;
+        if (y < g.h - 1) dpsis = dpsis + vp;
+        const float m12 = A[k].a12;
+        const float A11 = A[k].a22 + dpsis, A22 = A[k].a11 + dpsis;                      // solver.c:102
+        const float det = A11 * A22 - m12 * m12;
+        const float i11 = __fdiv_rn(A11, det), i22 = __fdiv_rn(A22, det), i12 = __fdiv_rn(m12, -det);   // solver.c:104-106
+        tA[yl][tx] = make_float4(i11, i12, i22, vt);
+        tB[yl][tx] = make_float4(A[k].b1, A[k].b2, hp, y < g.h - 1 ? vp : 0.0f);
+        tX[yl][tx] = make_float2(u[k], v[k]);
+    }
+    if (!a.op.sa) return;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                        // reset the solver's progress words and ticket
+        for (int i = threadIdx.x; i < a.op.ntasks; i += NT) a.op.flags[(size_t)b * a.op.ntasks + i] = 0;
+        if (b == 0 && threadIdx.x == 0) a.op.flags[(size_t)a.op.nb * a.op.ntasks] = 0;
+    }
+    __syncthreads();
+    // the tile's anti-diagonals: TY consecutive entries of the diagonal-major operand planes each
+    const int c0 = x0 + DT_H, r0 = y0 + DT_H;
+    for (int item = threadIdx.x; item < (DT_X + TY - 1) * TY; item += NT) {
+        const int dl = item / TY, rl = item % TY, cl = dl - rl;
+        if (cl < 0 || cl >= DT_X) continue;
+        const int r = r0 + rl, c = c0 + cl;
+        if (r >= g.h || c >= g.w) continue;
+        const size_t e = (size_t)b * a.op.ent + (size_t)(c + r + a.op.G) * a.op.RP + (r + a.op.G);
+        a.op.sa[e] = tA[rl][cl];
+        a.op.sb[e] = tB[rl][cl];
+        const float2 xv = tX[rl][cl];
+        unsigned long long xu;
+        __builtin_memcpy(&xu, &xv, 8);
+        a.op.x[e] = xu;
     }
 }
 void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,

@@ -104,6 +104,11 @@ void launch_fill(sfa_ctx *c, float *p, size_t n, float v);
 void launch_fill_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes, float v);
 void launch_zero_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes);
 
+// Where a kernel other than k_sor_prepare leaves the solver's operands (diagonal-major planes of a SorWorkspace)
+struct SorOperandOut {
+    float4 *sa = nullptr, *sb = nullptr; unsigned long long *x = nullptr; unsigned *flags = nullptr;
+    long ent = 0; int RP = 0, G = 0, ntasks = 0, nb = 0;
+};
 struct Term {
     long stack_off; long mask_off; float hd, hg, s; int is_ref;
     // fused form (launch_assemble_images): the image pair the derivative stack is taken of, arena offsets like mask_off;
@@ -121,6 +126,9 @@ struct AssembleArgs {
     int do_laplacian;    // apply sub_laplacian(b1,uu), (b2,vv) at the end
     // fused form only: occlusion / direction weighting of the masks (variational_mt.cpp:293-320) applied on the fly
     float data_norm; int one_direction;
+    // fused form only: if op.sa is set, the 2x2 blocks are inverted and the operands written diagonal-major for the solver
+    // (what k_sor_prepare does from the planes); a11 .. b2 are then not written at all
+    SorOperandOut op;
 };
 void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base /*element arena of batch 0*/, float *a11, float *a12,
                      float *a22, float *b1, float *b2, const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv);
@@ -160,6 +168,9 @@ struct SorWorkspace {
     int configure(sfa_ctx *ctx, int w, int h, int K, int nb);   // (re)allocates for this shape
 };
 // planes: row-major device planes of element 0 (+es).  inv_out: write the inverted blocks back to a11/a12/a22
+// the same in two halves for a producer that writes the operands itself (launch_assemble_images with a.op set)
+int sor_operand_target(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, SorOperandOut *out);
+int sor_run_prepared(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, int K, float omega);
 int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
             const float *sh, const float *sv, int K, float omega, bool inv_out);
 

@@ -748,6 +748,16 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     return SFA_OK;
 }
 
+int sor_operand_target(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, SorOperandOut *out) {
+    if (g.w < 2 || g.h < 2 || K < 1) return set_error(c, SFA_ERR_ARG, "sor_operand_target: system too small for the pipelined solver");
+    SFA_TRY(ws.configure(c, g.w, g.h, K, g.nb));
+    out->sa = (float4 *)ws.sa.p; out->sb = (float4 *)ws.sb.p; out->x = (unsigned long long *)ws.x.p; out->flags = (unsigned *)ws.flags.p;
+    out->ent = ws.ent; out->RP = ws.RP; out->G = ws.G; out->ntasks = ws.ntasks; out->nb = g.nb;
+    return SFA_OK;
+}
+
+static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, int K, float omega);
+
 int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
             const float *sh, const float *sv, int K, float omega, bool inv_out) {
     if (g.w < 2 || g.h < 2 || K < 1) {                                                    // solver.c:66-69
@@ -761,7 +771,16 @@ int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, fl
     p.ent = ws.ent; p.es = g.es; p.W = g.w; p.H = g.h; p.RP = ws.RP; p.ND = ws.ND; p.G = ws.G; p.pitch = g.pitch;
     p.ntasks = ws.ntasks; p.nb = g.nb; p.inv_out = inv_out ? 1 : 0;
     hipLaunchKernelGGL(k_sor_prepare, dim3((g.w + PT_C - 1) / PT_C, (g.h + PT_R - 1) / PT_R, g.nb), dim3(256), 0, c->stream, p);
+    return sor_launch_solve(c, ws, g, du, dv, K, omega);
+}
 
+int sor_run_prepared(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, int K, float omega) {
+    if (ws.ctx != c || ws.w != g.w || ws.h != g.h || ws.K != K || ws.nb != g.nb) return set_error(c, SFA_ERR_ARG, "sor_run_prepared: workspace not configured for this system");
+    return sor_launch_solve(c, ws, g, du, dv, K, omega);
+}
+
+static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, int K, float omega) {
+    struct { float4 *sa, *sb; unsigned long long *x; unsigned *flags; } p{(float4 *)ws.sa.p, (float4 *)ws.sb.p, (unsigned long long *)ws.x.p, (unsigned *)ws.flags.p};
     SorArgs a;
     a.sa = p.sa; a.sb = p.sb; a.x = p.x; a.flags = p.flags; a.order = (const int2 *)ws.order.p; a.err = c->d_err;
     a.ent = ws.ent; a.W = g.w; a.H = g.h; a.K = K; a.NB = ws.NB; a.NG = ws.NG; a.RP = ws.RP; a.G = ws.G; a.NS = ws.NS; a.NCH = ws.NCH;
