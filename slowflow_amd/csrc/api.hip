@@ -198,18 +198,24 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             g.active = active;
             if (outer > 0) get_derivatives(c, L, p, active, need_toref);                                    // :289-290
             if (!L.fused) launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);   // :293-320
-            launch_zero_planes(c, g, L.plane(P_DU), 2);                                                      // :323-324 (du, dv adjacent)
+            // in the direct form the first inner iteration never touches du / dv / old du / old dv: they are zeros by construction
+            const bool direct_outer = L.fused && active == all && !getenv("SFA_NO_DIRECT_OPERANDS");
+            if (!direct_outer) launch_zero_planes(c, g, L.plane(P_DU), 2);                                   // :323-324 (du, dv adjacent)
             unsigned long long in_active = active;
             for (int inner = 0; inner < p.niter_inner; inner++) {
                 Geo gi = g;
                 gi.active = in_active;
-                launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                    // :329-330
+                const bool direct = direct_outer && in_active == all;
+                const bool first_zero = direct && inner == 0;        // du = dv = 0 known, planes possibly stale
+                if (!first_zero) {
+                    launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                // :329-330
+                }
                 launch_smoothness(c, gi, p.smoothing, L.plane(P_SH), L.plane(P_SV), L.plane(P_UU), L.plane(P_VV), L.plane(P_DPSIS), p.alpha,
                                   pen(p.robust_reg));                                                       // :333
                 // the fused assembly can leave the solver's operands directly (no a11 .. b2 planes, no prepare pass) when the
                 // whole batch is solved in one launch
-                const bool direct = L.fused && in_active == all && !getenv("SFA_NO_DIRECT_OPERANDS");
                 aa.op = SorOperandOut();
+                aa.zero_duv = first_zero ? 1 : 0;
                 if (direct) SFA_TRY(sor_operand_target(c, sorws, gi, p.niter_solver, &aa.op));
                 if (L.fused)
                     launch_assemble_images(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
@@ -218,7 +224,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                     launch_assemble(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
                                     L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV));   // :336-365
                 if (direct) {
-                    SFA_TRY(sor_run_prepared(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), p.niter_solver, p.sor_omega));   // :368
+                    SFA_TRY(sor_run_prepared(c, sorws, gi, nullptr, nullptr, p.niter_solver, p.sor_omega));             // :368
                 } else if (in_active == all) {
                     SFA_TRY(sor_run(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1),
                                     L.plane(P_B2), L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega, false));   // :368
@@ -234,8 +240,13 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                                             p.niter_solver, p.sor_omega, false));
                         }
                 }
-                launch_update_inner(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), L.plane(P_DU), L.plane(P_DV), L.plane(P_ODU),
-                                    L.plane(P_ODV), red);                                                   // :371-402
+                if (direct) {
+                    const bool keep = inner + 1 < p.niter_inner;      // du, dv are read again only by a further inner iteration
+                    launch_update_inner_x(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, first_zero ? nullptr : L.plane(P_ODU),
+                                          first_zero ? nullptr : L.plane(P_ODV), keep ? L.plane(P_DU) : nullptr, keep ? L.plane(P_DV) : nullptr, red);   // :371-402
+                } else
+                    launch_update_inner(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), L.plane(P_DU), L.plane(P_DV), L.plane(P_ODU),
+                                        L.plane(P_ODV), red);                                               // :371-402
                 if (use_thres_in && inner + 1 < p.niter_inner) {
                     SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                     SFA_HIP(c, hipStreamSynchronize(c->stream));

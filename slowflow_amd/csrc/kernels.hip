@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         wk[k][0] = wk[k][1] = wk[k][2] = 1.0f;
         if (!ok[k]) continue;
         const size_t o = (size_t)y * g.pitch + x;
-        u[k] = du[eb + o]; v[k] = dv[eb + o];
+        if (!a.zero_duv) { u[k] = du[eb + o]; v[k] = dv[eb + o]; }
         if (a.chw) {                                                                   // see k_assemble
             const long lin = (long)y * a.lstride + x;
             const long r0 = lin / a.chw_stride0, c0 = lin % a.chw_stride0;
@@ -942,6 +942,32 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner(float *__restrict__ uu,
         partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
     }
 }
+// the solver's result read straight from its diagonal-major x plane (k_sor_finish folded in)
+__global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ uu, float *__restrict__ vv, const float *__restrict__ wx, const float *__restrict__ wy,
+                                                            const unsigned long long *__restrict__ xs, long ent, int RP, int G, const float *__restrict__ odu,
+                                                            const float *__restrict__ odv, float *__restrict__ du_out, float *__restrict__ dv_out,
+                                                            double *__restrict__ partial, Geo g) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x;
+    double sa = 0, sb = 0;
+    if (elem_active(g.active, b) && x < g.w)
+        for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
+            const size_t o = b * g.es + (size_t)y * g.pitch + x;
+            const unsigned long long xv = xs[(size_t)b * ent + (size_t)(x + y + G) * RP + (y + G)];
+            const float d = __uint_as_float((unsigned)(xv & 0xffffffffu)), e = __uint_as_float((unsigned)(xv >> 32));
+            const float od = odu ? odu[o] : 0.0f, oe = odv ? odv[o] : 0.0f;
+            sa += (double)fabsf(od - d);                                                 // :389-393
+            sb += (double)fabsf(oe - e);
+            uu[o] = wx[o] + d;                                                           // :396-397
+            vv[o] = wy[o] + e;
+            if (du_out) { du_out[o] = d; dv_out[o] = e; }
+        }
+    block_sum2(sa, sb);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
+    }
+}
 __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx, float *__restrict__ wy, const float *__restrict__ uu, const float *__restrict__ vv,
                                                           double *__restrict__ partial, Geo g) {
     const int b = blockIdx.z;
@@ -988,6 +1014,13 @@ void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const f
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_inner, grid, block2d(), 0, c->stream, uu, vv, wx, wy, du, dv, old_du, old_dv, partials_of(c), g);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
+}
+void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const SorOperandOut &x, const float *old_du,
+                           const float *old_dv, float *du_out, float *dv_out, double *red) {
+    dim3 grid = red_grid(g, g.nb);
+    const int per_elem = grid.x * grid.y;
+    hipLaunchKernelGGL(k_update_inner_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, old_du, old_dv, du_out, dv_out, partials_of(c), g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
 }
 void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red) {

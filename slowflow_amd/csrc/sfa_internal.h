@@ -129,6 +129,7 @@ struct AssembleArgs {
     // fused form only: if op.sa is set, the 2x2 blocks are inverted and the operands written diagonal-major for the solver
     // (what k_sor_prepare does from the planes); a11 .. b2 are then not written at all
     SorOperandOut op;
+    int zero_duv;        // fused form: du = dv = 0 (first inner iteration, variational_mt.cpp:323-324): the planes are not read
 };
 void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base /*element arena of batch 0*/, float *a11, float *a12,
                      float *a22, float *b1, float *b2, const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv);
@@ -141,6 +142,10 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, con
 // du/dv -> uu,vv, zero padding, L1 change norms (variational_mt.cpp:371-402); red = per-element 2 doubles (sum|old_du-du|, sum|old_dv-dv|)
 void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const float *du, const float *dv,
                          const float *old_du, const float *old_dv, double *red /* [nb][2] */);
+// the same with du,dv taken from a solver workspace's x plane (diagonal-major); old_du == nullptr: zeros; du_out == nullptr:
+// du,dv are not stored
+void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const SorOperandOut &x, const float *old_du,
+                           const float *old_dv, float *du_out, float *dv_out, double *red);
 // sum|uu-wx|, sum|vv-wy|; wx<-uu, wy<-vv (variational_mt.cpp:412-429)
 void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red);
 void launch_copy_planes(sfa_ctx *c, const Geo &g, float *dst, const float *src, int nplanes, long dst_es, long src_es);
@@ -170,6 +175,7 @@ struct SorWorkspace {
 // planes: row-major device planes of element 0 (+es).  inv_out: write the inverted blocks back to a11/a12/a22
 // the same in two halves for a producer that writes the operands itself (launch_assemble_images with a.op set)
 int sor_operand_target(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, SorOperandOut *out);
+// du == nullptr: leave the result in the workspace's x plane (read it with launch_update_inner_x)
 int sor_run_prepared(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, int K, float omega);
 int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
             const float *sh, const float *sv, int K, float omega, bool inv_out);

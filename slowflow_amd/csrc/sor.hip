@@ -812,8 +812,9 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         c->ev_used += 2;
         c->sor_bytes += (44.0 * K + 12.0) * (double)g.w * g.h * g.nb;
     }
-    hipLaunchKernelGGL(k_sor_finish, dim3((g.w + 63) / 64, (g.h + 3) / 4, g.nb), dim3(64, 4), 0, c->stream, du, dv, p.x, ws.ent, g.es, g.w, g.h, ws.RP,
-                       ws.G, g.pitch);
+    if (du)
+        hipLaunchKernelGGL(k_sor_finish, dim3((g.w + 63) / 64, (g.h + 3) / 4, g.nb), dim3(64, 4), 0, c->stream, du, dv, p.x, ws.ent, g.es, g.w, g.h, ws.RP,
+                           ws.G, g.pitch);
     SFA_HIP(c, hipGetLastError());
     return SFA_OK;
 }
