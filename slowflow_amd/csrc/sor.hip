@@ -678,8 +678,8 @@ static int band_shape(int K, int nb) {
     // spread over K CUs (shorter critical path); SFA_SOR_BAND = 0 (never) / 1..3 (always, that many fused sweeps)
     int F = nb >= 16 ? 3 : 0;
     if (const char *e = getenv("SFA_SOR_BAND")) F = atoi(e);
-    if (F <= 0 || F > 3) return 0;
-    auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f <= (f == 3 ? 10 : 16); };
+    if (F <= 0 || F > 5 || F == 4) return 0;
+    auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f <= (f == 5 ? 6 : f == 3 ? 10 : 16); };
     if (fits(F)) return F;
     if (fits(3)) return 3;
     if (fits(2)) return 2;
@@ -797,7 +797,8 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
         const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F);
-        if (ws.F == 3)      hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
+        if (ws.F == 5)      hipLaunchKernelGGL((k_sor_band<5, 6, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
+        else if (ws.F == 3) hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, kBandCH, kBandMC, 8>), bgrid, bblock, lds, c->stream, ba);
         else                hipLaunchKernelGGL((k_sor_band<1, 16, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
     } else {
