@@ -691,12 +691,13 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     constexpr int TR = TY + 2 * DT_H, AT_R1 = TY + 4, NR = NT / 64, NP = TY / NR;
     // one LDS block: staged planes during the terms, the operand tile of the solver afterwards
     constexpr int NM = TR * DT_W, N1 = AT_R1 * AT_W1;
-    __shared__ __attribute__((aligned(16))) float lds[3 * NM + 9 * N1];
-    float(*sM)[NM] = reinterpret_cast<float(*)[NM]>(lds);
-    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 3 * NM);
-    float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 3 * NM + 3 * N1);
-    float(*sZ)[N1] = reinterpret_cast<float(*)[N1]>(lds + 3 * NM + 6 * N1);
-    static_assert(TY * 65 * 10 <= 3 * NM + 9 * N1, "operand tile must fit the staging block");
+    __shared__ __attribute__((aligned(16))) float lds[6 * NM + 6 * N1];
+    float(*sM)[NM] = reinterpret_cast<float(*)[NM]>(lds);                       // M  = (I1+I2)/2, halo 4 (rows x DT_W)
+    float(*sZ)[NM] = reinterpret_cast<float(*)[NM]>(lds + 3 * NM);              // Iz = I1-I2, same geometry (aligned 16-byte rows)
+    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 6 * NM);              // Ix, Iy: halo 2 (rows x AT_W1)
+    float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 6 * NM + 3 * N1);
+    static_assert(TY * 65 * 10 <= 6 * NM + 6 * N1, "operand tile must fit the staging block");
+    static_assert(DT_W % 4 == 0 && AT_W1 % 4 == 0 && NM % 4 == 0 && N1 % 4 == 0, "16-byte LDS rows");
     const int b = blockIdx.z;
     if (!elem_active(g.active, b)) return;
     const int x0 = blockIdx.x * DT_X - DT_H, y0 = blockIdx.y * TY - DT_H;       // origin of the halo-4 tile
@@ -729,82 +730,94 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         bwd[k] = __fdiv_rn((oc >= 0.0f) ? 1.0f : 0.0f, factor);
         fwd[k] = __fdiv_rn((oc <= 0.0f) ? 1.0f : 0.0f, factor);
     }
-    // this thread's staging columns: tile column tx (and 64 + tx for the first lanes), source column clamped into the image
-    const int gxa = clampi(x0 + tx, 0, g.w - 1), gxb = clampi(x0 + 64 + tx, 0, g.w - 1);
-    // stage-1 columns of the halo-2 region; sM index shift that realises X(clamp(x), y) for columns outside the image
-    const int sxa = clampi(x0 + 2 + tx, 0, g.w - 1) - (x0 + 2 + tx), sxb = clampi(x0 + 66 + tx, 0, g.w - 1) - (x0 + 66 + tx);
+    constexpr int QM = DT_W / 4, Q1 = AT_W1 / 4;                     // float4 quads per staged row
     for (int t = 0; t < a.n; t++) {
         const Term &T = a.t[t];
         const float *pa = base + eb + T.i1_off, *pb = base + eb + T.i2_off;
         __syncthreads();                                           // the staged planes are free again
-        // stage 0: M (halo 4), Iz (halo 2) of the three channels; rows outside the image are never read
-        for (int ly = ty; ly < TR; ly += NR) {
-            const int gy = y0 + ly;
+#ifdef SFA_EXP_NOSTAGE
+        if (t >= 0) goto stage2;
+#endif
+        // stage 0: M and Iz (halo 4) of the three channels, one float4 of a row per item; columns outside the image are
+        // replicated (clamped source column), rows outside are never read
+        for (int item = threadIdx.x; item < TR * 3 * QM; item += NT) {
+            const int q = item % QM, ch = (item / QM) % 3, ly = item / (3 * QM);
+            const int gy = y0 + ly, gx = x0 + 4 * q;
             if (gy < 0 || gy >= g.h) continue;
-            const size_t orow = (size_t)gy * g.pitch;
-            const bool zrow = ly >= 2 && ly < TR - 2;
-            float va[3], vb[3], wa[3], wb[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) { va[ch] = pa[ch * g.pl + orow + gxa]; vb[ch] = pb[ch * g.pl + orow + gxa]; }
-            if (tx < DT_W - 64) {
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) { wa[ch] = pa[ch * g.pl + orow + gxb]; wb[ch] = pb[ch * g.pl + orow + gxb]; }
+            const float *ra = pa + ch * g.pl + (size_t)gy * g.pitch, *rb = pb + ch * g.pl + (size_t)gy * g.pitch;
+            float4 va, vb;
+            if (gx >= 0 && gx + 3 < g.w) {
+                va = *reinterpret_cast<const float4 *>(ra + gx);
+                vb = *reinterpret_cast<const float4 *>(rb + gx);
+            } else {
+                const int c0 = clampi(gx, 0, g.w - 1), c1 = clampi(gx + 1, 0, g.w - 1), c2 = clampi(gx + 2, 0, g.w - 1), c3 = clampi(gx + 3, 0, g.w - 1);
+                va = make_float4(ra[c0], ra[c1], ra[c2], ra[c3]);
+                vb = make_float4(rb[c0], rb[c1], rb[c2], rb[c3]);
             }
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                sM[ch][ly * DT_W + tx] = 0.5f * (vb[ch] + va[ch]);                     // variational_mt.cpp:120
-                if (zrow && tx >= 2) sZ[ch][(ly - 2) * AT_W1 + (tx - 2)] = va[ch] - vb[ch];             // :122
-            }
-            if (tx < DT_W - 64) {
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    sM[ch][ly * DT_W + 64 + tx] = 0.5f * (wb[ch] + wa[ch]);
-                    if (zrow && tx < DT_W - 66) sZ[ch][(ly - 2) * AT_W1 + (62 + tx)] = wa[ch] - wb[ch];
-                }
-            }
+            *reinterpret_cast<float4 *>(&sM[ch][ly * DT_W + 4 * q]) =
+                make_float4(0.5f * (vb.x + va.x), 0.5f * (vb.y + va.y), 0.5f * (vb.z + va.z), 0.5f * (vb.w + va.w));        // variational_mt.cpp:120
+            *reinterpret_cast<float4 *>(&sZ[ch][ly * DT_W + 4 * q]) = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);   // :122
         }
         __syncthreads();
-        // stage 1: Ix, Iy on the halo-2 region
-        for (int ly = ty; ly < AT_R1; ly += NR) {
-            const int gy = y0 + 2 + ly;
+        // stage 1: Ix, Iy on the halo-2 region, four columns per item (two aligned quads of M per tap row)
+        for (int item = threadIdx.x; item < AT_R1 * 3 * Q1; item += NT) {
+            const int q = item % Q1, ch = (item / Q1) % 3, ly = item / (3 * Q1);
+            const int gy = y0 + 2 + ly, gx = x0 + 2 + 4 * q;
             if (gy < 0 || gy >= g.h) continue;
+            const float *M = sM[ch];
+            const int c = (ly + 2) * DT_W + 4 * q;                 // M index of column gx - 2
+            float m[5][8];                                          // rows gy-2 .. gy+2, columns gx-2 .. gx+5
             const bool y_in = gy >= 2 && gy + 2 < g.h;
-            const int c = (ly + 2) * DT_W + 2;
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const float *M = sM[ch];
-                sX[ch][ly * AT_W1 + tx] = d5x_in<DT_W>(M, c + tx + sxa);                                  // :127
-                if (tx < AT_W1 - 64) sX[ch][ly * AT_W1 + 64 + tx] = d5x_in<DT_W>(M, c + 64 + tx + sxb);
-                if (y_in) {                                                                               // :128
-                    sY[ch][ly * AT_W1 + tx] = d5y_in<DT_W>(M, c + tx);
-                    if (tx < AT_W1 - 64) sY[ch][ly * AT_W1 + 64 + tx] = d5y_in<DT_W>(M, c + 64 + tx);
-                } else {
-                    const TileAcc m4{M, x0, y0};
-                    sY[ch][ly * AT_W1 + tx] = d5y(m4, clampi(x0 + 2 + tx, 0, g.w - 1), gy, g.h);
-                    if (tx < AT_W1 - 64) sY[ch][ly * AT_W1 + 64 + tx] = d5y(m4, clampi(x0 + 66 + tx, 0, g.w - 1), gy, g.h);
-                }
+            for (int r = 0; r < 5; r++) {
+                if (r != 2 && !y_in) continue;
+                const float4 lo = *reinterpret_cast<const float4 *>(M + c + (r - 2) * DT_W), hi = *reinterpret_cast<const float4 *>(M + c + (r - 2) * DT_W + 4);
+                m[r][0] = lo.x; m[r][1] = lo.y; m[r][2] = lo.z; m[r][3] = lo.w; m[r][4] = hi.x; m[r][5] = hi.y; m[r][6] = hi.z; m[r][7] = hi.w;
             }
+            float X[4], Y[4];
+            if (gx >= 0 && gx + 3 < g.w) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) X[e] = tap5(m[2][e], m[2][e + 1], m[2][e + 2], m[2][e + 3], m[2][e + 4]);            // :127
+            } else {                                                // X(clamp(x), y) for the columns outside the image
+#pragma unroll
+                for (int e = 0; e < 4; e++) X[e] = d5x_in<DT_W>(M, c + 2 + e + (clampi(gx + e, 0, g.w - 1) - (gx + e)));
+            }
+            if (y_in) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) Y[e] = tap5(m[0][e + 2], m[1][e + 2], m[2][e + 2], m[3][e + 2], m[4][e + 2]);        // :128
+            } else {
+                const TileAcc m4{M, x0, y0};
+#pragma unroll
+                for (int e = 0; e < 4; e++) Y[e] = d5y(m4, clampi(gx + e, 0, g.w - 1), gy, g.h);
+            }
+            *reinterpret_cast<float4 *>(&sX[ch][ly * AT_W1 + 4 * q]) = make_float4(X[0], X[1], X[2], X[3]);
+            *reinterpret_cast<float4 *>(&sY[ch][ly * AT_W1 + 4 * q]) = make_float4(Y[0], Y[1], Y[2], Y[3]);
         }
+#ifdef SFA_EXP_NOSTAGE
+    stage2:
+#endif
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NP; k++) {
             const int y = y0 + DT_H + ty + NR * k;
             if (y >= g.h) break;
             const bool y_in = y >= 2 && y + 2 < g.h;
-            const int c = (ty + NR * k + 2) * AT_W1 + (tx + 2);
+            const int c = (ty + NR * k + 2) * AT_W1 + (tx + 2);   // halo-2 planes (Ix, Iy)
+            const int cz = (ty + NR * k + 4) * DT_W + (tx + 4);   // halo-4 plane (Iz)
             Px p;
             if (y_in) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     p.ixy[ch] = d5y_in<AT_W1>(sX[ch], c);                              // :130
                     p.iyy[ch] = d5y_in<AT_W1>(sY[ch], c);                              // :131
-                    p.iyz[ch] = d5y_in<AT_W1>(sZ[ch], c);                              // :133
+                    p.iyz[ch] = d5y_in<DT_W>(sZ[ch], cz);                              // :133
                 }
             } else {
                 const int xc = x < g.w ? x : g.w - 1;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const Tile2Acc X{sX[ch], x0 + 2, y0 + 2}, Y{sY[ch], x0 + 2, y0 + 2}, Z{sZ[ch], x0 + 2, y0 + 2};
+                    const Tile2Acc X{sX[ch], x0 + 2, y0 + 2}, Y{sY[ch], x0 + 2, y0 + 2};
+                    const TileAcc Z{sZ[ch], x0, y0};
                     p.ixy[ch] = d5y(X, xc, y, g.h);
                     p.iyy[ch] = d5y(Y, xc, y, g.h);
                     p.iyz[ch] = d5y(Z, xc, y, g.h);
@@ -813,15 +826,19 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 p.wk[ch] = wk[k][ch];
-                p.ix[ch] = sX[ch][c]; p.iy[ch] = sY[ch][c]; p.iz[ch] = sZ[ch][c];
+                p.ix[ch] = sX[ch][c]; p.iy[ch] = sY[ch][c]; p.iz[ch] = sZ[ch][cz];
                 p.ixx[ch] = d5x_in<AT_W1>(sX[ch], c);                                  // :129
-                p.ixz[ch] = d5x_in<AT_W1>(sZ[ch], c);                                  // :132
+                p.ixz[ch] = d5x_in<DT_W>(sZ[ch], cz);                                  // :132
             }
             if (!ok[k]) continue;
             float m = base[eb + T.mask_off + (size_t)y * g.pitch + x];
             if (!a.one_direction || !T.backward) m = T.backward ? 1.0f * bwd[k] * m : 1.0f * fwd[k] * m;   // :314,316
+#ifdef SFA_EXP_NOTERM
+            { float q = m; for (int ch = 0; ch < 3; ch++) q += p.ix[ch] + p.iy[ch] + p.iz[ch] + p.ixx[ch] + p.ixy[ch] + p.iyy[ch] + p.ixz[ch] + p.iyz[ch]; A[k].a11 += q; }
+#else
             if (T.is_ref) term_ref(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
             else          term_succ(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
+#endif
         }
     }
     float4(*tA)[65] = reinterpret_cast<float4(*)[65]>(lds);                     // [TY][65] each; live after the last barrier below
