@@ -60,6 +60,10 @@ typedef struct sfa_params {
     int   layers;               /* slow_flow_layers */
     float p_scale;              /* slow_flow_p_scale */
     float presmooth_sigma;      /* > 0 when cfg `sigma` > 0: value of slow_flow_sigma */
+    /* discrete occlusion step between alternations (optimizeOcc, variational_aux_mt.cpp:758-887) */
+    float occlusion_penalty;    /* slow_flow_occlusion_penalty ("1.0"): cost of the label "occluded in the future" */
+    float occlusion_alpha;      /* slow_flow_occlusion_alpha ("0.5"): Potts weight between 4-neighbours */
+    int   niter_graphc;         /* slow_flow_niter_graphc ("10"): expansion iterations; a two-label cut is exact after one */
 } sfa_params;
 
 typedef struct sfa_ctx sfa_ctx;
@@ -105,6 +109,15 @@ void sor_coupled(sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, s
                  sfa_image *b2, sfa_image *dpsis_horiz, sfa_image *dpsis_vert, const int iterations, const float omega);
 
 /* ---- stage entry points (host planes; used by the parity tests and by partial integrations) ------ */
+
+/* optimizeOcc, first half (variational_aux_mt.cpp:783-866): the data costs of the labels "occluded in the past" (d0) and
+ * "occluded in the future" (d1).  masks[s]: raw warp mask of slot s; succ1/succ2[s], ref1/ref2[s]: the colour image pairs
+ * (first plane of 3) whose difference is Iz of the slot's successive-frames / reference-frame derivative stack. */
+int sfa_occlusion_costs(sfa_ctx *ctx, const sfa_params *p, float *d0, float *d1, const float *const *masks, const float *const *succ1,
+                        const float *const *succ2, const float *const *ref1, const float *const *ref2, int w, int h, int stride);
+/* optimizeOcc, second half (:868-880): occ[p] = 2*l_p - 1 for the labelling that minimises sum_p D_{l_p}(p) + alpha * #{4-neighbour
+ * pairs with different labels} -- what GCO's two-label expansion computes; exact s-t minimum cut on the GPU. */
+int sfa_grid_cut(sfa_ctx *ctx, float *occ, const float *d0, const float *d1, int w, int h, int stride, float alpha);
 
 /* Variational_AUX_MT::image_warp (variational_aux_mt.cpp:722-756); mask may be NULL */
 int sfa_image_warp(sfa_ctx *ctx, float *dst3, float *mask, const float *src3, const float *wx, const float *wy,

@@ -68,6 +68,7 @@ class Params(C.Structure):
         ("rho", C.c_float * MAX_REF), ("omega", C.c_float * MAX_REF),
         ("hbit", C.c_int), ("norm_avg", C.c_float * 3), ("norm_std", C.c_float * 3),
         ("occlusion_reasoning", C.c_int), ("layers", C.c_int), ("p_scale", C.c_float), ("presmooth_sigma", C.c_float),
+        ("occlusion_penalty", C.c_float), ("occlusion_alpha", C.c_float), ("niter_graphc", C.c_int),
     ]
 
 
@@ -95,6 +96,33 @@ class Oracle:
         s = np.array([self.lib.orc_psi_deriv_scalar(C.byref(pen), C.c_float(v)) for v in x.ravel()], dtype=np.float32)
         v = np.array([self.lib.orc_psi_deriv_vec(C.byref(pen), C.c_float(v)) for v in x.ravel()], dtype=np.float32)
         return s.reshape(x.shape), v.reshape(x.shape)
+
+    def psi_apply(self, pen, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        self.lib.orc_psi_apply_vec.restype = C.c_float
+        v = np.array([self.lib.orc_psi_apply_vec(C.byref(pen), C.c_float(t)) for t in x.ravel()], dtype=np.float32)
+        return v.reshape(x.shape)
+
+    def occlusion_costs(self, masks, succ, toref, ref, rho, omega, hd, hg, penalty, color, grad, w):
+        """masks (2ref,h,stride), succ/toref (2ref,8,3,h,stride) -> d0, d1"""
+        _, h, stride = masks.shape
+        d0, d1 = plane(h, stride), plane(h, stride)
+        r = (C.c_float * len(rho))(*rho); o = (C.c_float * len(omega))(*omega)
+        self.lib.orc_occlusion_costs(fptr(d0), fptr(d1), fptr(masks), fptr(succ), fptr(toref), int(ref), r, o, C.c_float(hd), C.c_float(hg),
+                                     C.c_float(penalty), C.byref(color), C.byref(grad), w, h, stride)
+        return d0, d1
+
+    def grid_cut(self, d0, d1, alpha, w):
+        h, stride = d0.shape
+        occ = plane(h, stride)
+        self.lib.orc_grid_cut.restype = C.c_double
+        e = self.lib.orc_grid_cut(fptr(occ), fptr(d0), fptr(d1), C.c_float(alpha), w, h, stride)
+        return occ, e
+
+    def grid_cut_energy(self, occ, d0, d1, alpha, w):
+        h, stride = d0.shape
+        self.lib.orc_grid_cut_energy.restype = C.c_double
+        return self.lib.orc_grid_cut_energy(fptr(occ), fptr(d0), fptr(d1), C.c_float(alpha), w, h, stride)
 
     def convolve(self, src, w, order, horiz):
         h, stride = src.shape
@@ -322,6 +350,14 @@ class RefLib:
         self.lib.compute_data_and_match(*[C.byref(i) for i in imgs], *[C.byref(c) for c in cols],
                                         C.c_float(half_delta_over3), C.c_float(half_gamma_over3))
         return outs
+
+    def penalty_apply(self, pid, eps, trunc, x):
+        x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+        n = (x.size // 4) * 4
+        x = x[:n].copy()
+        v = np.zeros(n, np.float32)
+        self.lib.ref_penalty_apply(int(pid), C.c_float(eps), C.c_float(trunc), fptr(x), n, fptr(v))
+        return x, v
 
     def penalty_derivative(self, pid, eps, trunc, x):
         x = np.ascontiguousarray(x, dtype=np.float32).ravel()

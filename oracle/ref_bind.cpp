@@ -32,3 +32,14 @@ extern "C" void ref_penalty_derivative(int id, float eps, float trunc, const flo
     }
     delete f;
 }
+
+// psi itself (apply), the v4sf overload optimizeOcc evaluates (variational_aux_mt.cpp:819-830)
+extern "C" void ref_penalty_apply(int id, float eps, float trunc, const float *xsq, int n, float *out_vec) {
+    PenaltyFunction *f = make(id, eps, trunc);
+    for (int i = 0; i + 4 <= n; i += 4) {
+        v4sf x = {xsq[i], xsq[i + 1], xsq[i + 2], xsq[i + 3]};
+        v4sf y = f->apply(x);
+        out_vec[i] = y[0]; out_vec[i + 1] = y[1]; out_vec[i + 2] = y[2]; out_vec[i + 3] = y[3];
+    }
+    delete f;
+}

@@ -35,6 +35,7 @@ void orc_params_default(orc_params *p) {
     for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
     p->occlusion_reasoning = 1;
     p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;
+    p->occlusion_penalty = 1.0f; p->occlusion_alpha = 0.5f; p->niter_graphc = 10;   /* variational_mt.cpp:182,189-190 */
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -80,6 +81,21 @@ float orc_psi_deriv_vec(const orc_penalty *pen, float xsq) {
         return (e2 + 2.0f * xsq) / tmp;
     }
     default: return 1.0f / (2.0f * sqrtf(xsq + e2));
+    }
+}
+
+float orc_psi_apply_vec(const orc_penalty *pen, float xsq) {
+    const float e2 = pen->eps * pen->eps;
+    switch (pen->id) {
+    case 0: return xsq;
+    case 2: return (float)log(1 + 0.5 * (double)xsq / (double)e2);              /* double: epsilon_sq is a double member */
+    case 3: {
+        float out = sqrtf(xsq + e2);
+        if (sqrtf(xsq) > pen->trunc) out = sqrtf(pen->trunc + e2);              /* sic: truncation, not its square */
+        return out;
+    }
+    case 4: return xsq / ((xsq + 1.0f) * (xsq + 1.0f));
+    default: return sqrtf(xsq + e2);
     }
 }
 
@@ -703,6 +719,131 @@ void orc_normalize_publish(const double avg[3], const double std_dev[3], float a
 }
 
 /* ------------------------------------------------------------------------------------------
+ * variational_aux_mt.cpp:758-887 -- optimizeOcc.  TEST INFRASTRUCTURE, parity unpinned (see header).
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_DT_SCALE_GRAPHC 0.01f   /* variational_aux_mt.h:24 */
+
+void orc_occlusion_costs(float *d0, float *d1, const float *masks, const float *succ, const float *toref, int ref,
+                         const float *rho, const float *omega, float hd, float hg, float penalty,
+                         const orc_penalty *color, const orc_penalty *grad, int w, int h, int stride) {
+    const size_t plane = (size_t)stride * h, cimg = 3 * plane, stack = 8 * cimg;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t o = (size_t)y * stride + x;
+            float e[2] = {0.0f, 0.0f}, n[2] = {0.0f, 0.0f};
+            for (int s = 0; s < 2 * ref; s++) {
+                const float m = masks[s * plane + o];
+                const float *S = succ + s * stack, *R = toref + s * stack;
+                const float *iz = S + 2 * cimg + o, *ixz = S + 6 * cimg + o, *iyz = S + 7 * cimg + o;
+                const float *izr = R + 2 * cimg + o, *ixzr = R + 6 * cimg + o, *iyzr = R + 7 * cimg + o;
+                const int idx = (ref - s - 1 > s - ref) ? ref - s - 1 : s - ref;                                  /* :814 */
+                float term = rho[idx] * hd * m * orc_psi_apply_vec(color, iz[0] * iz[0] + iz[plane] * iz[plane] + iz[2 * plane] * iz[2 * plane]);   /* :817 */
+                term += rho[idx] * hg * m * orc_psi_apply_vec(grad, ixz[0] * ixz[0] + ixz[plane] * ixz[plane] + ixz[2 * plane] * ixz[2 * plane] +
+                                                                        iyz[0] * iyz[0] + iyz[plane] * iyz[plane] + iyz[2 * plane] * iyz[2 * plane]);   /* :818-819 */
+                term += omega[idx] * hd * m * orc_psi_apply_vec(color, izr[0] * izr[0] + izr[plane] * izr[plane] + izr[2 * plane] * izr[2 * plane]);   /* :822 */
+                term += omega[idx] * hg * m * orc_psi_apply_vec(grad, ixzr[0] * ixzr[0] + ixzr[plane] * ixzr[plane] + ixzr[2 * plane] * ixzr[2 * plane] +
+                                                                          iyzr[0] * iyzr[0] + iyzr[plane] * iyzr[plane] + iyzr[2 * plane] * iyzr[2 * plane]);   /* :823-827 */
+                const int l = s >= ref ? 0 : 1;                                                                   /* :829-837 */
+                e[l] += term;
+                n[l] += m * (rho[idx] + rho[idx] + omega[idx] + omega[idx]);
+            }
+            for (int l = 0; l < 2; l++) {
+                if (n[l] == 0) n[l] = 1;                                                                          /* :846-849 */
+                const float c = ORC_DT_SCALE_GRAPHC * e[l] / n[l] + penalty * l;                                 /* :851 */
+                (l ? d1 : d0)[o] = c;
+            }
+        }
+}
+
+double orc_grid_cut_energy(const float *occ, const float *d0, const float *d1, float alpha, int w, int h, int stride) {
+    double E = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t o = (size_t)y * stride + x;
+            const int l = occ[o] > 0;
+            E += l ? d1[o] : d0[o];
+            if (x + 1 < w && (occ[o + 1] > 0) != l) E += alpha;
+            if (y + 1 < h && (occ[o + stride] > 0) != l) E += alpha;
+        }
+    return E;
+}
+
+/* Dinic on the implicit grid graph.  Node p: source arc capacity max(D1-D0, 0) (cut when p takes label 1), sink arc
+ * max(D0-D1, 0); four neighbour arcs of capacity alpha each way.  Label 1 = sink side = cannot be reached from the
+ * source in the residual graph. */
+typedef struct { int w, h; double *cs, *ct, *cn; int *level, *it; } cutg;   /* cn[4*p + d]: residual p -> neighbour d (0:+x 1:-x 2:+y 3:-y) */
+static int cut_nb(const cutg *g, int p, int d) {
+    const int x = p % g->w, y = p / g->w;
+    switch (d) {
+    case 0: return x + 1 < g->w ? p + 1 : -1;
+    case 1: return x > 0 ? p - 1 : -1;
+    case 2: return y + 1 < g->h ? p + g->w : -1;
+    default: return y > 0 ? p - g->w : -1;
+    }
+}
+static int cut_bfs(cutg *g, int *queue) {   /* levels from the source; returns 1 if the sink is reachable */
+    const int N = g->w * g->h;
+    int qh = 0, qt = 0, reach = 0;
+    for (int p = 0; p < N; p++) {
+        g->level[p] = -1;
+        if (g->cs[p] > 0) { g->level[p] = 1; queue[qt++] = p; }
+    }
+    while (qh < qt) {
+        const int p = queue[qh++];
+        if (g->ct[p] > 0) reach = 1;
+        for (int d = 0; d < 4; d++) {
+            const int q = cut_nb(g, p, d);
+            if (q >= 0 && g->cn[4 * p + d] > 0 && g->level[q] < 0) { g->level[q] = g->level[p] + 1; queue[qt++] = q; }
+        }
+    }
+    return reach;
+}
+static double cut_dfs(cutg *g, int p, double f) {   /* iterative would be safer for huge grids; test sizes are small */
+    if (g->ct[p] > 0) {
+        const double a = f < g->ct[p] ? f : g->ct[p];
+        g->ct[p] -= a;
+        return a;
+    }
+    for (; g->it[p] < 4; g->it[p]++) {
+        const int d = g->it[p], q = cut_nb(g, p, d);
+        if (q < 0 || g->cn[4 * p + d] <= 0 || g->level[q] != g->level[p] + 1) continue;
+        const double a = cut_dfs(g, q, f < g->cn[4 * p + d] ? f : g->cn[4 * p + d]);
+        if (a > 0) {
+            g->cn[4 * p + d] -= a;
+            g->cn[4 * q + (d ^ 1)] += a;
+            return a;
+        }
+    }
+    return 0;
+}
+double orc_grid_cut(float *occ, const float *d0, const float *d1, float alpha, int w, int h, int stride) {
+    const int N = w * h;
+    cutg g = {w, h, calloc(N, sizeof(double)), calloc(N, sizeof(double)), calloc(4 * (size_t)N, sizeof(double)), malloc(N * sizeof(int)), malloc(N * sizeof(int))};
+    int *queue = malloc(N * sizeof(int));
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int p = y * w + x;
+            const double u = (double)d1[(size_t)y * stride + x] - (double)d0[(size_t)y * stride + x];
+            if (u > 0) g.cs[p] = u; else g.ct[p] = -u;
+            for (int d = 0; d < 4; d++) g.cn[4 * p + d] = cut_nb(&g, p, d) >= 0 ? alpha : 0;
+        }
+    while (cut_bfs(&g, queue)) {
+        memset(g.it, 0, N * sizeof(int));
+        for (int p = 0; p < N; p++)
+            while (g.cs[p] > 0 && g.level[p] == 1) {
+                const double a = cut_dfs(&g, p, g.cs[p]);
+                if (a <= 0) break;
+                g.cs[p] -= a;
+            }
+    }
+    cut_bfs(&g, queue);                                         /* level >= 0: reachable from the source = label 0 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) occ[(size_t)y * stride + x] = g.level[y * w + x] >= 0 ? -1.0f : 1.0f;   /* :876 */
+    free(g.cs); free(g.ct); free(g.cn); free(g.level); free(g.it); free(queue);
+    return orc_grid_cut_energy(occ, d0, d1, alpha, w, h, stride);
+}
+
+/* ------------------------------------------------------------------------------------------
  * variational_mt.cpp:169-493 -- one pyramid level
  * ---------------------------------------------------------------------------------------- */
 int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *const *frames,
@@ -739,8 +880,7 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
     int rc = 0;
     for (int alter = 0; alter < p->niter_alter && !rc; alter++) {
         int need_derivs = 1;                                                    /* :266 */
-        /* alter > 0 with occlusion reasoning would call optimizeOcc (GCO, :269-273): not part of the
-         * oracle; occ keeps its initial value */
+        int occ_pending = alter > 0 && p->occlusion_reasoning && !p->one_direction;   /* :269-272, after get_derivatives (:266) */
         for (int outer = 0; outer < p->niter_outer; outer++) {
             if (outer > 0) need_derivs = 1;                                     /* :289-290 */
             if (need_derivs) {
@@ -758,6 +898,14 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
                     else         orc_derivative_stack(toref + s * stack, frames[ref], w_sp1, w, h, stride);    /* :143-144 */
                 }
                 need_derivs = 0;
+                if (occ_pending) {                                           /* optimizeOcc on the raw warp masks */
+                    float *d0 = plane_alloc(plane), *d1 = plane_alloc(plane);
+                    orc_occlusion_costs(d0, d1, mask, succ, toref, ref, p->rho, p->omega, delta_over3, gamma_over3, p->occlusion_penalty,
+                                        &p->robust_color, &p->robust_grad, w, h, stride);
+                    orc_grid_cut(occ, d0, d1, p->occlusion_alpha, w, h, stride);
+                    free(d0); free(d1);
+                    occ_pending = 0;
+                }
             }
             /* mask weighting :293-320 */
             for (int y = 0; y < h; y++)

@@ -60,6 +60,9 @@ typedef struct {
     int   layers;             /* slow_flow_layers */
     float p_scale;            /* slow_flow_p_scale */
     float presmooth_sigma;    /* >0: cfg sigma>0, value of slow_flow_sigma */
+    float occlusion_penalty;  /* slow_flow_occlusion_penalty */
+    float occlusion_alpha;    /* slow_flow_occlusion_alpha */
+    int   niter_graphc;       /* slow_flow_niter_graphc */
 } orc_params;
 
 void orc_params_default(orc_params *p);
@@ -67,6 +70,22 @@ void orc_params_default(orc_params *p);
 /* penalty_functions headers: psi'(x^2).  scalar overload = double inside, vec = pure fp32 */
 float orc_psi_deriv_scalar(const orc_penalty *pen, float xsq);
 float orc_psi_deriv_vec(const orc_penalty *pen, float xsq);
+/* psi itself, v4sf overload (modified_l1_norm.h:24-26, quadratic_function.h:18-20, lorentzian.h:24-32,
+ * trunc_modified_l1_norm.h:27-36, geman_mcclure.h:24-26) */
+float orc_psi_apply_vec(const orc_penalty *pen, float xsq);
+
+/* optimizeOcc (variational_aux_mt.cpp:758-887), first half: the two data costs per pixel.  succ / toref: nslots derivative
+ * stacks (8 x 3 planes each, orc_derivative_stack order), masks: nslots raw warp masks.  PARITY UNPINNED (the file does
+ * not compile here); psi is pinned. */
+void orc_occlusion_costs(float *d0, float *d1, const float *masks, const float *succ, const float *toref, int ref,
+                         const float *rho, const float *omega, float delta_over3, float gamma_over3, float penalty,
+                         const orc_penalty *color, const orc_penalty *grad, int w, int h, int stride);
+/* second half: GCO's two-label expansion = the exact minimum of sum_p D_{l_p}(p) + alpha * #{4-neighbours p,q: l_p != l_q}
+ * (s-t minimum cut; Dinic, fp64).  occ[p] = 2*l_p - 1.  Returns the minimum energy.  GCO v3.0 is not vendored: PARITY
+ * UNPINNED (ties may be broken differently). */
+double orc_grid_cut(float *occ, const float *d0, const float *d1, float alpha, int w, int h, int stride);
+/* energy of a labelling occ in {-1,+1} under the same model */
+double orc_grid_cut_energy(const float *occ, const float *d0, const float *d1, float alpha, int w, int h, int stride);
 
 /* image.c:400-526: 3-tap (order 1) / 5-tap (order 2) antisymmetric derivative filters.
  * order==2: c = [1/12,-8/12,-0,8/12,-1/12]; order==1: c = [-.5,-0,.5] */

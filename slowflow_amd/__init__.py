@@ -46,6 +46,7 @@ class Params(C.Structure):
         ("rho", C.c_float * MAX_REF), ("omega", C.c_float * MAX_REF),
         ("hbit", C.c_int), ("norm_avg", C.c_float * 3), ("norm_std", C.c_float * 3),
         ("occlusion_reasoning", C.c_int), ("layers", C.c_int), ("p_scale", C.c_float), ("presmooth_sigma", C.c_float),
+        ("occlusion_penalty", C.c_float), ("occlusion_alpha", C.c_float), ("niter_graphc", C.c_int),
     ]
 
 
@@ -58,7 +59,7 @@ EXPORTS = [
     "sfa_device_count", "sfa_ctx_create", "sfa_ctx_destroy", "sfa_last_error", "sfa_ctx_sync", "sfa_params_default",
     "sfa_variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sor_coupled",
     "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
-    "sfa_add_data_and_match", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_pyramid_sizes",
+    "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_pyramid_sizes",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_mpix_iters",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
     "sfa_profile_enable", "sfa_profile_read", "sfa_timer_start", "sfa_timer_stop",
@@ -169,6 +170,22 @@ class Context:
         h, stride = src.shape
         self._ck(lib().sfa_sub_laplacian(self.h, fptr(dst), fptr(src), fptr(wh), fptr(wv), w, h, stride), "sfa_sub_laplacian")
         return dst
+
+    def occlusion_costs(self, p, masks, succ1, succ2, ref1, ref2, w):
+        """masks: list of 2ref planes; succ1/succ2/ref1/ref2: lists of 2ref colour images (3,h,stride) -> d0, d1"""
+        h, stride = masks[0].shape
+        d0, d1 = np.zeros((h, stride), np.float32), np.zeros((h, stride), np.float32)
+        n = len(masks)
+        arr = lambda xs: (_f * n)(*[fptr(x) for x in xs])
+        self._ck(lib().sfa_occlusion_costs(self.h, C.byref(p), fptr(d0), fptr(d1), arr(masks), arr(succ1), arr(succ2), arr(ref1), arr(ref2), w, h, stride),
+                 "sfa_occlusion_costs")
+        return d0, d1
+
+    def grid_cut(self, d0, d1, alpha, w):
+        h, stride = d0.shape
+        occ = np.zeros((h, stride), np.float32)
+        self._ck(lib().sfa_grid_cut(self.h, fptr(occ), fptr(d0), fptr(d1), w, h, stride, C.c_float(alpha)), "sfa_grid_cut")
+        return occ
 
     def add_data(self, sysm, mask, du, dv, D, chw, w, hd, hg, s, dt_norm, color, grad, ref_term=False):
         a11, a12, a22, b1, b2 = sysm

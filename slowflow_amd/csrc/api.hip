@@ -126,7 +126,27 @@ static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, uns
 
 // compute_one_level (variational_mt.cpp:169-493) for all batch elements in lockstep.
 // change: nb x 2 floats (host).  Thresholds <= 0 never break, so no host round trip is needed.
-static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const ChannelWeights &cw, SorWorkspace &sorws, float *change) {
+// optimizeOcc (variational_aux_mt.cpp:758-887) for all windows: data costs from the warped pairs, exact two-label cut
+static int optimize_occlusions(sfa_ctx *c, const Level &L, const sfa_params &p, const Geo &g, DevMem &scratch) {
+    const int ref = L.ref;
+    const size_t n = (size_t)L.nb * L.pl;
+    SFA_TRY(scratch.alloc(c, (2 + kCutWorkPlanes) * n * sizeof(float)));
+    float *d0 = scratch.f(), *d1 = d0 + n, *work = d1 + n;
+    OccArgs oa;
+    memset(&oa, 0, sizeof oa);
+    oa.nslots = 2 * ref; oa.hd = p.delta / 3.0f; oa.hg = p.gamma / 3.0f; oa.penalty = p.occlusion_penalty;
+    oa.color = pen(p.robust_color); oa.grad = pen(p.robust_grad);
+    for (int s = 0; s < 2 * ref; s++) {
+        const float *i1 = pair_image(L, s, 0), *i2 = pair_image(L, s, 1);
+        const float *r1 = s < ref ? i1 : L.frame(ref), *r2 = s < ref ? L.frame(ref) : i2;                  // variational_mt.cpp:139-144
+        const int idx = std::max(ref - s - 1, s - ref);
+        oa.slot[s] = OccSlot{i1 - L.base, i2 - L.base, r1 - L.base, r2 - L.base, L.off_masks + (long)s * L.pl, p.rho[idx], p.omega[idx], s >= ref ? 0 : 1};
+    }
+    launch_occ_costs(c, g, oa, L.base, d0, d1, L.pl);
+    return run_grid_cut(c, g, L.plane(P_OCC), L.es, d0, d1, work, p.occlusion_alpha);
+}
+
+static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const ChannelWeights &cw, SorWorkspace &sorws, DevMem &cut_scratch, float *change) {
     const int ref = L.ref;
     const float gamma_over3 = p.gamma / 3.0f, delta_over3 = p.delta / 3.0f;                                   // :548-549
     unsigned long long active = L.nb >= 64 ? ~0ull : ((1ull << L.nb) - 1);
@@ -192,8 +212,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
         active = all;
         g.active = active;
         get_derivatives(c, L, p, active, need_toref);                                                       // :266
-        // alter > 0 with occlusion reasoning: optimizeOcc (GCO graph cut, :269-273) -- third-party, absent;
-        // the occlusion plane keeps its initial value (documented in DESIGN.md)
+        if (alter > 0 && p.occlusion_reasoning && !p.one_direction) SFA_TRY(optimize_occlusions(c, L, p, g, cut_scratch));   // :269-272
         for (int outer = 0; outer < p.niter_outer; outer++) {
             g.active = active;
             if (outer > 0) get_derivatives(c, L, p, active, need_toref);                                    // :289-290
@@ -332,6 +351,7 @@ struct sfa_job {
     DevMem arena;                      // nb * es floats
     DevMem init_flow;                  // nb x 2 planes at level-0 pitch: the uploaded initial flow
     DevMem chw;                        // nb x 3 planes (level-0 pitch) or empty
+    DevMem cut_scratch;                // occlusion step: 2 cost planes + the cut's work planes, [nb][pl] each, grown on demand
     bool has_chw = false;
     int chw_stride0 = 0;
     std::vector<std::unique_ptr<SorWorkspace>> sor;   // one per level: no re-allocation between runs
@@ -412,6 +432,7 @@ void sfa_params_default(sfa_params *p) {           // slow_flow.cpp:64-128
     p->hbit = 1;
     for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
     p->occlusion_reasoning = 1; p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;
+    p->occlusion_penalty = 1.0f; p->occlusion_alpha = 0.5f; p->niter_graphc = 10;     // variational_mt.cpp:182-186
 }
 
 int sfa_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs) {
@@ -549,6 +570,41 @@ int sfa_sub_laplacian(sfa_ctx *ctx, float *dst, const float *src, const float *w
     SFA_TRY(s.up(0, dst, stride)); SFA_TRY(s.up(1, src, stride)); SFA_TRY(s.up(2, wh, stride)); SFA_TRY(s.up(3, wv, stride));
     launch_sub_laplacian(ctx, s.geo(), s.plane(0), s.plane(1), s.plane(2), s.plane(3));
     SFA_TRY(s.down(dst, stride, 0));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_occlusion_costs(sfa_ctx *ctx, const sfa_params *p, float *d0, float *d1, const float *const *masks, const float *const *succ1,
+                        const float *const *succ2, const float *const *ref1, const float *const *ref2, int w, int h, int stride) {
+    CHECK_ARGS(ctx && p && d0 && d1 && masks && succ1 && succ2 && ref1 && ref2 && w > 0 && h >= 4 && stride >= w, "bad arguments");
+    CHECK_ARGS(p->S >= 2 && p->S - 1 <= SFA_MAX_REF, "unsupported slow_flow_S");
+    const int ref = p->S - 1, ns = 2 * ref;
+    Staging s;
+    // planes: 0,1 costs; 2 .. 2+ns masks; then per slot 4 colour images
+    SFA_TRY(s.init(ctx, w, h, 2 + ns + ns * 12));
+    OccArgs oa;
+    memset(&oa, 0, sizeof oa);
+    oa.nslots = ns; oa.hd = p->delta / 3.0f; oa.hg = p->gamma / 3.0f; oa.penalty = p->occlusion_penalty;
+    oa.color = pen(p->robust_color); oa.grad = pen(p->robust_grad);
+    for (int k = 0; k < ns; k++) {
+        const int i0 = 2 + ns + k * 12;
+        SFA_TRY(s.up(2 + k, masks[k], stride));
+        SFA_TRY(s.up(i0, succ1[k], stride, 3)); SFA_TRY(s.up(i0 + 3, succ2[k], stride, 3));
+        SFA_TRY(s.up(i0 + 6, ref1[k], stride, 3)); SFA_TRY(s.up(i0 + 9, ref2[k], stride, 3));
+        const int idx = std::max(ref - k - 1, k - ref);
+        oa.slot[k] = OccSlot{i0 * s.pl, (i0 + 3) * s.pl, (i0 + 6) * s.pl, (i0 + 9) * s.pl, (2 + k) * s.pl, p->rho[idx], p->omega[idx], k >= ref ? 0 : 1};
+    }
+    launch_occ_costs(ctx, s.geo(), oa, s.plane(0), s.plane(0), s.plane(1), 0);
+    SFA_TRY(s.down(d0, stride, 0)); SFA_TRY(s.down(d1, stride, 1));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_grid_cut(sfa_ctx *ctx, float *occ, const float *d0, const float *d1, int w, int h, int stride, float alpha) {
+    CHECK_ARGS(ctx && occ && d0 && d1 && w > 0 && h > 0 && stride >= w && alpha >= 0, "bad arguments");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 3 + kCutWorkPlanes));
+    SFA_TRY(s.up(1, d0, stride)); SFA_TRY(s.up(2, d1, stride));
+    SFA_TRY(run_grid_cut(ctx, s.geo(), s.plane(0), 0, s.plane(1), s.plane(2), s.plane(3), alpha));
+    SFA_TRY(s.down(occ, stride, 0));
     return sfa_ctx_sync(ctx);
 }
 
@@ -855,7 +911,7 @@ int sfa_job_run(sfa_job *j) {
             launch_resize(ctx, Lc.plane(P_WX), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WX), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fx);   // :711,716
             launch_resize(ctx, Lc.plane(P_WY), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WY), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fy);
         }
-        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[l], j->change.data()));                                           // :761
+        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[l], j->cut_scratch, j->change.data()));                                           // :761
     }
     SFA_HIP(ctx, hipGetLastError());
     return SFA_OK;

@@ -139,6 +139,20 @@ void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const floa
 void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ);
 
+// ---- occlusion.hip: optimizeOcc (variational_aux_mt.cpp:758-887) ----------------------------------------------------
+struct OccSlot {
+    long s1_off, s2_off;     // image pair of the slot's successive-frames stack (arena offsets, like Term::i1_off)
+    long r1_off, r2_off;     // image pair of its reference-frame stack (variational_mt.cpp:139-144)
+    long mask_off;           // raw warp mask
+    float rho, omega;        // rho[idx], omega[idx], idx = max(ref-s-1, s-ref)  (:814)
+    int label;               // 0: slot in the future (s >= ref), 1: in the past  (:829-837)
+};
+struct OccArgs { OccSlot slot[2 * SFA_MAX_REF]; int nslots; float hd, hg, penalty; PenaltyDev color, grad; };
+void launch_occ_costs(sfa_ctx *c, const Geo &g, const OccArgs &a, const float *base, float *d0, float *d1, long d_es /* window stride of d0,d1 */);
+constexpr int kCutWorkPlanes = 12;
+// exact two-label cut of sum D_l(p) + alpha * [l_p != l_q] over 4-neighbours; occ = 2*l - 1.  d0, d1, work: planes packed [nb][pl]
+int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float *d0, const float *d1, float *work, float alpha);
+
 // du/dv -> uu,vv, zero padding, L1 change norms (variational_mt.cpp:371-402); red = per-element 2 doubles (sum|old_du-du|, sum|old_dv-dv|)
 void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const float *du, const float *dv,
                          const float *old_du, const float *old_dv, double *red /* [nb][2] */);

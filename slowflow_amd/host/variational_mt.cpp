@@ -52,6 +52,9 @@ sfa_params sfa_params_from_cfg(ParameterList &params, bool one_direction) {
         p.norm_std[k] = (float)params.parameter<double>(std_[k], "1");
     }
     p.occlusion_reasoning = params.parameter<bool>("slow_flow_occlusion_reasoning", "0");
+    p.occlusion_penalty = params.parameter<float>("slow_flow_occlusion_penalty", "1.0");
+    p.occlusion_alpha = params.parameter<float>("slow_flow_occlusion_alpha", "0.5");
+    p.niter_graphc = params.parameter<int>("slow_flow_niter_graphc", "10");
     p.layers = params.parameter<int>("slow_flow_layers");
     p.p_scale = params.parameter<float>("slow_flow_p_scale");
     p.presmooth_sigma = params.parameter<float>("sigma", "0") > 0 ? params.parameter<float>("slow_flow_sigma") : 0.0f;   // :590-591

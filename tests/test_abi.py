@@ -37,7 +37,7 @@ def test_header_symbols_exported(libpath):
 def test_struct_layouts_match_reference_images():
     # image_t: int width,height,stride; float* data (epic_flow_extended/image.h:17-23)
     assert C.sizeof(sfa.Image) == 24 and sfa.Image.data.offset == 16
-    assert C.sizeof(sfa.Params) == C.sizeof(C.c_int) * 8 + 4 * 6 + 12 * 3 + 16 * 2 + 4 + 12 * 2 + 4 * 4
+    assert C.sizeof(sfa.Params) == C.sizeof(C.c_int) * 8 + 4 * 6 + 12 * 3 + 16 * 2 + 4 + 12 * 2 + 4 * 4 + 4 * 3
 
 
 def test_params_default_matches_driver_defaults(libpath):
@@ -46,6 +46,7 @@ def test_params_default_matches_driver_defaults(libpath):
     assert abs(p.sor_omega - 1.9) < 1e-6 and p.alpha == 4.0 and p.gamma == 6.0 and p.delta == 1.0
     assert p.robust_color.id == 1 and abs(p.robust_color.eps - 0.001) < 1e-9
     assert list(p.omega)[:2] == [0.0, 2.0] and p.layers == 1 and abs(p.p_scale - 0.9) < 1e-6
+    assert (p.occlusion_penalty, p.occlusion_alpha, p.niter_graphc) == (1.0, 0.5, 10)       # variational_mt.cpp:182,189-190
 
 
 def test_pyramid_sizes_host_logic(libpath):

@@ -586,3 +586,105 @@ def test_config3_shape_2560x1440_cfg_terms(ctx, oracle, monkeypatch):
         out.append((wx, wy))
     assert np.array_equal(valid(out[0][0], w), valid(out[1][0], w)) and np.array_equal(valid(out[0][1], w), valid(out[1][1], w))
     assert abs(np.median(valid(out[1][0], w)) - 2.0) < 0.2 and abs(np.median(valid(out[1][1], w)) - 1.0) < 0.2
+
+
+# ------------------------------------------------------------------------------------------------------
+# occlusion step between alternations (optimizeOcc, variational_aux_mt.cpp:758-887)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pid", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("S,w,h", [(2, 67, 45), (3, 130, 70)])
+def test_occlusion_costs(ctx, oracle, pid, S, w, h):
+    """data costs from the image pairs (Iz, Ixz, Iyz formed in LDS) == the oracle's costs from materialised stacks"""
+    ref = S - 1
+    rng = np.random.default_rng(pid + 10 * S)
+    eps = 0.001 if pid in (1, 3) else 0.05
+    po, ps = mk_params(oracle, S=S, rho=[1, 0.5][:ref], omega=[0.5, 2][:ref], robust_color=(pid, eps, 0.5), robust_grad=(pid, eps, 0.3))
+    imgs = [[smooth_noise_color(rng, w, h, 10) for _ in range(4)] for _ in range(2 * ref)]     # per slot: succ1, succ2, ref1, ref2
+    masks = [noise_plane(rng, w, h, 0, 1) for _ in range(2 * ref)]
+    for m in masks:
+        m[:, :w] = (m[:, :w] > 0.2).astype(np.float32)
+    masks[0][:3, :w] = 0; masks[-1][:3, :w] = 0                                                # a region where one label has no support at all
+    succ = np.stack([oracle.derivative_stack(a, b, w) for a, b, _, _ in imgs])
+    toref = np.stack([oracle.derivative_stack(c, d, w) for _, _, c, d in imgs])
+    mo = orc.aligned_zeros((2 * ref,) + masks[0].shape); mo[...] = np.stack(masks)
+    so = orc.aligned_zeros(succ.shape); so[...] = succ
+    to = orc.aligned_zeros(toref.shape); to[...] = toref
+    o0, o1 = oracle.occlusion_costs(mo, so, to, ref, list(po.rho)[:ref], list(po.omega)[:ref], po.delta / np.float32(3), po.gamma / np.float32(3),
+                                    po.occlusion_penalty, po.robust_color, po.robust_grad, w)
+    g0, g1 = ctx.occlusion_costs(ps, [c_(m) for m in masks], [c_(i[0]) for i in imgs], [c_(i[1]) for i in imgs], [c_(i[2]) for i in imgs],
+                                 [c_(i[3]) for i in imgs], w)
+    for a, b in ((o0, g0), (o1, g1)):
+        if pid == 2:      # Lorentzian: log in fp64 on both sides, glibc vs ocml -> the float result may differ in the last bit
+            ulp = np.abs(valid(a, w).view(np.int32).astype(np.int64) - valid(b, w).view(np.int32).astype(np.int64))
+            assert ulp.max() <= 1 and (ulp > 0).mean() < 1e-3
+        else:
+            assert np.array_equal(valid(a, w), valid(b, w))
+
+
+def _cut_case(rng, w, h, kind):
+    st = sfa.stride_of(w)
+    d0, d1 = np.zeros((h, st), np.float32), np.zeros((h, st), np.float32)
+    if kind == "noise":
+        d0[:, :w] = rng.uniform(0, 2, (h, w)); d1[:, :w] = rng.uniform(0, 2, (h, w))
+    elif kind == "blobs":       # the typical shape: label 0 preferred everywhere except in a few compact regions
+        d0[:, :w] = rng.uniform(0, 0.2, (h, w)); d1[:, :w] = 1.0 + rng.uniform(0, 0.2, (h, w))
+        for _ in range(6):
+            cx, cy, r = rng.integers(0, w), rng.integers(0, h), rng.integers(2, 9)
+            yy, xx = np.mgrid[0:h, 0:w]
+            d0[:, :w][(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] += rng.uniform(1.0, 4.0)
+    else:                       # "stripes": long thin structures, long residual paths
+        d0[:, :w] = 0.1; d1[:, :w] = 0.6
+        d0[::7, :w] += 3.0; d1[3::7, :w] += 3.0
+        d0[:, :w] += rng.uniform(0, 0.05, (h, w))
+    return d0, d1
+
+
+@pytest.mark.parametrize("kind", ["noise", "blobs", "stripes"])
+@pytest.mark.parametrize("w,h,alpha", [(67, 45, 0.5), (130, 98, 0.5), (64, 64, 2.0), (5, 4, 0.3), (200, 33, 0.05), (33, 70, 0.0)])
+def test_grid_cut_reaches_the_minimum_energy(ctx, oracle, kind, w, h, alpha):
+    """the GPU push-relabel labelling has the energy of the oracle's exact (fp64 Dinic) minimum cut; labels agree
+    except where the minimum is not unique"""
+    rng = np.random.default_rng(w * h + int(alpha * 100))
+    d0, d1 = _cut_case(rng, w, h, kind)
+    a0 = orc.plane(*d0.shape); a0[...] = d0
+    a1 = orc.plane(*d1.shape); a1[...] = d1
+    occ_o, e_o = oracle.grid_cut(a0, a1, alpha, w)
+    occ_g = ctx.grid_cut(c_(d0), c_(d1), alpha, w)
+    assert set(np.unique(valid(occ_g, w))) <= {-1.0, 1.0}
+    og = orc.plane(*d0.shape); og[...] = occ_g
+    e_g = oracle.grid_cut_energy(og, a0, a1, alpha, w)
+    assert abs(e_g - e_o) <= 1e-5 * max(1.0, abs(e_o)), (e_g, e_o)
+    assert (valid(occ_o, w) != valid(occ_g, w)).mean() < 0.01
+    assert np.array_equal(occ_g, ctx.grid_cut(c_(d0), c_(d1), alpha, w))       # deterministic
+
+
+def test_grid_cut_full_size(ctx, oracle):
+    """1024x436: energy against the oracle's exact cut"""
+    w, h = 1024, 436
+    rng = np.random.default_rng(5)
+    d0, d1 = _cut_case(rng, w, h, "blobs")
+    a0 = orc.plane(*d0.shape); a0[...] = d0
+    a1 = orc.plane(*d1.shape); a1[...] = d1
+    _, e_o = oracle.grid_cut(a0, a1, 0.5, w)
+    occ_g = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
+    og = orc.plane(*d0.shape); og[...] = occ_g
+    assert abs(oracle.grid_cut_energy(og, a0, a1, 0.5, w) - e_o) <= 1e-5 * abs(e_o)
+
+
+@pytest.mark.parametrize("S,rho,omega", [(2, [1], [0]), (3, [1, 1], [0, 2])])
+def test_level_with_occlusion_reasoning(ctx, oracle, S, rho, omega):
+    """alternations with the discrete occlusion step (cfgs/slow_flow.cfg: occlusion reasoning on): same labels, same flow"""
+    w, h = 96, 64
+    frames, af, sf = normalized_frames(oracle, w, h, 2 * S - 1, seed=4)
+    po, ps = mk_params(oracle, S=S, rho=rho, omega=omega, norm_avg=af, norm_std=sf, niter_outer=2, niter_alter=3, occlusion_reasoning=1)
+    stride = orc.stride_of(w)
+    wxo, wyo = orc.plane(h, stride), orc.plane(h, stride)
+    wxg, wyg = c_(wxo).copy(), c_(wyo).copy()
+    rc, cho, occ_o = oracle.compute_one_level(po, wxo, wyo, frames, w, None, want_occ=True)
+    chg, occ_g = ctx.compute_one_level(ps, wxg, wyg, [c_(f) for f in frames], w, None, want_occ=True)
+    assert rc == 0
+    assert set(np.unique(valid(occ_g, w))) <= {-1.0, 1.0} and (valid(occ_g, w) > 0).any()    # the cut did label something "future"
+    assert (valid(occ_o, w) != valid(occ_g, w)).mean() < 0.002
+    d = max(np.abs(valid(wxo, w) - valid(wxg, w)).max(), np.abs(valid(wyo, w) - valid(wyg, w)).max())
+    if np.array_equal(valid(occ_o, w), valid(occ_g, w)):
+        assert d <= max(TOL_LEVEL, 3 * oracle_sensitivity(oracle, po, frames, w, h)), d

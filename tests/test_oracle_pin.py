@@ -220,3 +220,30 @@ def test_expf_restatement():
     src = open(os.path.join(os.path.dirname(__file__), "..", "slowflow_amd", "csrc", "kernels.hip")).read()
     for v in T:
         assert ("0x%016xull" % int(v)) in src
+
+
+# ------------------------------------------------------------------------------------------------------
+# occlusion step (optimizeOcc): psi itself is pinned; the energies / cut are restated (parity unpinned, oracle header)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pid,eps,trunc", [(0, .05, .5), (1, .001, .5), (2, .05, .5), (3, .001, .5), (3, .05, .02), (4, .05, .5)])
+def test_psi_apply_pinned(oracle, reflib, pid, eps, trunc):
+    rng = np.random.default_rng(pid)
+    x = np.concatenate([rng.uniform(0, 1e-4, 2000), rng.uniform(0, 2, 2000), rng.uniform(0, 1e4, 2000), [0, 0, 0, 0]]).astype(np.float32)
+    xx, v = reflib.penalty_apply(pid, eps, trunc, x)
+    assert np.array_equal(v, oracle.psi_apply(orc.Penalty(pid, eps, trunc), xx))
+
+
+def test_grid_cut_is_the_exact_minimum(oracle):
+    """the oracle's Dinic cut against exhaustive search on 4x3 grids"""
+    rng = np.random.default_rng(0)
+    w, h = 4, 3
+    st = orc.stride_of(w)
+    for trial in range(40):
+        d0, d1 = orc.plane(h, st), orc.plane(h, st)
+        d0[:, :w] = rng.uniform(0, 2, (h, w)); d1[:, :w] = rng.uniform(0, 2, (h, w))
+        alpha = float(rng.uniform(0, 1))
+        occ, e = oracle.grid_cut(d0, d1, alpha, w)
+        best = min(np.where(lab, d1[:, :w], d0[:, :w]).astype(np.float64).sum() + alpha * ((lab[:, 1:] != lab[:, :-1]).sum() + (lab[1:] != lab[:-1]).sum())
+                   for lab in (np.array([(bits >> i) & 1 for i in range(w * h)]).reshape(h, w) for bits in range(1 << (w * h))))
+        assert abs(best - e) < 1e-6
+        assert abs(oracle.grid_cut_energy(occ, d0, d1, alpha, w) - e) < 1e-12
