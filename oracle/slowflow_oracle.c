@@ -35,7 +35,7 @@ void orc_params_default(orc_params *p) {
     for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
     p->occlusion_reasoning = 1;
     p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;
-    p->occlusion_penalty = 1.0f; p->occlusion_alpha = 0.5f; p->niter_graphc = 10;   /* variational_mt.cpp:182,189-190 */
+    p->occlusion_penalty = 0.1f; p->occlusion_alpha = 0.1f; p->niter_graphc = 10;   /* slow_flow.cpp:117-118 */
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@
  *   solver.c / image.c / variational_aux.c / penalty_functions headers):
  *     orc_sor_coupled, orc_convolve_{horiz,vert} (3/5-tap), orc_image_warp,
  *     orc_sub_laplacian, orc_dpsis_weight (output 0), orc_derivative_stack,
- *     orc_psi_deriv_{scalar,vec};
+ *     orc_psi_deriv_{scalar,vec}, orc_psi_apply_vec;
  *   near-pinned (same operator in the reference's 2-frame variational_aux.c, different
  *   rounding order, <= few ulp): orc_smoothness (method 1), orc_add_data_and_match
  *   (normalised, ModL1);
@@ -25,7 +25,9 @@
  *   variational_mt.cpp need the absent GCO/OpenCV headers and cannot be built here):
  *     orc_add_data_and_match_ref, the unnormalised data-term branches, smoothing
  *     methods 0/2, orc_compute_one_level orchestration, orc_normalize, and the OpenCV
- *     defined pyramid arithmetic (orc_gaussian_blur_cv, orc_resize_linear_cv).
+ *     defined pyramid arithmetic (orc_gaussian_blur_cv, orc_resize_linear_cv), and
+ *     optimizeOcc: orc_occlusion_costs (restated) and orc_grid_cut (GCO v3.0 is not
+ *     vendored; an exact fp64 minimum cut stands in for its two-label expansion).
  */
 #ifndef SLOWFLOW_ORACLE_H
 #define SLOWFLOW_ORACLE_H

@@ -432,7 +432,7 @@ void sfa_params_default(sfa_params *p) {           // slow_flow.cpp:64-128
     p->hbit = 1;
     for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
     p->occlusion_reasoning = 1; p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;
-    p->occlusion_penalty = 1.0f; p->occlusion_alpha = 0.5f; p->niter_graphc = 10;     // variational_mt.cpp:182-186
+    p->occlusion_penalty = 0.1f; p->occlusion_alpha = 0.1f; p->niter_graphc = 10;     // slow_flow.cpp:117-118 (the class itself falls back to 1.0 / 0.5, variational_mt.cpp:189-190)
 }
 
 int sfa_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs) {

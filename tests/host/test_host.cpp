@@ -81,6 +81,7 @@ int main(int argc, char **argv) {
         CHECK(sp.rho[0] == 1.0f && sp.rho[1] == 1.0f && sp.omega[0] == 0.0f && sp.omega[1] == 2.0f);
         CHECK(sp.norm_avg[0] == 0.0f && std::fabs(sp.norm_avg[1] - 127.368f) < 1e-4f && sp.norm_std[0] == 1.0f && std::fabs(sp.norm_std[2] - 0.177831f) < 1e-7f);
         CHECK(sp.hbit == 1 && sp.occlusion_reasoning == 0 && sp.layers == 5 && sp.presmooth_sigma == 0.0f);
+        CHECK(sp.occlusion_penalty == 1.0f && sp.occlusion_alpha == 0.5f && sp.niter_graphc == 10);                        // variational_mt.cpp:182,189-190
         p.insert("slow_flow_method", "forward", true);
         CHECK(sfa_params_from_cfg(p, false).one_direction == 1);
     }

@@ -46,7 +46,7 @@ def test_params_default_matches_driver_defaults(libpath):
     assert abs(p.sor_omega - 1.9) < 1e-6 and p.alpha == 4.0 and p.gamma == 6.0 and p.delta == 1.0
     assert p.robust_color.id == 1 and abs(p.robust_color.eps - 0.001) < 1e-9
     assert list(p.omega)[:2] == [0.0, 2.0] and p.layers == 1 and abs(p.p_scale - 0.9) < 1e-6
-    assert (p.occlusion_penalty, p.occlusion_alpha, p.niter_graphc) == (1.0, 0.5, 10)       # variational_mt.cpp:182,189-190
+    assert abs(p.occlusion_penalty - 0.1) < 1e-7 and abs(p.occlusion_alpha - 0.1) < 1e-7 and p.niter_graphc == 10       # slow_flow.cpp:117-118
 
 
 def test_pyramid_sizes_host_logic(libpath):

@@ -57,8 +57,10 @@ def read_flo(path):
 
 
 @pytest.mark.gpu
-def test_slow_flow_driver_end_to_end(host_build, tmp_path):
-    """cfg + PPM frames -> ./slow_flow -> .flo, against the same windows refined through the Python binding"""
+@pytest.mark.parametrize("alter,occ", [(1, 0), (3, 1)])
+def test_slow_flow_driver_end_to_end(host_build, tmp_path, alter, occ):
+    """cfg + PPM frames -> ./slow_flow -> .flo, against the same windows refined through the Python binding; the second
+    case alternates with the discrete occlusion step, as cfgs/slow_flow.cfg does by default"""
     import slowflow_amd as sfa
     from synth import texture_frame
     w, h, jets, S = 96, 64, 3, 2
@@ -70,8 +72,8 @@ def test_slow_flow_driver_end_to_end(host_build, tmp_path):
     cfg = tmp_path / "run.cfg"
     cfg.write_text(
         "file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\n"
-        "slow_flow_S\t%d\nslow_flow_layers\t2\nslow_flow_niter_alter\t1\nslow_flow_niter_outer\t3\nslow_flow_occlusion_reasoning\t0\n"
-        "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\ngpu_batch\t4\n" % (tmp_path, tmp_path, jets, S))
+        "slow_flow_S\t%d\nslow_flow_layers\t2\nslow_flow_niter_alter\t%d\nslow_flow_niter_outer\t3\nslow_flow_occlusion_reasoning\t%d\n"
+        "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\ngpu_batch\t4\n" % (tmp_path, tmp_path, jets, S, alter, occ))
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Done!" in r.stdout
@@ -87,7 +89,7 @@ def test_slow_flow_driver_end_to_end(host_build, tmp_path):
         fr.append(a)
     avg, std = ctx.normalize(fr, w)
     p = sfa.default_params()
-    p.S = S; p.layers = 2; p.niter_alter = 1; p.niter_outer = 3; p.occlusion_reasoning = 0; p.thres_outer = 0; p.thres_inner = 0
+    p.S = S; p.layers = 2; p.niter_alter = alter; p.niter_outer = 3; p.occlusion_reasoning = occ; p.thres_outer = 0; p.thres_inner = 0
     p.hbit = 0; p.smoothing = 1; p.rho[0] = 1; p.omega[0] = 0
     for k in range(3):
         p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
