@@ -144,6 +144,9 @@ int sfa_add_data_and_match(sfa_ctx *ctx, float *a11, float *a12, float *a22, flo
 /* pyramid arithmetic (cv::GaussianBlur / cv::resize as used at variational_mt.cpp:607,611,672,711) */
 int sfa_gaussian_blur(sfa_ctx *ctx, float *dst, const float *src, int w, int h, int stride, float sigma);
 int sfa_resize_linear(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride);
+/* cv::resize(src, dst, Size(0,0), fx, fy, INTER_LINEAR) as the driver's input rescaling uses it (slow_flow.cpp:552): the caller
+ * passes dw = cvRound(sw*fx), dh = cvRound(sh*fy); source coordinate = (dst + 0.5) / fx - 0.5 */
+int sfa_resize_linear_fx(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double fx, double fy);
 int sfa_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs);
 
 /* ---- device-resident batches (measurement and the multi-pair driver) ------------------------------

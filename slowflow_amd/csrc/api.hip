@@ -661,6 +661,18 @@ int sfa_resize_linear(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, con
     return sfa_ctx_sync(ctx);
 }
 
+int sfa_resize_linear_fx(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double fx, double fy) {
+    CHECK_ARGS(ctx && dst && src && dw > 0 && dh > 0 && sw > 0 && sh > 0 && dstride >= dw && sstride >= sw && fx > 0 && fy > 0, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    DevMem a, b;
+    const int sp = dev_pitch(sw), dp = dev_pitch(dw);
+    SFA_TRY(a.alloc(ctx, (size_t)sp * sh * 4)); SFA_TRY(b.alloc(ctx, (size_t)dp * dh * 4));
+    SFA_TRY(upload_plane(ctx, a.f(), sp, src, sstride, sw, sh));
+    launch_resize_scaled(ctx, b.f(), dw, dh, dp, (long)dp * dh, 0, a.f(), sw, sh, sp, (long)sp * sh, 0, 1, 1, 1.0f, 1.0 / fx, 1.0 / fy);
+    SFA_TRY(download_plane(ctx, dst, dstride, b.f(), dp, dw, dh));
+    return sfa_ctx_sync(ctx);
+}
+
 // ---- SOR ----------------------------------------------------------------------------------------------------
 struct sfa_sor_batch {
     sfa_ctx *ctx = nullptr;

@@ -1083,11 +1083,15 @@ __global__ void k_resize(float *__restrict__ dst, int dw, int dh, int dpitch, lo
     if (post_scale != 1.0f) v *= post_scale;                                             // image_mul_scalar after the flow resize (:679-680,716-717)
     dst[b * des + pl * dpl + (size_t)dy * dpitch + dx] = v;
 }
+void launch_resize_scaled(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl,
+                          long ses, int nplanes, int nb, float post_scale, double scale_x, double scale_y) {
+    dim3 grid((dw + BX - 1) / BX, (dh + BY - 1) / BY, nb * nplanes);
+    hipLaunchKernelGGL(k_resize, grid, block2d(), 0, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes, scale_x, scale_y, post_scale);
+}
 void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
                    int nplanes, int nb, float post_scale) {
-    dim3 grid((dw + BX - 1) / BX, (dh + BY - 1) / BY, nb * nplanes);
-    hipLaunchKernelGGL(k_resize, grid, block2d(), 0, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes,
-                       (double)sw / dw, (double)sh / dh, post_scale);
+    // cv::resize with an explicit dsize: scale = ssize / dsize (imgproc resize.cpp: inv_scale_x = dsize.width / ssize.width)
+    launch_resize_scaled(c, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes, nb, post_scale, (double)sw / dw, (double)sh / dh);
 }
 
 // optional level-0 Gaussian presmoothing (cfg sigma > 0, variational_mt.cpp:590-597): gaussian_filter

@@ -3,8 +3,8 @@
 // :1027-1030, resume :794,958, config.cfg :684-688) for the path this repository implements:
 //   frames -> normalize -> per jet: forward / backward Variational_MT::variational -> flow * steps -> .flo
 // The jets of a sequence are independent; they are sharded over the node's GPUs (one host thread per GPU) and each
-// GPU refines `gpu_batch` frame windows in lockstep.  Out of scope here (and rejected with a message): Bayer raw
-// demosaicing, input rescaling (scale != 1), DeepMatching/EpicFlow initialisation, adaptive frame rates -- they
+// GPU refines `gpu_batch` frame windows in lockstep.  Out of scope here (and rejected with a message): the third-party
+// demosaicers (raw_demosaicing 1, 2), DeepMatching/EpicFlow initialisation, adaptive frame rates -- they
 // live in third-party code (OpenCV, MATLAB SED, DeepMatching) outside the path.
 //
 // New, additive keys: gpus (default: all visible), gpu_batch (default 8), gpu_device (first device, default 0).
@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "image.h"
+#include "ingest.h"
 #include "io.h"
 #include "parameter_list.h"
 #include "variational_mt.h"
@@ -88,8 +89,14 @@ int main(int argc, char **argv) {
         else { fprintf(stderr, "unknown argument %s", a); usage(); }
     }
     if (params.parameter<bool>("deep_matching")) { std::cerr << "deep_matching=1 needs the external DeepMatching/SED/EpicFlow stage: not part of this build (set deep_matching 0)" << std::endl; return 2; }
-    if (params.exists("raw") && params.parameter<bool>("raw")) { std::cerr << "raw=1 (Bayer demosaicing) is outside the path: provide demosaiced frames and set raw 0" << std::endl; return 2; }
-    if (params.parameter<float>("scale", "1.0") != 1.0f) { std::cerr << "scale != 1 (OpenCV blur+resize at load) is outside the path: provide frames at working resolution" << std::endl; return 2; }
+    const bool raw = params.exists("raw") && params.parameter<bool>("raw");
+    if (raw && params.parameter<int>("raw_demosaicing", "0") != 0) {
+        std::cerr << "raw_demosaicing 1 (Hamilton-Adams, P. Getreuer) and 2 (OpenCV) are third-party code absent from the reference tree: use raw_demosaicing 0 "
+                     "(the reference's own bilinear / green-ratio routine) or provide demosaiced frames with raw 0" << std::endl;
+        return 2;
+    }
+    const std::vector<int> red_loc = params.splitParameter<int>("raw_red_loc", "0,0");   // :439
+    const float scale = params.parameter<float>("scale", "1.0");
 
     const int steps = params.parameter<int>("slow_flow_S") - 1, ref = steps;         // :208-209
     const int max_fps = params.parameter<int>("max_fps", "1");
@@ -127,6 +134,7 @@ int main(int argc, char **argv) {
 
     // ---- read the image sequence (:447-592, without OpenCV: binary PPM / PGM / PFM) ------------------------------
     std::vector<color_image_t *> seq(frames, nullptr), seq_back(frames, nullptr);
+    sfa_ctx *ingest_ctx = nullptr;
     for (unsigned f = start_f; f < end_f; f++) {
         string img_file;
         if (!sintel) img_file = fmt1(sequence_path + format, (int)start - ref * skip + (int)f * skip);
@@ -140,11 +148,36 @@ int main(int argc, char **argv) {
         int maxval = 255;
         seq[f] = color_image_load(img_file.c_str(), &maxval);
         if (!seq[f]) { std::cerr << "cannot read frame " << img_file << " (binary PPM/PGM/PFM expected)" << std::endl; return 3; }
+        if (raw) {                                                                   // demosaicing (:482-527): the mosaic is the grey image
+            image_t mosaic = {seq[f]->width, seq[f]->height, seq[f]->stride, seq[f]->c1};
+            color_image_t *rgb = color_image_new(seq[f]->width, seq[f]->height);
+            color_image_erase(rgb);
+            bayer2rgbGR(&mosaic, rgb, red_loc.size() > 0 ? red_loc[0] : 0, red_loc.size() > 1 ? red_loc[1] : 0);
+            color_image_delete(seq[f]);
+            seq[f] = rgb;
+        }
+        if (!params.exists("raw") || params.parameter<float>("raw_weight", "1.0") == 1.0f) {   // :531
+            if (params.extent.x > 0 || params.extent.y > 0) {                        // use only a part of the images (:533-536)
+                color_image_t *part = color_image_crop(seq[f], params.center.x, params.center.y, params.extent.x, params.extent.y);
+                if (!part) { std::cerr << "center / extent do not fit the " << seq[f]->width << "x" << seq[f]->height << " frames" << std::endl; return 3; }
+                color_image_delete(seq[f]);
+                seq[f] = part;
+            }
+            if (scale != 1) {                                                        // blur + resize against aliasing (:550-553), on the GPU
+                if (!ingest_ctx && sfa_ctx_create(params.parameter<int>("gpu_device", "0"), &ingest_ctx) != SFA_OK) { std::cerr << sfa_last_error(nullptr) << std::endl; return 4; }
+                color_image_t *small = color_image_rescale(ingest_ctx, seq[f], scale);
+                if (!small) { std::cerr << "rescaling failed: " << sfa_last_error(ingest_ctx) << std::endl; return 4; }
+                color_image_delete(seq[f]);
+                seq[f] = small;
+            }
+        }
         seq_back[frames - 1 - f] = seq[f];                                           // :590-591
     }
     const int width = seq[start_f]->width, height = seq[start_f]->height;
     color_image_t *channel_weights = color_image_new(width, height);                 // :597-598 (all ones without raw weighting)
     for (size_t i = 0; i < (size_t)3 * channel_weights->stride * height; i++) channel_weights->c1[i] = 1.0f;
+    if (raw) rawWeighting(channel_weights, red_loc.size() > 0 ? red_loc[0] : 0, red_loc.size() > 1 ? red_loc[1] : 0, params.parameter<float>("raw_weight", "1.0"));   // :599-600
+    if (ingest_ctx) { sfa_ctx_destroy(ingest_ctx); ingest_ctx = nullptr; }
 
     normalize(&seq[start_f], end_f - start_f, params);                               // :673
     {

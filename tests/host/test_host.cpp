@@ -8,6 +8,7 @@
 #include <string>
 
 #include "image.h"
+#include "ingest.h"
 #include "io.h"
 #include "parameter_list.h"
 #include "variational_mt.h"
@@ -122,6 +123,50 @@ int main(int argc, char **argv) {
             normalize(seq, 1, p);
         } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("no HIP device") != std::string::npos; }
         CHECK(threw);
+    }
+    // ---- ingest: raw weighting, Bayer demosaicing, crop (utils.cpp:1241-1374, slow_flow.cpp:533-536) ----------------------
+    {
+        const int w = 10, h = 7;
+        for (int red_y = 0; red_y < 2; red_y++)
+            for (int red_x = 0; red_x < 2; red_x++) {
+                color_image_t *cw = color_image_new(w, h);
+                rawWeighting(cw, red_x, red_y, 2.0f);
+                // a mosaic sampled from a constant colour (R,G,B) = (40, 100, 20): the measured channel of every pixel carries the
+                // weight, the two others (3 - weight) / 2; the demosaiced image is that colour again
+                image_t *mosaic = image_new(w, h);
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) {
+                        const size_t o = (size_t)y * cw->stride + x;
+                        const float r = cw->c1[o], g = cw->c2[o], b = cw->c3[o];
+                        CHECK(std::fabs(r + g + b - 3.0f) < 1e-6f);
+                        CHECK((r == 2.0f) + (g == 2.0f) + (b == 2.0f) == 1);
+                        const bool is_red = (x % 2 == red_x) && (y % 2 == red_y), is_blue = (x % 2 != red_x) && (y % 2 != red_y);
+                        // (for red_y == 1 the reference's weighting swaps green and blue/red columns relative to its own demosaicer,
+                        //  utils.cpp:1345-1346,1360-1361: restated as written, checked against the Bayer layout for red_y == 0 only)
+                        if (red_y == 0) CHECK(is_red ? r == 2.0f : is_blue ? b == 2.0f : g == 2.0f);
+                        mosaic->data[(size_t)y * mosaic->stride + x] = is_red ? 40.0f : is_blue ? 20.0f : 100.0f;
+                    }
+                color_image_t *rgb = color_image_new(w, h);
+                bayer2rgbGR(mosaic, rgb, red_x, red_y);
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) {
+                        const size_t o = (size_t)y * rgb->stride + x;
+                        CHECK(std::fabs(rgb->c1[o] - 40.0f) < 1e-4f && std::fabs(rgb->c2[o] - 100.0f) < 1e-4f && std::fabs(rgb->c3[o] - 20.0f) < 1e-4f);
+                    }
+                image_delete(mosaic); color_image_delete(rgb); color_image_delete(cw);
+            }
+        color_image_t *cw = color_image_new(4, 4);
+        rawWeighting(cw, 0, 0, 7.0f);                                  // clamped to [0, 3]
+        CHECK(cw->c1[0] == 3.0f && cw->c2[0] == 0.0f && cw->c3[0] == 0.0f);
+        color_image_delete(cw);
+        color_image_t *img = color_image_new(20, 12);
+        for (int y = 0; y < 12; y++)
+            for (int x = 0; x < 20; x++) { img->c1[y * img->stride + x] = (float)(100 * y + x); img->c2[y * img->stride + x] = 1; img->c3[y * img->stride + x] = 2; }
+        color_image_t *part = color_image_crop(img, 10, 6, 8, 4);     // rows 4..7, columns 6..13
+        CHECK(part && part->width == 8 && part->height == 4 && part->c1[0] == 406.0f && part->c1[3 * part->stride + 7] == 713.0f && part->c3[5] == 2.0f);
+        CHECK(color_image_crop(img, 2, 2, 8, 4) == nullptr);          // does not fit
+        if (part) color_image_delete(part);
+        color_image_delete(img);
     }
     printf(fails ? "host tests FAILED (%d)\n" : "host tests OK\n", fails);
     return fails ? 1 : 0;

@@ -109,3 +109,75 @@ def test_slow_flow_driver_end_to_end(host_build, tmp_path, alter, occ):
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-resume"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.count("already exist") == 2 * jets
     ctx.close()
+
+
+def write_pgm(path, img):           # img: (h,w) float 0..255
+    h, w = img.shape
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (w, h))
+        f.write(np.clip(np.round(img), 0, 255).astype(np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+def test_driver_ingest_scale_and_raw(host_build, tmp_path):
+    """rank-2 ingest through the driver: (a) scale 0.5 = GaussianBlur(1/sqrt(2*scale)) + resize(fx) on load, against the same
+    operators applied through the binding; (b) raw 1 with the reference's own bilinear demosaicer and raw weighting runs and
+    recovers the motion of a colour-constant textured mosaic"""
+    import slowflow_amd as sfa
+    from synth import texture_frame
+    w, h, jets, S = 128, 96, 1, 2
+    steps = S - 1
+    nframes = 1 + (jets + 2) * steps
+    frames = [np.clip(np.round(texture_frame(w, h, k)[:, :, :w]), 0, 255) for k in range(nframes)]
+    for k, f in enumerate(frames):
+        write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), f)
+    common = ("Jets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\ndeep_matching\t0\nslow_flow_S\t%d\nslow_flow_layers\t2\nslow_flow_niter_alter\t1\n"
+              "slow_flow_niter_outer\t3\nslow_flow_occlusion_reasoning\t0\nslow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\n"
+              "slow_flow_omega_0\t0\ngpus\t1\ngpu_batch\t4\n" % (jets, S))
+    # (a) scale
+    cfg = tmp_path / "scale.cfg"
+    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out_scale\nraw\t0\nscale\t0.5\n" % (tmp_path, tmp_path) + common)
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ctx = sfa.Context(0)
+    sw, sh = w // 2, h // 2
+    stride = sfa.stride_of(sw)
+    sigma = np.float32(1 / np.sqrt(2 * 0.5))
+    fr = []
+    for f in frames:
+        a = np.zeros((3, sh, stride), np.float32)
+        for c in range(3):
+            src = np.zeros((h, sfa.stride_of(w)), np.float32)
+            src[:, :w] = f[c]
+            small, dw = ctx.resize_linear_fx(ctx.gaussian_blur(src, w, float(sigma)), w, 0.5, 0.5)
+            assert dw == sw and small.shape == (sh, stride)
+            a[c] = small
+        fr.append(a)
+    avg, std = ctx.normalize(fr, sw)
+    p = sfa.default_params()
+    p.S = S; p.layers = 2; p.niter_alter = 1; p.niter_outer = 3; p.occlusion_reasoning = 0; p.thres_outer = 0; p.thres_inner = 0
+    p.hbit = 0; p.smoothing = 1; p.rho[0] = 1; p.omega[0] = 0
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    wx, wy = np.zeros((sh, stride), np.float32), np.zeros((sh, stride), np.float32)
+    ctx.variational(p, wx, wy, fr[0:3], sw)
+    u, v = read_flo(str(tmp_path / "out_scale" / "f_010.flo"))
+    assert u.shape == (sh, sw)
+    assert np.array_equal(u, wx[:, :sw] * steps) and np.array_equal(v, wy[:, :sw] * steps)
+    assert abs(np.median(u) - 0.75) < 0.1 and abs(np.median(v) + 0.375) < 0.1          # half the resolution, half the motion
+    ctx.close()
+    # (b) raw: grey mosaics of the same frames (all three channels of texture_frame are sampled by the pattern)
+    for k, f in enumerate(frames):
+        yy, xx = np.mgrid[0:h, 0:w]
+        red = (xx % 2 == 1) & (yy % 2 == 0)
+        blue = (xx % 2 == 0) & (yy % 2 == 1)
+        write_pgm(str(tmp_path / ("m_%03d.pgm" % (10 - steps + k))), np.where(red, f[0], np.where(blue, f[2], f[1])))
+    cfg = tmp_path / "raw.cfg"
+    cfg.write_text("file\t%s/m_%%03i.pgm\noutput\t%s/out_raw\nraw\t1\nraw_demosaicing\t0\nraw_red_loc\t1,0\nraw_weight\t2\nscale\t1.0\n" % (tmp_path, tmp_path) + common)
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    u, v = read_flo(str(tmp_path / "out_raw" / "m_010.flo"))
+    assert abs(np.median(u) - 1.5) < 0.15 and abs(np.median(v) + 0.75) < 0.15
+    cfg.write_text("file\t%s/m_%%03i.pgm\noutput\t%s/out_raw2\nraw\t1\nraw_demosaicing\t1\n" % (tmp_path, tmp_path) + common)
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "raw_demosaicing" in r.stderr
