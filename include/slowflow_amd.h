@@ -66,6 +66,13 @@ typedef struct sfa_params {
     int   niter_graphc;         /* slow_flow_niter_graphc ("10"): expansion iterations; a two-label cut is exact after one */
 } sfa_params;
 
+/* variational_params_t (epic_flow_extended/variational.h:16-25), same layout */
+typedef struct sfa_params_2frame {
+    float alpha, gamma, delta, sigma;
+    int niter_outer, niter_inner, niter_solver;
+    float sor_omega;
+} sfa_params_2frame;
+
 typedef struct sfa_ctx sfa_ctx;
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -86,6 +93,15 @@ void sfa_params_default(sfa_params *p);             /* driver defaults, slow_flo
 int sfa_variational(sfa_ctx *ctx, const sfa_params *p, float *wx, float *wy, int w, int h, int stride,
                     const float *const *frames, int n_frames, const float *const chw[3],
                     float *occlusions_out, float change[2]);
+
+/* The reference's ORIGINAL two-frame refinement, `variational(wx, wy, im1, im2, params)` (epic_flow_extended/variational.c:101-143
+ * with variational_aux.c): one level, fixed modified-L1 penalties, weights halved; wx, wy refined in place.  im1, im2: first
+ * plane of 3.  Pinned end to end, bit for bit, against the compiled reference.  p == NULL: variational_params_default. */
+int sfa_variational_2frame(sfa_ctx *ctx, float *wx, float *wy, int w, int h, int stride, const float *im1, const float *im2, const sfa_params_2frame *p);
+void sfa_params_2frame_default(sfa_params_2frame *p);          /* variational.c:86-98 */
+/* The reference's own symbol and signature (variational.h:34), for relinking callers such as adaptiveFR / EpicFlow's refinement
+ * step: runs on device 0 with a process-wide context; aborts with a message on error like the reference does. */
+void variational(sfa_image *wx, sfa_image *wy, const sfa_color_image *im1, const sfa_color_image *im2, sfa_params_2frame *params);
 
 /* Replaces Variational_MT::compute_one_level (variational_mt.cpp:169-493): one pyramid level. */
 int sfa_compute_one_level(sfa_ctx *ctx, const sfa_params *p, float *wx, float *wy, int w, int h, int stride,

@@ -112,6 +112,10 @@ class Oracle:
                                      C.c_float(penalty), C.byref(color), C.byref(grad), w, h, stride)
         return d0, d1
 
+    def variational_2frame(self, wx, wy, im1, im2, w, p):
+        h, stride = wx.shape
+        self.lib.orc_variational_2frame(fptr(wx), fptr(wy), fptr(im1), fptr(im2), C.byref(p), w, h, stride)
+
     def grid_cut(self, d0, d1, alpha, w):
         h, stride = d0.shape
         occ = plane(h, stride)
@@ -266,6 +270,17 @@ def ref_available():
     return os.path.exists(REF_SO)
 
 
+class Params2f(C.Structure):
+    """variational_params_t (variational.h:16-25) == orc_params_2f == sfa_params_2frame"""
+    _fields_ = [("alpha", C.c_float), ("gamma", C.c_float), ("delta", C.c_float), ("sigma", C.c_float),
+                ("niter_outer", C.c_int), ("niter_inner", C.c_int), ("niter_solver", C.c_int), ("sor_omega", C.c_float)]
+
+
+def params_2f(alpha=1.0, gamma=0.71, delta=0.0, sigma=1.0, niter_outer=5, niter_inner=1, niter_solver=30, sor_omega=1.9):
+    """defaults of variational_params_default (variational.c:86-98)"""
+    return Params2f(alpha, gamma, delta, sigma, niter_outer, niter_inner, niter_solver, sor_omega)
+
+
 class RefLib:
     """The reference's own compiled C (solver.c, image.c, variational_aux.c, penalty headers)."""
 
@@ -290,6 +305,12 @@ class RefLib:
         d_i, s_i = as_image(dst, w), as_image(s2, w)
         fn(C.byref(d_i), C.byref(s_i), conv)
         return dst
+
+    def variational_2frame(self, wx, wy, im1, im2, w, p):
+        """the reference's own two-frame `variational` (variational.c:101), in place on wx, wy"""
+        a, b = as_image(wx, w), as_image(wy, w)
+        i1, i2 = as_color(im1, w), as_color(im2, w)
+        self.lib.variational(C.byref(a), C.byref(b), C.byref(i1), C.byref(i2), C.byref(p))
 
     def sor(self, du, dv, a11, a12, a22, b1, b2, sh, sv, w, iterations, omega, readable=False):
         imgs = [as_image(a, w) for a in (du, dv, a11, a12, a22, b1, b2, sh, sv)]

@@ -1277,3 +1277,116 @@ int orc_variational(const orc_params *p, float *wx, float *wy, float *const *fra
     free(pyr); free(ones);
     return rc;
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * variational.c:19-143 + variational_aux.c -- the original two-frame refinement
+ * ---------------------------------------------------------------------------------------- */
+#define EPS2F (0.001f * 0.001f)          /* epsilon_color / _grad / _smooth, variational_aux.c:11-13 */
+
+static void smoothness_2f(float *sh, float *sv, const float *uu, const float *vv, const float *dps, int w, int h, int s, float half_alpha) {
+    const size_t plane = (size_t)s * h;
+    float *ux2 = plane_alloc(plane), *uy2 = plane_alloc(plane), *vx2 = plane_alloc(plane), *vy2 = plane_alloc(plane);
+    orc_convolve_horiz(ux2, uu, w, h, s, 1); orc_convolve_horiz(vx2, vv, w, h, s, 1);          /* variational_aux.c:110-113 */
+    orc_convolve_vert(uy2, uu, w, h, s, 1);  orc_convolve_vert(vy2, vv, w, h, s, 1);
+    memset(sh, 0, plane * sizeof(float)); memset(sv, 0, plane * sizeof(float));
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w - 1; i++) {                                                      /* :115-128 */
+            const size_t o = (size_t)j * s + i;
+            const float ux1 = uu[o + 1] - uu[o], vx1 = vv[o + 1] - vv[o];
+            float tmp = 0.5f * (uy2[o] + uy2[o + 1]);
+            const float uxsq = ux1 * ux1 + tmp * tmp;
+            tmp = 0.5f * (vy2[o] + vy2[o + 1]);
+            const float vxsq = vx1 * vx1 + tmp * tmp;
+            tmp = uxsq + vxsq;
+            sh[o] = (float)((dps[o] + dps[o + 1]) * half_alpha / sqrt(tmp + EPS2F));            /* double sqrt and division, :126 */
+        }
+    for (int j = 0; j < h - 1; j++)
+        for (int i = 0; i < w; i++) {                                                          /* :130-146 */
+            const size_t o = (size_t)j * s + i;
+            const float uy1 = uu[o + s] - uu[o], vy1 = vv[o + s] - vv[o];
+            float tmp = 0.5f * (ux2[o] + ux2[o + s]);
+            const float uysq = uy1 * uy1 + tmp * tmp;
+            tmp = 0.5f * (vx2[o] + vx2[o + s]);
+            const float vysq = vy1 * vy1 + tmp * tmp;
+            tmp = uysq + vysq;
+            sv[o] = (float)((dps[o] + dps[o + s]) * half_alpha / sqrt(tmp + EPS2F));
+        }
+    free(ux2); free(uy2); free(vx2); free(vy2);
+}
+
+static void data_2f(float *a11, float *a12, float *a22, float *b1, float *b2, const float *mask, const float *du, const float *dv, const float *D,
+                    int w, int h, int s, float hd, float hg) {
+    const size_t plane = (size_t)s * h, cimg = 3 * plane;
+    const float dn = 0.1f * 0.1f;                                                               /* datanorm, :10 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t o = (size_t)y * s + x;
+            float ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
+            for (int k = 0; k < 3; k++) {
+                ix[k] = D[D_IX * cimg + k * plane + o]; iy[k] = D[D_IY * cimg + k * plane + o]; iz[k] = D[D_IZ * cimg + k * plane + o];
+                ixx[k] = D[D_IXX * cimg + k * plane + o]; ixy[k] = D[D_IXY * cimg + k * plane + o]; iyy[k] = D[D_IYY * cimg + k * plane + o];
+                ixz[k] = D[D_IXZ * cimg + k * plane + o]; iyz[k] = D[D_IYZ * cimg + k * plane + o];
+            }
+            const float u = du[o], v = dv[o], m = mask[o];
+            float A11 = 0, A12 = 0, A22 = 0, B1 = 0, B2 = 0;
+            if (hd) {                                                                           /* :245-269 */
+                float t[3], n[3];
+                for (int k = 0; k < 3; k++) { t[k] = iz[k] + ix[k] * u + iy[k] * v; n[k] = ix[k] * ix[k] + iy[k] * iy[k] + dn; }
+                const float q = m * hd / sqrtf(t[0] * t[0] / n[0] + t[1] * t[1] / n[1] + t[2] * t[2] / n[2] + EPS2F);
+                for (int k = 0; k < 3; k++) {
+                    const float tk = q / n[k];
+                    A11 += tk * ix[k] * ix[k]; A12 += tk * ix[k] * iy[k]; A22 += tk * iy[k] * iy[k];
+                    B1 -= tk * iz[k] * ix[k];  B2 -= tk * iz[k] * iy[k];
+                }
+            }
+            float t[6], n[6];                                                                   /* :271-300 */
+            for (int k = 0; k < 3; k++) {
+                n[2 * k] = ixx[k] * ixx[k] + ixy[k] * ixy[k] + dn;
+                n[2 * k + 1] = iyy[k] * iyy[k] + ixy[k] * ixy[k] + dn;
+                t[2 * k] = ixz[k] + ixx[k] * u + ixy[k] * v;
+                t[2 * k + 1] = iyz[k] + ixy[k] * u + iyy[k] * v;
+            }
+            const float q = m * hg / sqrtf(t[0] * t[0] / n[0] + t[1] * t[1] / n[1] + t[2] * t[2] / n[2] + t[3] * t[3] / n[3] + t[4] * t[4] / n[4] +
+                                           t[5] * t[5] / n[5] + EPS2F);
+            for (int k = 0; k < 3; k++) {
+                const float ta = q / n[2 * k], tb = q / n[2 * k + 1];
+                A11 += ta * ixx[k] * ixx[k] + tb * ixy[k] * ixy[k];
+                A12 += ta * ixx[k] * ixy[k] + tb * ixy[k] * iyy[k];
+                A22 += tb * iyy[k] * iyy[k] + ta * ixy[k] * ixy[k];
+                B1 -= ta * ixx[k] * ixz[k] + tb * ixy[k] * iyz[k];
+                B2 -= tb * iyy[k] * iyz[k] + ta * ixy[k] * ixz[k];
+            }
+            a11[o] = A11; a12[o] = A12; a22[o] = A22; b1[o] = B1; b2[o] = B2;
+        }
+}
+
+void orc_variational_2frame(float *wx, float *wy, const float *im1, const float *im2, const orc_params_2f *p, int w, int h, int stride) {
+    const size_t plane = (size_t)stride * h, cimg = 3 * plane;
+    const float half_alpha = 0.5f * p->alpha, hg = p->gamma * 0.5f / 3.0f, hd = p->delta * 0.5f / 3.0f;     /* variational.c:113-115 */
+    float *du = plane_alloc(plane), *dv = plane_alloc(plane), *mask = plane_alloc(plane), *sh = plane_alloc(plane), *sv = plane_alloc(plane);
+    float *uu = plane_alloc(plane), *vv = plane_alloc(plane), *a11 = plane_alloc(plane), *a12 = plane_alloc(plane), *a22 = plane_alloc(plane);
+    float *b1 = plane_alloc(plane), *b2 = plane_alloc(plane), *dps = plane_alloc(plane), *w_im2 = plane_alloc(cimg), *D = plane_alloc(8 * cimg);
+    const float zero3[3] = {0, 0, 0}, one3[3] = {1, 1, 1};
+    orc_dpsis_weight(dps, im1, w, h, stride, 5.0f, zero3, one3, 0);                                             /* :35 */
+    for (int outer = 0; outer < p->niter_outer; outer++) {
+        orc_image_warp(w_im2, mask, im2, wx, wy, w, h, stride, 1);                                              /* :41 */
+        orc_derivative_stack(D, w_im2, im1, w, h, stride);                                                      /* :43: mean = (im2+im1)/2, dt = im2-im1 */
+        memset(du, 0, plane * sizeof(float)); memset(dv, 0, plane * sizeof(float));
+        memcpy(uu, wx, plane * sizeof(float)); memcpy(vv, wy, plane * sizeof(float));
+        for (int inner = 0; inner < p->niter_inner; inner++) {
+            smoothness_2f(sh, sv, uu, vv, dps, w, h, stride, half_alpha);                                       /* :54 */
+            data_2f(a11, a12, a22, b1, b2, mask, du, dv, D, w, h, stride, hd, hg);                              /* :55 */
+            orc_sub_laplacian(b1, wx, sh, sv, w, h, stride);                                                    /* :56-57 (wx, not uu) */
+            orc_sub_laplacian(b2, wy, sh, sv, w, h, stride);
+            orc_sor_coupled(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, stride, p->niter_solver, p->sor_omega);   /* :59 */
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    const size_t o = (size_t)y * stride + x;
+                    uu[o] = wx[o] + du[o]; vv[o] = wy[o] + dv[o];                                               /* :64-65 */
+                }
+        }
+        memcpy(wx, uu, plane * sizeof(float)); memcpy(wy, vv, plane * sizeof(float));                           /* :70-71 */
+    }
+    free(du); free(dv); free(mask); free(sh); free(sv); free(uu); free(vv); free(a11); free(a12); free(a22); free(b1); free(b2); free(dps); free(w_im2); free(D);
+}

@@ -17,7 +17,8 @@
  *   solver.c / image.c / variational_aux.c / penalty_functions headers):
  *     orc_sor_coupled, orc_convolve_{horiz,vert} (3/5-tap), orc_image_warp,
  *     orc_sub_laplacian, orc_dpsis_weight (output 0), orc_derivative_stack,
- *     orc_psi_deriv_{scalar,vec}, orc_psi_apply_vec;
+ *     orc_psi_deriv_{scalar,vec}, orc_psi_apply_vec, and -- end to end -- orc_variational_2frame
+ *     (the reference's original two-frame variational(), variational.c:101);
  *   near-pinned (same operator in the reference's 2-frame variational_aux.c, different
  *   rounding order, <= few ulp): orc_smoothness (method 1), orc_add_data_and_match
  *   (normalised, ModL1);
@@ -154,6 +155,18 @@ int  orc_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs
  * weight planes are NOT rescaled per level) */
 int orc_variational(const orc_params *p, float *wx, float *wy, float *const *frames, const float *const chw[3],
                     int w, int h, int stride, float change[2]);
+
+/* ------------------------------------------------------------------------------------------
+ * The reference's original two-frame refinement (epic_flow_extended/variational.c:101-143 with variational_aux.c): one
+ * level, fixed modified-L1 penalties (eps 0.001), weights halved.  The reference file compiles here as is, so this
+ * restatement is pinned END TO END, bit for bit, against the real `variational()` (tests/test_oracle_pin.py).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {   /* variational_params_t, variational.h:16-25 */
+    float alpha, gamma, delta, sigma;
+    int niter_outer, niter_inner, niter_solver;
+    float sor_omega;
+} orc_params_2f;
+void orc_variational_2frame(float *wx, float *wy, const float *im1, const float *im2, const orc_params_2f *p, int w, int h, int stride);
 
 #ifdef __cplusplus
 }

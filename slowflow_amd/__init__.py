@@ -55,9 +55,15 @@ class Image(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("stride", C.c_int), ("data", _f)]
 
 
+class Params2f(C.Structure):
+    """sfa_params_2frame == variational_params_t (variational.h:16-25)"""
+    _fields_ = [("alpha", C.c_float), ("gamma", C.c_float), ("delta", C.c_float), ("sigma", C.c_float),
+                ("niter_outer", C.c_int), ("niter_inner", C.c_int), ("niter_solver", C.c_int), ("sor_omega", C.c_float)]
+
+
 EXPORTS = [
     "sfa_device_count", "sfa_ctx_create", "sfa_ctx_destroy", "sfa_last_error", "sfa_ctx_sync", "sfa_params_default",
-    "sfa_variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sor_coupled",
+    "sfa_variational", "sfa_variational_2frame", "sfa_params_2frame_default", "variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sor_coupled",
     "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
     "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_resize_linear_fx", "sfa_pyramid_sizes",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_mpix_iters",
@@ -242,6 +248,12 @@ class Context:
         rc = fn(self.h, C.byref(p), fptr(wx), fptr(wy), w, h, stride, arr, F, cw, fptr(occ) if want_occ else None, change)
         self._ck(rc, name)
         return (change[0], change[1]), occ
+
+    def variational_2frame(self, wx, wy, im1, im2, w, p=None):
+        """the reference's original two-frame `variational` (variational.c:101), in place on wx, wy"""
+        h, stride = wx.shape
+        self._ck(lib().sfa_variational_2frame(self.h, fptr(wx), fptr(wy), w, h, stride, fptr(im1), fptr(im2), C.byref(p) if p is not None else None),
+                 "sfa_variational_2frame")
 
     def compute_one_level(self, p, wx, wy, frames, w, chw=None, want_occ=False):
         return self._run(lib().sfa_compute_one_level, "sfa_compute_one_level", p, wx, wy, frames, w, chw, want_occ)

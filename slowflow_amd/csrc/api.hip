@@ -769,6 +769,66 @@ void sor_coupled(sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, s
     }
 }
 
+// ---- the original two-frame refinement (variational.c:19-143) --------------------------------------------------
+void sfa_params_2frame_default(sfa_params_2frame *p) {                                   // variational.c:86-98
+    if (!p) return;
+    p->alpha = 1.0f; p->gamma = 0.71f; p->delta = 0.0f; p->sigma = 1.00f;
+    p->niter_outer = 5; p->niter_inner = 1; p->niter_solver = 30; p->sor_omega = 1.9f;
+}
+
+int sfa_variational_2frame(sfa_ctx *ctx, float *wx, float *wy, int w, int h, int stride, const float *im1, const float *im2, const sfa_params_2frame *pp) {
+    CHECK_ARGS(ctx && wx && wy && im1 && im2 && w >= 2 && h >= 5 && stride >= w, "bad arguments (h >= 5, w >= 2)");
+    sfa_params_2frame p;
+    if (pp) p = *pp; else sfa_params_2frame_default(&p);
+    const float half_alpha = 0.5f * p.alpha, hg = p.gamma * 0.5f / 3.0f, hd = p.delta * 0.5f / 3.0f;   // :113-115
+    enum { WX, WY, UU, VV, DU, DV, SH, SV, A11, A12, A22, B1, B2, MASK, DPS, IM1, IM2 = IM1 + 3, WIM2 = IM2 + 3, STACK = WIM2 + 3, NPL = STACK + 24 };
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, NPL));
+    SFA_TRY(s.up(WX, wx, stride)); SFA_TRY(s.up(WY, wy, stride));
+    SFA_TRY(s.up(IM1, im1, stride, 3)); SFA_TRY(s.up(IM2, im2, stride, 3));
+    const Geo g = s.geo();
+    const float zero3[3] = {0, 0, 0}, one3[3] = {1, 1, 1};
+    launch_dpsis(ctx, g, s.plane(DPS), s.plane(IM1), 0, 5.0f, zero3, one3, 0);                           // :35
+    SorWorkspace ws;
+    for (int outer = 0; outer < p.niter_outer; outer++) {
+        launch_warp(ctx, g, s.plane(WIM2), s.plane(MASK), s.plane(IM2), s.plane(WX), s.plane(WY), 1, 0);   // :41
+        launch_deriv_stack(ctx, g, s.plane(STACK), s.plane(WIM2), s.plane(IM1), 0, 0);                   // :43 (mean of both, dt = im2 - im1)
+        launch_zero_planes(ctx, g, s.plane(DU), 2);                                                      // :45-46
+        launch_copy_planes(ctx, g, s.plane(UU), s.plane(WX), 2, 0, 0);                                   // :48-49
+        for (int inner = 0; inner < p.niter_inner; inner++) {
+            launch_smoothness_2f(ctx, g, s.plane(SH), s.plane(SV), s.plane(UU), s.plane(VV), s.plane(DPS), half_alpha);   // :54
+            launch_data_2f(ctx, g, s.plane(STACK), s.plane(MASK), s.plane(DU), s.plane(DV), s.plane(A11), s.plane(A12), s.plane(A22), s.plane(B1), s.plane(B2),
+                           s.plane(WX), s.plane(WY), s.plane(SH), s.plane(SV), hd, hg);                  // :55-57
+            SFA_TRY(sor_run(ctx, ws, g, s.plane(DU), s.plane(DV), s.plane(A11), s.plane(A12), s.plane(A22), s.plane(B1), s.plane(B2), s.plane(SH), s.plane(SV),
+                            p.niter_solver, p.sor_omega, false));                                       // :59
+            // uu = wx + du, vv = wy + dv (:62-67); the change norms of the shared kernel are not used here
+            launch_update_inner(ctx, g, s.plane(UU), s.plane(VV), s.plane(WX), s.plane(WY), s.plane(DU), s.plane(DV), s.plane(DU), s.plane(DV), ctx->d_red);
+        }
+        launch_copy_planes(ctx, g, s.plane(WX), s.plane(UU), 2, 0, 0);                                   // :70-71
+    }
+    SFA_TRY(check_device_error(ctx));
+    SFA_TRY(s.down(wx, stride, WX)); SFA_TRY(s.down(wy, stride, WY));
+    return sfa_ctx_sync(ctx);
+}
+
+void variational(sfa_image *wx, sfa_image *wy, const sfa_color_image *im1, const sfa_color_image *im2, sfa_params_2frame *params) {
+    static std::mutex mu;
+    static sfa_ctx *def = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!def && sfa_ctx_create(0, &def) != SFA_OK) {
+        fprintf(stderr, "error in variational(): %s\n", sfa_last_error(nullptr));
+        exit(1);
+    }
+    const bool ok = wx && wy && im1 && im2 && wx->data && wy->data && im1->c1 && im2->c1 && wy->width == wx->width && wy->height == wx->height &&
+                    wy->stride == wx->stride && im1->width == wx->width && im1->height == wx->height && im1->stride == wx->stride &&
+                    im2->width == wx->width && im2->height == wx->height && im2->stride == wx->stride &&
+                    im1->c2 == im1->c1 + (size_t)im1->stride * im1->height && im2->c2 == im2->c1 + (size_t)im2->stride * im2->height;
+    if (!ok || sfa_variational_2frame(def, wx->data, wy->data, wx->width, wx->height, wx->stride, im1->c1, im2->c1, params) != SFA_OK) {
+        fprintf(stderr, "error in variational(): %s\n", ok ? sfa_last_error(def) : "images must share one geometry (color_image_new layout)");
+        exit(1);
+    }
+}
+
 // ---- normalize ---------------------------------------------------------------------------------------------
 int sfa_normalize(sfa_ctx *ctx, float *const *frames, int F, int w, int h, int stride, double avg[3], double std_dev[3]) {
     CHECK_ARGS(ctx && frames && F > 0 && w > 0 && h > 0 && stride >= w && avg && std_dev, "bad arguments");

@@ -322,6 +322,109 @@ void launch_sub_laplacian(sfa_ctx *c, const Geo &g, float *dst, const float *src
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The original two-frame refinement (epic_flow_extended/variational.c + variational_aux.c): smoothness and data term with
+// its fixed modified-L1 penalties (eps = 0.001) in ITS operation order (the multi-frame class above rounds differently).
+// ---------------------------------------------------------------------------------------------------
+#define EPS2F (0.001f * 0.001f)     // epsilon_color / _grad / _smooth, variational_aux.c:11-13
+__global__ void k_smoothness_2f(float *__restrict__ sh, float *__restrict__ sv, const float *__restrict__ uu_, const float *__restrict__ vv_,
+                                const float *__restrict__ dps_, Geo g, float half_alpha) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.pitch || y >= g.h) return;
+    const size_t o = (size_t)y * g.pitch + x;
+    sh += b * g.es; sv += b * g.es;
+    if (x >= g.w) { sh[o] = 0.0f; sv[o] = 0.0f; return; }
+    PlaneAcc uu{uu_ + b * g.es, g.pitch}, vv{vv_ + b * g.es, g.pitch}, dps{dps_ + b * g.es, g.pitch};
+    const int w = g.w, h = g.h;
+    float outh = 0.0f, outv = 0.0f;
+    if (x < w - 1) {                                                                     // variational_aux.c:115-128
+        const float ux1 = uu(x + 1, y) - uu(x, y), vx1 = vv(x + 1, y) - vv(x, y);
+        float tmp = 0.5f * (d3y(uu, x, y, h) + d3y(uu, x + 1, y, h));
+        const float uxsq = ux1 * ux1 + tmp * tmp;
+        tmp = 0.5f * (d3y(vv, x, y, h) + d3y(vv, x + 1, y, h));
+        const float vxsq = vx1 * vx1 + tmp * tmp;
+        tmp = uxsq + vxsq;
+        outh = (float)((double)((dps(x, y) + dps(x + 1, y)) * half_alpha) / __dsqrt_rn((double)(tmp + EPS2F)));   // double sqrt and division (:126)
+    }
+    if (y < h - 1) {                                                                     // :130-146
+        const float uy1 = uu(x, y + 1) - uu(x, y), vy1 = vv(x, y + 1) - vv(x, y);
+        float tmp = 0.5f * (d3x(uu, x, y, w) + d3x(uu, x, y + 1, w));
+        const float uysq = uy1 * uy1 + tmp * tmp;
+        tmp = 0.5f * (d3x(vv, x, y, w) + d3x(vv, x, y + 1, w));
+        const float vysq = vy1 * vy1 + tmp * tmp;
+        tmp = uysq + vysq;
+        outv = (float)((double)((dps(x, y) + dps(x, y + 1)) * half_alpha) / __dsqrt_rn((double)(tmp + EPS2F)));
+    }
+    sh[o] = outh;
+    sv[o] = outv;
+}
+void launch_smoothness_2f(sfa_ctx *c, const Geo &g, float *sh, float *sv, const float *uu, const float *vv, const float *dpsis, float half_alpha) {
+    dim3 grid((g.pitch + BX - 1) / BX, (g.h + BY - 1) / BY, g.nb);
+    hipLaunchKernelGGL(k_smoothness_2f, grid, block2d(), 0, c->stream, sh, sv, uu, vv, dpsis, g, half_alpha);
+}
+// compute_data_and_match (variational_aux.c:215-302) followed by both sub_laplacian calls (variational.c:56-57, on wx / wy)
+__global__ void __launch_bounds__(BX *BY) k_data_2f(const float *__restrict__ D, const float *__restrict__ mask, const float *__restrict__ du, const float *__restrict__ dv,
+                                                     float *__restrict__ a11, float *__restrict__ a12, float *__restrict__ a22, float *__restrict__ b1, float *__restrict__ b2,
+                                                     const float *__restrict__ wx, const float *__restrict__ wy, const float *__restrict__ sh, const float *__restrict__ sv,
+                                                     Geo g, float hd, float hg) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const long eb = b * g.es;
+    const size_t o = (size_t)y * g.pitch + x;
+    const float *S = D + eb + o;
+    float ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        ix[k] = S[(0 * 3 + k) * g.pl]; iy[k] = S[(1 * 3 + k) * g.pl]; iz[k] = S[(2 * 3 + k) * g.pl];
+        ixx[k] = S[(3 * 3 + k) * g.pl]; ixy[k] = S[(4 * 3 + k) * g.pl]; iyy[k] = S[(5 * 3 + k) * g.pl];
+        ixz[k] = S[(6 * 3 + k) * g.pl]; iyz[k] = S[(7 * 3 + k) * g.pl];
+    }
+    const float u = du[eb + o], v = dv[eb + o], m = mask[eb + o];
+    const float dn = 0.1f * 0.1f;                                                        // datanorm (:10)
+    float A11 = 0.0f, A12 = 0.0f, A22 = 0.0f, B1 = 0.0f, B2 = 0.0f;
+    if (hd) {                                                                            // :245-269
+        float t[3], n[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { t[k] = iz[k] + ix[k] * u + iy[k] * v; n[k] = ix[k] * ix[k] + iy[k] * iy[k] + dn; }
+        const float q = __fdiv_rn(m * hd, sqrt_rn(__fdiv_rn(t[0] * t[0], n[0]) + __fdiv_rn(t[1] * t[1], n[1]) + __fdiv_rn(t[2] * t[2], n[2]) + EPS2F));
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float tk = __fdiv_rn(q, n[k]);
+            A11 += tk * ix[k] * ix[k]; A12 += tk * ix[k] * iy[k]; A22 += tk * iy[k] * iy[k];
+            B1 -= tk * iz[k] * ix[k];  B2 -= tk * iz[k] * iy[k];
+        }
+    }
+    float t[6], n[6];                                                                    // :271-300
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        n[2 * k] = ixx[k] * ixx[k] + ixy[k] * ixy[k] + dn;
+        n[2 * k + 1] = iyy[k] * iyy[k] + ixy[k] * ixy[k] + dn;
+        t[2 * k] = ixz[k] + ixx[k] * u + ixy[k] * v;
+        t[2 * k + 1] = iyz[k] + ixy[k] * u + iyy[k] * v;
+    }
+    const float q = __fdiv_rn(m * hg, sqrt_rn(__fdiv_rn(t[0] * t[0], n[0]) + __fdiv_rn(t[1] * t[1], n[1]) + __fdiv_rn(t[2] * t[2], n[2]) + __fdiv_rn(t[3] * t[3], n[3]) +
+                                              __fdiv_rn(t[4] * t[4], n[4]) + __fdiv_rn(t[5] * t[5], n[5]) + EPS2F));
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float ta = __fdiv_rn(q, n[2 * k]), tb = __fdiv_rn(q, n[2 * k + 1]);
+        A11 += ta * ixx[k] * ixx[k] + tb * ixy[k] * ixy[k];
+        A12 += ta * ixx[k] * ixy[k] + tb * ixy[k] * iyy[k];
+        A22 += tb * iyy[k] * iyy[k] + ta * ixy[k] * ixy[k];
+        B1 -= ta * ixx[k] * ixz[k] + tb * ixy[k] * iyz[k];
+        B2 -= tb * iyy[k] * iyz[k] + ta * ixy[k] * ixz[k];
+    }
+    PlaneAcc U{wx + eb, g.pitch}, V{wy + eb, g.pitch}, H{sh + eb, g.pitch}, W{sv + eb, g.pitch};
+    B1 = laplacian_gather(B1, U, H, W, x, y, g.w, g.h);
+    B2 = laplacian_gather(B2, V, H, W, x, y, g.w, g.h);
+    a11[eb + o] = A11; a12[eb + o] = A12; a22[eb + o] = A22; b1[eb + o] = B1; b2[eb + o] = B2;
+}
+void launch_data_2f(sfa_ctx *c, const Geo &g, const float *D, const float *mask, const float *du, const float *dv, float *a11, float *a12, float *a22, float *b1,
+                    float *b2, const float *wx, const float *wy, const float *sh, const float *sv, float hd, float hg) {
+    hipLaunchKernelGGL(k_data_2f, grid2d(g), block2d(), 0, c->stream, D, mask, du, dv, a11, a12, a22, b1, b2, wx, wy, sh, sv, g, hd, hg);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // mask weighting by occlusion / direction (variational_mt.cpp:293-320)
 // ---------------------------------------------------------------------------------------------------
 __global__ void k_mask_weight(float *__restrict__ masks, const float *__restrict__ occ, Geo g, float data_norm, int ref, int one_direction) {

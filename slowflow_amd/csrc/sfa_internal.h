@@ -139,6 +139,11 @@ void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const floa
 void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ);
 
+// two-frame refinement (variational.c / variational_aux.c)
+void launch_smoothness_2f(sfa_ctx *c, const Geo &g, float *sh, float *sv, const float *uu, const float *vv, const float *dpsis, float half_alpha);
+void launch_data_2f(sfa_ctx *c, const Geo &g, const float *D, const float *mask, const float *du, const float *dv, float *a11, float *a12, float *a22, float *b1,
+                    float *b2, const float *wx, const float *wy, const float *sh, const float *sv, float hd, float hg);
+
 // ---- occlusion.hip: optimizeOcc (variational_aux_mt.cpp:758-887) ----------------------------------------------------
 struct OccSlot {
     long s1_off, s2_off;     // image pair of the slot's successive-frames stack (arena offsets, like Term::i1_off)

@@ -21,7 +21,7 @@ def libpath():
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "slowflow_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(sfa_[a-z0-9_]+|sor_coupled)\s*\(", src)
+    names = re.findall(r"\b(sfa_[a-z0-9_]+|sor_coupled|variational)\s*\(", src)
     return sorted(set(names))
 
 

@@ -688,3 +688,30 @@ def test_level_with_occlusion_reasoning(ctx, oracle, S, rho, omega):
     d = max(np.abs(valid(wxo, w) - valid(wxg, w)).max(), np.abs(valid(wyo, w) - valid(wyg, w)).max())
     if np.array_equal(valid(occ_o, w), valid(occ_g, w)):
         assert d <= max(TOL_LEVEL, 3 * oracle_sensitivity(oracle, po, frames, w, h)), d
+
+
+# ------------------------------------------------------------------------------------------------------
+# the reference's original two-frame refinement (variational.c:101) -- the oracle is pinned end to end against the real one
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(67, 45), (130, 98), (1024, 436)])
+@pytest.mark.parametrize("kw", [dict(), dict(delta=0.5, niter_outer=3, niter_inner=2), dict(alpha=3.0, gamma=0.2, niter_solver=7, sor_omega=1.5)])
+def test_two_frame_variational(ctx, oracle, w, h, kw):
+    rng = np.random.default_rng(w + h)
+    big = smooth_noise_color(rng, w + 8, h + 8, 40)
+    a, b = orc.aligned_zeros((3, h, orc.stride_of(w))), orc.aligned_zeros((3, h, orc.stride_of(w)))
+    a[:, :, :w] = big[:, 4:4 + h, 4:4 + w]
+    b[:, :, :w] = big[:, 3:3 + h, 2:2 + w]                       # translated by (2, 1)
+    wx0, wy0 = noise_plane(rng, w, h, 1.5, 2.5), noise_plane(rng, w, h, 0.5, 1.5)
+    wxo, wyo = orc.plane(*wx0.shape), orc.plane(*wx0.shape)
+    wxo[...] = wx0; wyo[...] = wy0
+    oracle.variational_2frame(wxo, wyo, a, b, w, orc.params_2f(**kw))
+    po = orc.params_2f(**kw)
+    pg = sfa.Params2f(po.alpha, po.gamma, po.delta, po.sigma, po.niter_outer, po.niter_inner, po.niter_solver, po.sor_omega)
+    wxg, wyg = c_(wx0).copy(), c_(wy0).copy()
+    ctx.variational_2frame(wxg, wyg, c_(a), c_(b), w, pg)
+    assert np.array_equal(valid(wxo, w), valid(wxg, w)) and np.array_equal(valid(wyo, w), valid(wyg, w))
+    if orc.ref_available():                                      # and directly against the compiled reference where it travelled along
+        wxr, wyr = orc.plane(*wx0.shape), orc.plane(*wx0.shape)
+        wxr[...] = wx0; wyr[...] = wy0
+        orc.RefLib().variational_2frame(wxr, wyr, a, b, w, po)
+        assert np.array_equal(valid(wxr, w), valid(wxg, w)) and np.array_equal(valid(wyr, w), valid(wyg, w))

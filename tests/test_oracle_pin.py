@@ -247,3 +247,26 @@ def test_grid_cut_is_the_exact_minimum(oracle):
                    for lab in (np.array([(bits >> i) & 1 for i in range(w * h)]).reshape(h, w) for bits in range(1 << (w * h))))
         assert abs(best - e) < 1e-6
         assert abs(oracle.grid_cut_energy(occ, d0, d1, alpha, w) - e) < 1e-12
+
+
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (130, 98)])
+@pytest.mark.parametrize("kw", [dict(), dict(delta=0.5, niter_outer=3, niter_inner=2), dict(alpha=3.0, gamma=0.2, niter_solver=7, sor_omega=1.5)])
+def test_two_frame_variational_end_to_end(oracle, reflib, w, h, kw):
+    """the original two-frame refinement (variational.c:101): the restatement against the REAL compiled entry point, bit for bit
+    on the whole output -- warp, derivative stack, smoothness, data term, laplacian, SOR, updates, all iterations"""
+    rng = np.random.default_rng(w + h)
+    im1 = smooth_noise_color(rng, w + 8, h + 8, 40)
+    a, b = orc.aligned_zeros((3, h, orc.stride_of(w))), orc.aligned_zeros((3, h, orc.stride_of(w)))
+    a[:, :, :w] = im1[:, 4:4 + h, 4:4 + w]
+    b[:, :, :w] = im1[:, 3:3 + h, 2:2 + w]                       # translated by (2, 1)
+    wx0, wy0 = noise_plane(rng, w, h, 1.5, 2.5), noise_plane(rng, w, h, 0.5, 1.5)
+    p = orc.params_2f(**kw)
+    wxr, wyr = orc.plane(*wx0.shape), orc.plane(*wx0.shape)
+    wxr[...] = wx0; wyr[...] = wy0
+    wxo, wyo = wxr.copy(), wyr.copy()
+    wxo2, wyo2 = orc.plane(*wx0.shape), orc.plane(*wx0.shape)
+    wxo2[...] = wx0; wyo2[...] = wy0
+    reflib.variational_2frame(wxr, wyr, a, b, w, p)
+    oracle.variational_2frame(wxo2, wyo2, a, b, w, p)
+    assert np.array_equal(valid(wxr, w), valid(wxo2, w)) and np.array_equal(valid(wyr, w), valid(wyo2, w))
+    assert np.abs(valid(wxr, w) - valid(wx0, w)).max() > 1e-3      # it did move
