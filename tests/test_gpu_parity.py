@@ -715,3 +715,16 @@ def test_two_frame_variational(ctx, oracle, w, h, kw):
         wxr[...] = wx0; wyr[...] = wy0
         orc.RefLib().variational_2frame(wxr, wyr, a, b, w, po)
         assert np.array_equal(valid(wxr, w), valid(wxg, w)) and np.array_equal(valid(wyr, w), valid(wyg, w))
+
+
+@pytest.mark.parametrize("case", ["default", "color_inner", "weights"])
+def test_two_frame_golden_gpu(ctx, case):
+    """GPU against the committed outputs of the compiled reference's own variational() (no oracle in between)"""
+    cases = {"default": dict(), "color_inner": dict(delta=0.5, niter_outer=3, niter_inner=2), "weights": dict(alpha=3.0, gamma=0.2, niter_solver=7, sor_omega=1.5)}
+    T = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_two_frame.npz"))
+    w, h = (int(v) for v in T["size"])
+    po = orc.params_2f(**cases[case])
+    pg = sfa.Params2f(po.alpha, po.gamma, po.delta, po.sigma, po.niter_outer, po.niter_inner, po.niter_solver, po.sor_omega)
+    wx, wy = c_(T["wx0"]).copy(), c_(T["wy0"]).copy()
+    ctx.variational_2frame(wx, wy, c_(T["im1"]), c_(T["im2"]), w, pg)
+    assert np.array_equal(wx[:, :w], T[f"{case}_wx"]) and np.array_equal(wy[:, :w], T[f"{case}_wy"])
