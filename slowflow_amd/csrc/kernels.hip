@@ -1197,6 +1197,83 @@ void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl,
     launch_resize_scaled(c, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes, nb, post_scale, (double)sw / dw, (double)sh / dh);
 }
 
+// One pyramid step in one pass (variational_mt.cpp:607,611): GaussianBlur then resize of `nplanes` planes per window.  A block owns a
+// 64x8 tile of the DESTINATION; the source footprint (+ blur radius, replicated at the image border) is staged in LDS,
+// blurred along rows, then along columns, and sampled bilinearly -- the same operations in the same order as k_gauss_h,
+// k_gauss_v, k_resize, without the two intermediate images.
+__global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int dw, int dh, int dpitch, long dpl, long des, const float *__restrict__ src, int sw, int sh,
+                                                  int spitch, long spl, long ses, int nplanes, double scale_x, double scale_y, Taps t, int CM, int RM) {
+    extern __shared__ float pyr_lds[];
+    const int r = t.r, CS = CM + 2 * r, RS = RM + 2 * r;
+    float *S = pyr_lds, *Hb = S + RS * CS, *V = Hb + RS * CM;
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    const int dx0 = blockIdx.x * 64, dy0 = blockIdx.y * 8;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    // first source column / row any pixel of the tile samples (k_resize's own coordinate arithmetic)
+    int mx0 = (int)floorf((float)((dx0 + 0.5) * scale_x - 0.5)), my0 = (int)floorf((float)((dy0 + 0.5) * scale_y - 0.5));
+    mx0 = mx0 < 0 ? 0 : mx0; my0 = my0 < 0 ? 0 : my0;
+    const float *s = src + b * ses + pl * spl;
+    for (int i = tid; i < RS * CS; i += 256) {
+        const int j = i / CS, c = i % CS;
+        S[i] = s[(size_t)clampi(my0 - r + j, 0, sh - 1) * spitch + clampi(mx0 - r + c, 0, sw - 1)];
+    }
+    __syncthreads();
+    for (int i = tid; i < RS * CM; i += 256) {                       // k_gauss_h on the rows of the footprint
+        const int j = i / CM, c = i % CM;
+        const float *row = S + j * CS + c + r;
+        float acc = t.k[r] * row[0];
+        for (int q = 1; q <= r; q++) acc += t.k[r + q] * (row[-q] + row[q]);
+        Hb[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < RM * CM; i += 256) {                       // k_gauss_v
+        const int j = i / CM, c = i % CM;
+        const float *col = Hb + (j + r) * CM + c;
+        float acc = t.k[r] * col[0];
+        for (int q = 1; q <= r; q++) acc += t.k[r + q] * (col[-q * CM] + col[q * CM]);
+        V[i] = acc;
+    }
+    __syncthreads();
+    const int dx = dx0 + threadIdx.x;
+    if (dx >= dw) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);                 // k_resize
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+    const float a0 = 1.f - fx, a1 = fx;
+    for (int k = 0; k < 2; k++) {
+        const int dy = dy0 + threadIdx.y + 4 * k;
+        if (dy >= dh) break;
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        const int sy1 = sy + 1 < sh ? sy + 1 : sy;
+        const float *r0 = V + (sy - my0) * CM - mx0, *r1 = V + (sy1 - my0) * CM - mx0;
+        const float b0 = 1.f - fy, b1 = fy;
+        const float h0 = r0[sx] * a0 + r0[sx1] * a1;
+        const float h1 = r1[sx] * a0 + r1[sx1] * a1;
+        dst[b * des + pl * dpl + (size_t)dy * dpitch + dx] = h0 * b0 + h1 * b1;
+    }
+}
+// returns false if the footprint does not fit LDS (very small p_scale): the caller then runs the separate kernels
+bool launch_pyr_down(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
+                     int nplanes, int nb, const float *taps, int radius) {
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    const int CM = (int)ceil(64 * scale_x) + 2, RM = (int)ceil(8 * scale_y) + 2, CS = CM + 2 * radius, RS = RM + 2 * radius;
+    const size_t lds = (size_t)(RS * CS + RS * CM + RM * CM) * sizeof(float);
+    if (lds > 60 * 1024 || radius > 8) return false;
+    Taps t;
+    t.r = radius;
+    for (int i = 0; i < 2 * radius + 1; i++) t.k[i] = taps[i];
+    hipLaunchKernelGGL(k_pyr_down, dim3((dw + 63) / 64, (dh + 7) / 8, nb * nplanes), dim3(64, 4), lds, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl,
+                       ses, nplanes, scale_x, scale_y, t, CM, RM);
+    return true;
+}
+
 // optional level-0 Gaussian presmoothing (cfg sigma > 0, variational_mt.cpp:590-597): gaussian_filter
 // (image.c:310-348) + the generic convolve_horiz / convolve_vert (image.c:537-644), whose border handling
 // uses the accumulated coefficients.

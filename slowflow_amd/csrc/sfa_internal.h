@@ -176,6 +176,8 @@ void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl,
                    int nplanes, int nb, float post_scale);
 void launch_resize_scaled(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl,
                           long ses, int nplanes, int nb, float post_scale, double scale_x, double scale_y);
+bool launch_pyr_down(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
+                     int nplanes, int nb, const float *taps, int radius);   // blur + resize fused; false: footprint too large, use the two kernels
 void launch_presmooth(sfa_ctx *c, const Geo &g, float *dst, float *tmp, const float *src, int nplanes, float sigma);
 void launch_normalize_sums(sfa_ctx *c, const Geo &g, const float *frames3, double *red /* [3][2] */);
 void launch_normalize_apply(sfa_ctx *c, const Geo &g, float *frames3, const double avg[3], const double stdv[3]);

@@ -728,3 +728,21 @@ def test_two_frame_golden_gpu(ctx, case):
     wx, wy = c_(T["wx0"]).copy(), c_(T["wy0"]).copy()
     ctx.variational_2frame(wx, wy, c_(T["im1"]), c_(T["im2"]), w, pg)
     assert np.array_equal(wx[:, :w], T[f"{case}_wx"]) and np.array_equal(wy[:, :w], T[f"{case}_wy"])
+
+
+@pytest.mark.parametrize("w,h,p_scale,layers", [(130, 98, 0.9, 4), (200, 150, 0.75, 3), (97, 61, 0.5, 3), (1024, 436, 0.9, 5)])
+def test_fused_pyramid_step_is_blur_then_resize(ctx, oracle, monkeypatch, w, h, p_scale, layers):
+    """k_pyr_down (blur rows, blur columns, bilinear sample from an LDS tile) gives the frames of the two-kernel pyramid bit for
+    bit: whole runs agree exactly, for several scale factors (tile footprints) and sizes off the tile grid"""
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=31)
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=2, layers=layers, p_scale=p_scale)
+    out = []
+    for unfused in ("1", "0"):
+        if unfused == "1":
+            monkeypatch.setenv("SFA_PYRAMID_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("SFA_PYRAMID_UNFUSED", raising=False)
+        wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
+        ctx.variational(ps, wx, wy, [c_(f) for f in frames], w, None)
+        out.append((wx, wy))
+    assert np.array_equal(valid(out[0][0], w), valid(out[1][0], w)) and np.array_equal(valid(out[0][1], w), valid(out[1][1], w))
