@@ -718,14 +718,6 @@ int sfa_sor_batch_run(sfa_sor_batch *sb, int iterations, float omega) {
     return sor_run(ctx, sb->ws, g, sb->plane(0, 0), sb->plane(0, 1), sb->plane(0, 2), sb->plane(0, 3), sb->plane(0, 4), sb->plane(0, 5), sb->plane(0, 6),
                    sb->plane(0, 7), sb->plane(0, 8), iterations, omega, true);
 }
-// debug only (not in the public header): wall-clock stamps of the band kernel's waves, see SFA_SOR_TRACE
-extern "C" int sfa_debug_sor_trace(sfa_sor_batch *sb, unsigned long long *out, int n) {
-    if (!sb || !sb->ws.trace.p) return -1;
-    (void)hipStreamSynchronize(sb->ctx->stream);
-    const int have = sb->nb * sb->ws.NB * sb->ws.NG * 4;
-    if (n > have) n = have;
-    return hipMemcpy(out, sb->ws.trace.p, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? n : -1;
-}
 int sfa_sor_batch_download(sfa_sor_batch *sb, int b, float *du, float *dv, int stride) {
     sfa_ctx *ctx = sb ? sb->ctx : nullptr;
     CHECK_ARGS(sb && b >= 0 && b < sb->nb && du && dv && stride >= sb->w, "bad arguments");

@@ -778,9 +778,6 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         const Term &T = a.t[t];
         const float *pa = base + eb + T.i1_off, *pb = base + eb + T.i2_off;
         __syncthreads();                                           // the staged planes are free again
-#ifdef SFA_EXP_NOSTAGE
-        if (t >= 0) goto stage2;
-#endif
         // stage 0: M and Iz (halo 4) of the three channels, one float4 of a row per item; columns outside the image are
         // replicated (clamped source column), rows outside are never read
         for (int item = threadIdx.x; item < TR * 3 * QM; item += NT) {
@@ -836,9 +833,6 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             *reinterpret_cast<float4 *>(&sX[ch][ly * AT_W1 + 4 * q]) = make_float4(X[0], X[1], X[2], X[3]);
             *reinterpret_cast<float4 *>(&sY[ch][ly * AT_W1 + 4 * q]) = make_float4(Y[0], Y[1], Y[2], Y[3]);
         }
-#ifdef SFA_EXP_NOSTAGE
-    stage2:
-#endif
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NP; k++) {
@@ -876,12 +870,8 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             if (!ok[k]) continue;
             float m = base[eb + T.mask_off + (size_t)y * g.pitch + x];
             if (!a.one_direction || !T.backward) m = T.backward ? 1.0f * bwd[k] * m : 1.0f * fwd[k] * m;   // :314,316
-#ifdef SFA_EXP_NOTERM
-            { float q = m; for (int ch = 0; ch < 3; ch++) q += p.ix[ch] + p.iy[ch] + p.iz[ch] + p.ixx[ch] + p.ixy[ch] + p.iyy[ch] + p.ixz[ch] + p.iyz[ch]; A[k].a11 += q; }
-#else
             if (T.is_ref) term_ref(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
             else          term_succ(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
-#endif
         }
     }
     float4(*tA)[65] = reinterpret_cast<float4(*)[65]>(lds);                     // [TY][65] each; live after the last barrier below

@@ -192,7 +192,7 @@ struct SorWorkspace {
     long ent = 0;                 // entries per element (ND*RP)
     int band = 0, Wp = 0, EP = 0;   // band kernel: fused sweeps per wave (0 = task kernel), edge row pitch / left pad
     long edge_job = 0;
-    DevMem sa, sb, x, flags, order, edge, trace;
+    DevMem sa, sb, x, flags, order, edge;
     int configure(sfa_ctx *ctx, int w, int h, int K, int nb);   // (re)allocates for this shape
 };
 // planes: row-major device planes of element 0 (+es).  inv_out: write the inverted blocks back to a11/a12/a22

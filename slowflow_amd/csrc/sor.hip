@@ -292,7 +292,6 @@ struct BandArgs {
     unsigned long long *edge;      // [nb][NB][K][Wp]  lane-63 iterates of every sweep
     unsigned *gflags;              // [nb][NB][NW] chunks whose edge stores are complete; gflags[nb*NB*NW] = ticket
     unsigned *err;
-    unsigned long long *trace;     // debug (SFA_SOR_TRACE): [nb*NB][NW][4] wall-clock stamps, or null
     long ent, edge_job;            // entries per batch element (diag planes / edge rows)
     int W, H, K, NB, NW, RP, G, NS, NCH, nb, Wp, EP;
     int lead;                      // steps a stage may run ahead of the next one (<= ring slots)
@@ -331,7 +330,6 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     // Only sweep f = 0 reads its operands from HBM.  Sweep f at step s works on what f = 0 worked on at step s - 2f, one
     // row up per sweep (FOFF): the wave keeps its last 2(F-1) operand rows in LDS and sweeps f >= 1 read them back at
     // lane offset -f.  Rows r0-(F-1) .. r0-1 (positions 0 .. F-2 of a window row) come through a third, 8-lane load.
-    (void)FOFF;
     constexpr int NSLOT = F > 1 ? 2 * (F - 1) : 1, WP = 64 + F - 1;      // window rows (steps) / positions per row
     const char *ba0 = reinterpret_cast<const char *>(a.sa + (size_t)job * a.ent + U0);
     const char *bb0 = reinterpret_cast<const char *>(a.sb + (size_t)job * a.ent + U0);
@@ -363,13 +361,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     unsigned *gmine = a.gflags + ((size_t)job * a.NB + b) * a.NW + wave;
     const unsigned *g_up = a.gflags + ((size_t)job * a.NB + (b - 1)) * a.NW + wave;      // (b-1, w)
     const unsigned *g_up2 = g_up - 1;                                                    // (b-1, w-1)
-#if defined(SFA_EXPERIMENT_NODEP)
-    const bool has_up = false, publishes = false;                 // timing experiment: bands as independent problems (wrong results)
-#elif defined(SFA_EXPERIMENT_NOPUB)
-    const bool has_up = false, publishes = b + 1 < a.NB;          // timing experiment: edge stores but nobody waits
-#else
     const bool has_up = b > 0, publishes = b + 1 < a.NB;
-#endif
     // lane t = fi*MC + j fetches lane 0's "lane -1" value of step j of the macro chunk: fi = 0: right of f = 0 (sweep
     // k0-1, column s+1); fi = f+1: top of f (sweep k0+f, column s-f)
     const int tfi = lane / MC, tj = lane % MC;
@@ -384,11 +376,6 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     auto need_up2 = [&](int m) { return (unsigned)min(m + 1 + (64 + F + MC - 1) / MC, NMC); };
     auto ready = [&](int m) { return !has_up || (known_up >= need_up(m) && (FIRST || known_up2 >= need_up2(m))); };
 
-#ifdef SFA_BUILD_TRACE
-    unsigned long long *tr = a.trace ? a.trace + (((size_t)b * a.nb + job) * a.NW + wave) * 4 : nullptr;
-    if (tr && lane == 0) tr[0] = wall_clock64();
-    unsigned nblock = 0;
-#endif
     // ---- prologue ---------------------------------------------------------------------------------------
     if (has_up) {
         // start one macro chunk further behind the band above than strictly needed: its progress is seen one macro chunk
@@ -413,9 +400,6 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
         }
     } else if (has_up && lane == 0) selfv[0] = u2f(ld_x(e_up - a.Wp));                  // x^(k0-1)(0, r0): band above, lane 63
     if (tv_lane) tv = ld_x(e_up + tv_off);
-#ifdef SFA_BUILD_TRACE
-    if (tr && lane == 0) tr[1] = wall_clock64();
-#endif
 
     int s0 = 0;
     for (int m = 0; m < NMC; m++) {
@@ -471,15 +455,6 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                     const int slot = (jj - 2 * f + 4 * NSLOT) & (NSLOT - 1);
                     oa[f] = winA[slot * WP + lane + (F - 1 - f)];
                     ob[f] = winB[slot * WP + lane + (F - 1 - f)];
-#ifdef SFA_DEBUG_WINDOW
-                    {
-                        const float4 ra = *reinterpret_cast<const float4 *>(ba0 - (long)f * FOFF * 16 + vo16);
-                        const float4 rb = *reinterpret_cast<const float4 *>(bb0 - (long)f * FOFF * 16 + vo16);
-                        const bool bad = __float_as_uint(ra.x) != __float_as_uint(oa[f].x) || __float_as_uint(ra.w) != __float_as_uint(oa[f].w) ||
-                                         __float_as_uint(rb.x) != __float_as_uint(ob[f].x) || __float_as_uint(rb.w) != __float_as_uint(ob[f].w);
-                        if (bad) atomicCAS(a.err, 0u, 0x10000000u | (b << 24) | (wave << 20) | (f << 16) | (lane << 8) | (s & 255));
-                    }
-#endif
                 }
                 float2 nres[F];
 #pragma unroll
@@ -507,11 +482,9 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                     if (ex_lane) wex[slot * WP * 2] = ex[j];
                 }
                 // refill slot j for step s + CH (beyond the last step this reads zero guards)
-#ifndef SFA_EXPERIMENT_NOLOAD
                 sa0[j] = *reinterpret_cast<const float4 *>(ba0 + (vo16 + CH * st16));
                 sb0[j] = *reinterpret_cast<const float4 *>(bb0 + (vo16 + CH * st16));
                 if (ex_lane) ex[j] = *reinterpret_cast<const float2 *>(bex + (vo16 + CH * st16));
-#endif
                 if (FIRST) {
                     xr[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8));
                     xb[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8 + 8));
@@ -530,18 +503,12 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
             if (m > 0 && lane == 0) __hip_atomic_store(gmine, (unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (has_up && !last && !pre) {
-#ifdef SFA_BUILD_TRACE
-            nblock++;
-#endif
             known_up = wait_ge(g_up, need_up(m + 1), a.err);
             if (known_up == 0xffffffffu) return;
             if (!FIRST) { known_up2 = wait_ge(g_up2, need_up2(m + 1), a.err); if (known_up2 == 0xffffffffu) return; }
             if (tv_lane) tv = ld_x(e_up + s0 + tv_off);
         }
     }
-#ifdef SFA_BUILD_TRACE
-    if (tr && lane == 0) { tr[2] = wall_clock64(); tr[3] = nblock; }
-#endif
     if (publishes) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(gmine, (unsigned)NMC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -724,7 +691,6 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
         edge_job = (long)NB * K * Wp;
         SFA_TRY(edge.alloc(c, (size_t)nb * edge_job * sizeof(unsigned long long)));
         SFA_HIP(c, hipMemsetAsync(edge.p, 0, (size_t)nb * edge_job * sizeof(unsigned long long), c->stream));
-        if (getenv("SFA_SOR_TRACE")) SFA_TRY(trace.alloc(c, (size_t)nb * NB * NG * 4 * sizeof(unsigned long long)));
     }
     SFA_TRY(sa.alloc(c, (size_t)nb * ent * sizeof(float4)));
     SFA_TRY(sb.alloc(c, (size_t)nb * ent * sizeof(float4)));
@@ -791,7 +757,6 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         BandArgs ba;
         ba.sa = p.sa; ba.sb = p.sb; ba.x = p.x; ba.edge = (unsigned long long *)ws.edge.p; ba.gflags = p.flags; ba.err = c->d_err;
         ba.ent = ws.ent; ba.edge_job = ws.edge_job; ba.W = g.w; ba.H = g.h; ba.K = K; ba.NB = ws.NB; ba.NW = ws.NG; ba.RP = ws.RP; ba.G = ws.G;
-        ba.trace = (unsigned long long *)ws.trace.p;
         ba.lead = band_ring(ws.F);
         if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(kBandCH + 2, std::min(atoi(e), band_ring(ws.F)));
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;

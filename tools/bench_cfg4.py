@@ -1,7 +1,7 @@
 """config 4 per-GPU load: cfgs/slow_flow.cfg schedule (S=3, 5 levels, 10 alternations x 10 outer x 30 sweeps, occlusion reasoning,
 thresholds 1e-5) on 16 windows of 1024x436 (64 jets x 2 directions over 8 GPUs)"""
 import sys, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import numpy as np, slowflow_amd as sfa, bench
 B=int(sys.argv[1]) if len(sys.argv)>1 else 16
 ctx=sfa.Context(0)

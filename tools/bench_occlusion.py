@@ -1,6 +1,6 @@
 """cost of the occlusion step: whole-path step with niter_alter=2, occlusion reasoning on vs off"""
 import sys, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import numpy as np, slowflow_amd as sfa, bench
 B=int(sys.argv[1]) if len(sys.argv)>1 else 32
 ctx=sfa.Context(0)

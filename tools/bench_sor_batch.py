@@ -1,11 +1,11 @@
 import sys
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import numpy as np, slowflow_amd as sfa
 from synth import sor_system
 ctx=sfa.Context(0)
 K=30
-B=int(sys.argv[1]) if len(sys.argv)>1 else 32
-for (W,H) in [(1024,436),(512,218),(256,109),(128,54),(64,27)]:
+W,H=1024,436
+for B in [int(x) for x in sys.argv[1:]] or [32,64,128]:
     rng=np.random.default_rng(0)
     s=sor_system(rng,W,H)
     planes=[np.ascontiguousarray(s[k]) for k in ("du","dv","a11","a12","a22","b1","b2","sh","sv")]
