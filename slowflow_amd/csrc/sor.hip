@@ -317,7 +317,8 @@ __device__ __forceinline__ bool wait_lds_ge(unsigned *p, unsigned target, unsign
 // Two granularities: operands are refilled and the LDS hand-over to the next stage happens every CH steps; the
 // (slower) HBM hand-over to the band below -- progress words, lane-0 values -- every MC steps.
 template <int F, int CH, int MC, int RING, int ROLE>
-__device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long (*ring)[RING][64], unsigned *lprog, unsigned char *win, int job, int b, int wave, int lane) {
+__device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long (*ring)[RING][64], unsigned *lprog, unsigned char *win, unsigned long long (*estage)[MC], int job, int b,
+                                          int wave, int lane) {
     constexpr bool FIRST = ROLE == 0 || ROLE == 3, LASTW = ROLE == 2 || ROLE == 3;
     constexpr int NQ = MC / CH;
     const int k0 = wave * F;
@@ -464,7 +465,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                     const v2f xn = sor_point(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hl[f], oa[f], ob[f], omega);
                     nres[f] = make_float2(xn.x, xn.y);
                     // lane 63's iterate of every sweep is band b+1's lane-0 input (zeros outside the image land in the row pads)
-                    if (publishes && lane == 63) st_x(e_mine + (long)f * a.Wp + (s - 63 - f), f2u(xn.x, xn.y));
+                    if (publishes && lane == 63) estage[f][jj] = f2u(xn.x, xn.y);      // staged in LDS, stored once per macro chunk
                     if (f == F - 1) {
                         if (!LASTW) ring[wave][s & (RING - 1)][lane] = f2u(xn.x, xn.y);
                         else if (row_ok_last && (unsigned)(s - lane - f) < (unsigned)W)
@@ -496,8 +497,14 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
             // tell wave+1 / wave-1 (LDS words are written in order behind the ring writes)
             __hip_atomic_store(&lprog[wave], (unsigned)s0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        // ---- one macro chunk late, band b+1 (HBM): the previous macro chunk's lane-63 stores are older than the >= 16
-        // operand loads issued since (in-order vmcnt), so this counted wait covers them without draining the prefetch ----
+        // lane 63's iterates of this macro chunk: sweep f, steps s0-MC .. s0-1 are MC consecutive columns of edge row f, one
+        // 64-byte piece per sweep in a single store (instead of F stores per step)
+        if (publishes && lane < F * MC) {
+            const int fi = lane / MC, j = lane % MC;
+            st_x(e_mine + (long)fi * a.Wp + (s0 - MC - 63 - fi + j), estage[fi][j]);
+        }
+        // ---- one macro chunk late, band b+1 (HBM): the previous macro chunk's edge store is older than the >= 16
+        // operand loads issued since (in-order vmcnt), so this counted wait covers it without draining the prefetch ----
         if (publishes && !last) {
             asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             if (m > 0 && lane == 0) __hip_atomic_store(gmine, (unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -523,6 +530,7 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     unsigned *lprog = reinterpret_cast<unsigned *>(smem + (size_t)(NW - 1) * RING * 64 * 8);          // steps completed by each wave
     constexpr int WINB = F > 1 ? 2 * (F - 1) * (64 + F - 1) * 32 : 0;                                // operand window per wave (bytes)
     unsigned char *win0 = smem + (size_t)(NW - 1) * RING * 64 * 8 + 256;                             // 16-byte aligned behind the progress words
+    unsigned long long(*est0)[MC] = reinterpret_cast<unsigned long long(*)[MC]>(win0 + (size_t)NW * WINB);   // [NW][F][MC] edge staging
     unsigned &s_ticket = lprog[NW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -532,10 +540,10 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;                     // band-major tickets
-    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, job, b, wave, lane);
-    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, job, b, wave, lane);
-    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, job, b, wave, lane);
-    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, win0 + (size_t)wave * WINB, job, b, wave, lane);
+    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, job, b, wave, lane);
+    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, job, b, wave, lane);
+    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, job, b, wave, lane);
+    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, job, b, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -761,7 +769,7 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(kBandCH + 2, std::min(atoi(e), band_ring(ws.F)));
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
-        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F);
+        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F) + (size_t)ws.NG * ws.F * kBandMC * 8;
         if (ws.F == 5)      hipLaunchKernelGGL((k_sor_band<5, 6, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 3) hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, kBandCH, kBandMC, 8>), bgrid, bblock, lds, c->stream, ba);
