@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="frame windows per GPU solved in lockstep (fwd/bwd of several jets)")
+    ap.add_argument("--streams", type=int, default=2, help="the batch is refined as this many lockstep groups on separate HIP streams, one host thread each "
+                    "(the reference drives its windows from OpenMP threads, slow_flow.cpp:706): the groups fill each other's ramp-up / drain phases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path-only", action="store_true", help="skip the SOR-only section (used for the PMC passes: every SOR dispatch then belongs to the path)")
     args = ap.parse_args()
@@ -156,38 +158,63 @@ def main():
     else:
         torch.cuda.set_device(0)
 
-    ctx = sfa.Context(local_rank if world > 1 else 0)
-    p = bench_params()
+    import threading
+    dev = local_rank if world > 1 else 0
+    S = max(1, args.streams)
     B = args.batch
+    if B % S:
+        raise SystemExit("--batch must be a multiple of --streams")
+    BL = B // S                                       # windows per launch (one lockstep group)
+    ctxs = [sfa.Context(dev) for _ in range(S)]
+    ctx = ctxs[0]
+    p = bench_params()
     # one normalisation for the whole sequence, as the driver does (slow_flow.cpp:673)
     windows = [synth_window(1000 * rank + b) for b in range(B)]
     allf = [f for wdw in windows for f in wdw]
     avg, std = ctx.normalize(allf, W)
     for k in range(3):
         p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])     # 6-digit publish, variational_mt.cpp:71-84
-    job = sfa.Job(ctx, p, W, H, B)
-    for b in range(B):
-        job.upload(b, windows[b])
-    mpix_iters = job.mpix_iters()
+    jobs = [sfa.Job(c, p, W, H, BL) for c in ctxs]
+    for g, job in enumerate(jobs):
+        for b in range(BL):
+            job.upload(b, windows[g * BL + b])
+    mpix_iters = sum(job.mpix_iters() for job in jobs)
 
     def barrier():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        job.run()
+    def run_all(n):
+        """every group runs n passes on its own stream; returns when all streams have drained"""
+        def work(g):
+            for _ in range(n):
+                jobs[g].run()
+            ctxs[g].sync()
+        if S == 1:
+            work(0)
+            return
+        th = [threading.Thread(target=work, args=(g,)) for g in range(S)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    run_all(args.warmup)
     barrier()
-    ctx.profile_enable(True)
+    for c in ctxs:
+        c.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.run()
-    ctx.sync()
+    run_all(args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    n_sor, sor_ms, sor_bytes = ctx.profile_read()
-    ctx.profile_enable(False)
+    n_sor, sor_ms, sor_bytes = 0, 0.0, 0.0
+    for c in ctxs:
+        n_, ms_, by_ = c.profile_read()
+        n_sor += n_; sor_ms += ms_; sor_bytes += by_
+        c.profile_enable(False)
     from slowflow_amd import shard
     if dist is not None:
         dist.barrier()
@@ -199,41 +226,44 @@ def main():
     # SOR-only: the metric's own kernel at 1024x436, same batch, HIP events on the launch stream
     n1 = ms1 = by1 = n2 = ms2 = by2 = 0
     if not args.path_only:
-        n1, ms1, by1, n2, ms2, by2 = sor_only(ctx, B, rank)
+        n1, ms1, by1, n2, ms2, by2 = sor_only(ctx, BL, rank)
     if rank == 0:
         total = mpix_iters * args.steps * world
         value = total / elapsed_max
         achieved = sor_bytes / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(B)
+        traffic, traffic_src = measured_traffic(BL)
         out = {
             "metric": "Mpix*solver-iters/s at 1024x436 (whole coarse-to-fine path)", "value": round(value, 1), "unit": "Mpix*solver-iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 1024x436, S=2 (3 frames), 5 pyramid levels, 5 outer x 1 inner x 30 SOR sweeps, "
                                    "symmetric window, modified-L1 penalties, thresholds off",
-                       "frame_windows_per_gpu": B, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
+                       "frame_windows_per_gpu": B, "streams": S, "windows_per_launch": BL, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
                        "parallelism": f"frame-window data parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_sor_band<3,10,2,8,16> (batched lockstep solves; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
                          "algorithmic_bytes_per_launch": round(sor_bytes / max(n_sor, 1)),
                          "traffic_source": traffic_src,
-                         "note": "over the timed region: sum of (44*K+12)*w*h*batch ALGORITHMIC bytes of every SOR launch (all 5 levels) / sum of HIP-event durations; the kernel fuses all K sweeps of a 64-row band in one workgroup (x stays in registers/LDS), so its real HBM traffic is far below the algorithmic bytes and frac can exceed 1",
+                         "note": "over the timed region (launches of all streams; with streams > 1 a launch shares the GPU with the other groups' kernels, so its duration is longer than alone): sum of (44*K+12)*w*h*batch ALGORITHMIC bytes of every SOR launch (all 5 levels) / sum of HIP-event durations; the kernel fuses all K sweeps of a 64-row band in one workgroup (x stays in registers/LDS), so its real HBM traffic is far below the algorithmic bytes and frac can exceed 1",
                          },
-            "sor_share_of_step": round(sor_ms / (elapsed * 1e3), 4),
+            "sor_share_of_step": round(sor_ms / S / (elapsed * 1e3), 4),
             "seconds_per_window": {"mean": round(float(window_seconds.mean()), 6), "max": round(float(window_seconds.max()), 6), "n": int(window_seconds.size)},
         }
         if n1:
-            out["roofline"]["sor_1024x436_batch"] = {"batch": B, "avg_launch_ms": round(ms1 / n1, 4), "achieved": round(by1 / (ms1 * 1e-3) / 1e9, 1),
+            out["roofline"]["sor_1024x436_batch"] = {"batch": BL, "avg_launch_ms": round(ms1 / n1, 4), "achieved": round(by1 / (ms1 * 1e-3) / 1e9, 1),
                                                      "frac": round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                     "mpix_iters_per_s": round(W * H * SWEEPS * B * n1 / 1e6 / (ms1 * 1e-3), 1)}
+                                                     "mpix_iters_per_s": round(W * H * SWEEPS * BL * n1 / 1e6 / (ms1 * 1e-3), 1)}
             out["roofline"]["sor_1024x436_single"] = {"batch": 1, "avg_launch_ms": round(ms2 / n2, 4), "achieved": round(by2 / (ms2 * 1e-3) / 1e9, 1),
                                                       "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                       "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    job.close(); ctx.close()
+    for job in jobs:
+        job.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -3,7 +3,7 @@
 #   bash profiles/collect.sh r01        -> gpurun_out/<tag>_{stats,fetch,write}/...
 # pass 1: kernel trace + stats; pass 2/3: HBM-side PMC counters, each in its own run (MI355X_MICROARCH.md:
 # FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2; --pmc is never combined with the trace domains).
-# Afterwards, in the container:  python profiles/summarize.py <tag>   (writes profiles/<tag>_*.{csv,json})
+# Afterwards, in the container:  python profiles/summarize.py <tag> <windows per launch = batch / streams>   (writes profiles/<tag>_*.{csv,json})
 set -e
 TAG=${1:-r01}
 BATCH=${2:-64}

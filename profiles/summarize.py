@@ -3,7 +3,7 @@
    <tag>_kernel_stats.csv   per-kernel totals of the bench command (rocprofv3 --kernel-trace --stats)
    <tag>_sor_by_level.csv   SOR kernel: dispatches / average duration per pyramid level
    <tag>_traffic.json       HBM-side bytes per SOR launch: 2 x FETCH_SIZE (gfx950 tallies 128-B reads at 64 B) + WRITE_SIZE
-usage: python profiles/summarize.py r01 [batch]"""
+usage: python profiles/summarize.py r01 [windows_per_launch]     (bench.py --batch 64 --streams 2 launches 32 windows at a time)"""
 import collections
 import csv
 import json
@@ -12,7 +12,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go = os.path.join(root, "gpurun_out")
 out = os.path.join(root, "profiles")
@@ -51,7 +51,7 @@ def pmc(d, counter):
 
 
 fetch, write = pmc(f"{tag}_fetch", "FETCH_SIZE"), pmc(f"{tag}_write", "WRITE_SIZE")
-res = {"batch": batch, "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B by rocprofv3; x2 on FETCH_SIZE per MI355X_MICROARCH.md (gfx950)",
+res = {"batch": batch, "batch_note": "windows per SOR launch (bench.py: --batch / --streams)", "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B by rocprofv3; x2 on FETCH_SIZE per MI355X_MICROARCH.md (gfx950)",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("void sfa::") and not k.startswith("sfa::"):

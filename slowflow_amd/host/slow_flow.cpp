@@ -208,9 +208,14 @@ int main(int argc, char **argv) {
 
     std::mutex io_mu;
     bool failed = false;
-    auto worker = [&](int g) {
-        // contiguous block of windows per GPU: neighbouring jets share frames
-        const size_t lo = todo.size() * g / ngpu, hi = todo.size() * (g + 1) / ngpu;
+    // `gpu_streams` workers per GPU (default 2), each with its own context = HIP stream: two lockstep groups fill each other's
+    // ramp-up / drain phases (the reference runs its windows from `threads` OpenMP threads the same way, slow_flow.cpp:706)
+    const int streams = std::max(1, std::min(4, params.parameter<int>("gpu_streams", "2")));
+    const int nworkers = ngpu * streams;
+    auto worker = [&](int wk) {
+        const int g = wk / streams;
+        // contiguous block of windows per worker: neighbouring jets share frames
+        const size_t lo = todo.size() * wk / nworkers, hi = todo.size() * (wk + 1) / nworkers;
         if (lo >= hi) return;
         sfa_ctx *ctx = nullptr;
         if (sfa_ctx_create(dev0 + g, &ctx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; return; }
@@ -267,7 +272,7 @@ int main(int argc, char **argv) {
         sfa_ctx_destroy(ctx);
     };
     std::vector<std::thread> th;
-    for (int g = 0; g < ngpu; g++) th.emplace_back(worker, g);
+    for (int wk = 0; wk < nworkers; wk++) th.emplace_back(worker, wk);
     for (auto &t : th) t.join();
 
     // the gathered per-window timings (the only cross-GPU exchange of the path)
