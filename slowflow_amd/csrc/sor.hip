@@ -95,7 +95,7 @@ __device__ __forceinline__ unsigned wait_ge(const unsigned *p, unsigned target, 
         if ((++spins & 1023u) == 0) {
             const unsigned e = ld_flag(err);
             if (e || spins > kSpinLimit) {
-                if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return 0xffffffffu;
             }
         }
