@@ -13,7 +13,9 @@ for k in range(3): p.norm_avg[k]=float("%g"%avg[k]); p.norm_std[k]=float("%g"%st
 jobs=[sfa.Job(c,p,bench.W,bench.H,B) for c in ctxs]
 for j in jobs:
     for b in range(B): j.upload(b,windows[b%4])
+DELAY=float(sys.argv[3])*1e-3 if len(sys.argv)>3 else 0.0
 def run(i,n):
+    if i: time.sleep(DELAY*i)
     for _ in range(n): jobs[i].run()
     ctxs[i].sync()
 for i in range(NS): run(i,1)
@@ -23,3 +25,6 @@ for t in th: t.start()
 for t in th: t.join()
 dt=(time.perf_counter()-t0)/3*1e3
 print(f"{NS} streams x batch {B}: {dt:.2f} ms per step of {NS*B} windows = {dt/(NS*B):.3f} ms/window", flush=True)
+
+for j in jobs: j.close()
+for c in ctxs: c.close()
