@@ -177,6 +177,8 @@ int  sfa_job_upload(sfa_job *job, int b, const float *const *frames, int n_frame
 int  sfa_job_reset_flow(sfa_job *job);               /* re-arm every element with the uploaded initial flow */
 int  sfa_job_run(sfa_job *job);                      /* the whole coarse-to-fine path, asynchronous on the ctx stream */
 int  sfa_job_download(sfa_job *job, int b, float *wx, float *wy, int stride, float change[2]);
+/* Variational_MT::getOcclusions() of window b after the run: -1 occluded in the past / forward terms only, +1 in the future, 0 none */
+int  sfa_job_download_occlusions(sfa_job *job, int b, float *occ, int stride);
 double sfa_job_mpix_iters(const sfa_job *job);       /* sum over the job's SOR solves of w*h*K / 1e6, per run */
 
 /* SOR-only resident batch: `batch` independent systems of one size */

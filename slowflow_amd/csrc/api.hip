@@ -995,6 +995,15 @@ int sfa_job_download(sfa_job *j, int b, float *wx, float *wy, int stride, float 
     return sfa_ctx_sync(ctx);
 }
 
+int sfa_job_download_occlusions(sfa_job *j, int b, float *occ, int stride) {
+    sfa_ctx *ctx = j ? j->ctx : nullptr;
+    CHECK_ARGS(j && b >= 0 && b < j->nb && occ && stride >= j->w, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    Level L0 = j->level(0);
+    SFA_TRY(download_plane(ctx, occ, stride, L0.plane(P_OCC) + b * j->es, L0.pitch, j->w, j->h));
+    return sfa_ctx_sync(ctx);
+}
+
 // ---- host-plane convenience entry points ------------------------------------------------------------------------
 static int variational_host(sfa_ctx *ctx, const sfa_params *p, float *wx, float *wy, int w, int h, int stride, const float *const *frames, int n_frames,
                             const float *const chw[3], float *occlusions_out, float change[2]) {

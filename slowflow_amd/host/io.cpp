@@ -111,3 +111,16 @@ color_image_t *color_image_load(const char *filename, int *maxval_out) {
     fclose(f);
     return im;
 }
+
+int writePGM(const char *filename, const image_t *img, float offset, float scale) {
+    FILE *f = fopen(filename, "wb");
+    if (!f) return -1;
+    fprintf(f, "P5\n%d %d\n255\n", img->width, img->height);
+    for (int y = 0; y < img->height; y++)
+        for (int x = 0; x < img->width; x++) {
+            float v = scale * (img->data[(size_t)y * img->stride + x] + offset);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            fputc((int)(v + 0.5f), f);
+        }
+    return fclose(f) == 0 ? 0 : -1;
+}

@@ -10,5 +10,7 @@ int writeFlowFile(const char *filename, const image_t *flowx, const image_t *flo
 image_t **readFlowFile(const char *filename);                                           /* [0]=u, [1]=v; NULL on failure */
 /* loads a frame as 3 float planes (grey images are replicated); *maxval = 255 / 65535 / 1 (pfm). NULL on failure */
 color_image_t *color_image_load(const char *filename, int *maxval);
+/* binary P5, 8 bit: value = clamp(round(scale * (v + offset)), 0, 255); 0 on success */
+int writePGM(const char *filename, const image_t *img, float offset, float scale);
 
 #endif

@@ -253,6 +253,18 @@ int main(int argc, char **argv) {
                         image_mul_scalar(wy, (float)steps);
                         if (writeFlowFile(wd.out.c_str(), wx, wy) != 0) rc = SFA_ERR_ARG;
                     }
+                    if (rc == SFA_OK && sp.occlusion_reasoning && !wd.backward && tp.parameter<bool>("slow_flow_output_occlusions", "0")) {
+                        // the final occlusion labels of the forward window as an image, (occ + 1) / 2 * 255 like :276-279 (there: one PNG per
+                        // alternation; here the last one, as PGM)
+                        image_t *occ = image_new(width, height);
+                        rc = sfa_job_download_occlusions(job, (int)e, occ->data, occ->stride);
+                        if (rc == SFA_OK) {
+                            mkdirs(params.output + "occlusion/");                    // :676-677
+                            const string of = params.output + "occlusion/" + wd.out.substr(wd.out.find_last_of('/') + 1, wd.out.find_last_of('.') - wd.out.find_last_of('/') - 1) + "_occ.pgm";
+                            writePGM(of.c_str(), occ, 1.0f, 127.5f);
+                        }
+                        image_delete(occ);
+                    }
                     image_delete(wx); image_delete(wy);
                     wd.gpu = dev0 + g;
                 }

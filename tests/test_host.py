@@ -105,6 +105,10 @@ def test_slow_flow_driver_end_to_end(host_build, tmp_path, alter, occ):
     # forward flows recover the synthetic translation (1.5, -0.75) px per frame
     u, v = read_flo(str(out / "f_010.flo"))
     assert abs(np.median(u) - 1.5) < 0.1 and abs(np.median(v) + 0.75) < 0.1
+    if occ:                                                       # the occlusion labels of every forward window were written
+        for j in range(jets):
+            with open(str(out / "occlusion" / ("f_%03d_occ.pgm" % (10 + j * steps))), "rb") as f:
+                assert f.readline() == b"P5\n" and f.readline().split() == [b"%d" % w, b"%d" % h]
     # -resume skips what exists
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-resume"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.count("already exist") == 2 * jets
