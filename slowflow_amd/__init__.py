@@ -102,6 +102,13 @@ def stride_of(w):
     return ((w + 3) // 4) * 4
 
 
+def pyramid_sizes(w, h, layers, p_scale):
+    """level sizes of the coarse-to-fine pyramid (variational_mt.cpp:576-652); pure host logic, no GPU needed"""
+    ws, hs = (C.c_int * 64)(), (C.c_int * 64)()
+    n = lib().sfa_pyramid_sizes(int(w), int(h), int(layers), C.c_float(p_scale), ws, hs)
+    return list(ws[:n]), list(hs[:n])
+
+
 def default_params():
     p = Params()
     lib().sfa_params_default(C.byref(p))
