@@ -221,6 +221,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             const bool direct_outer = L.fused && active == all && !getenv("SFA_NO_DIRECT_OPERANDS");
             if (!direct_outer) launch_zero_planes(c, g, L.plane(P_DU), 2);                                   // :323-324 (du, dv adjacent)
             unsigned long long in_active = active;
+            bool outer_done = false;
             for (int inner = 0; inner < p.niter_inner; inner++) {
                 Geo gi = g;
                 gi.active = in_active;
@@ -259,7 +260,11 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                                             p.niter_solver, p.sor_omega, false));
                         }
                 }
-                if (direct) {
+                if (direct && inner + 1 == p.niter_inner) {
+                    // last inner iteration: nothing reads its inner norms or du/dv; the flow update and the outer update run as one pass
+                    launch_update_outer_x(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, red);   // :396-397 + :412-429
+                    outer_done = true;
+                } else if (direct) {
                     const bool keep = inner + 1 < p.niter_inner;      // du, dv are read again only by a further inner iteration
                     launch_update_inner_x(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, first_zero ? nullptr : L.plane(P_ODU),
                                           first_zero ? nullptr : L.plane(P_ODV), keep ? L.plane(P_DU) : nullptr, keep ? L.plane(P_DV) : nullptr, red);   // :371-402
@@ -277,7 +282,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                     if (!in_active) break;
                 }
             }
-            launch_update_outer(c, g, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);      // :412-429
+            if (!outer_done) launch_update_outer(c, g, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);      // :412-429
             const bool last_iter = (alter == p.niter_alter - 1 && outer == p.niter_outer - 1);
             if (use_thres_out || last_iter) {
                 SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));

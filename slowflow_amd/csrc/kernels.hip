@@ -1018,6 +1018,31 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ u
         partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
     }
 }
+// last inner iteration of an outer one, solver result still in its x plane: flow update (:396-397) and the outer change norms and
+// wx <- uu (:412-429) in one pass; the inner norms are not formed (nobody reads them after the last inner iteration)
+__global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ uu, float *__restrict__ vv, float *__restrict__ wx, float *__restrict__ wy,
+                                                            const unsigned long long *__restrict__ xs, long ent, int RP, int G, double *__restrict__ partial, Geo g) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * BX + threadIdx.x;
+    double sa = 0, sb = 0;
+    if (elem_active(g.active, b) && x < g.w)
+        for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
+            const size_t o = b * g.es + (size_t)y * g.pitch + x;
+            const unsigned long long xv = xs[(size_t)b * ent + (size_t)(x + y + G) * RP + (y + G)];
+            const float d = __uint_as_float((unsigned)(xv & 0xffffffffu)), e = __uint_as_float((unsigned)(xv >> 32));
+            const float ox = wx[o], oy = wy[o];
+            const float u = ox + d, v = oy + e;                                           // :396-397
+            sa += (double)fabsf(u - ox);                                                 // :415-419
+            sb += (double)fabsf(v - oy);
+            uu[o] = u; vv[o] = v;
+            wx[o] = u; wy[o] = v;                                                         // :428-429
+        }
+    block_sum2(sa, sb);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
+    }
+}
 __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx, float *__restrict__ wy, const float *__restrict__ uu, const float *__restrict__ vv,
                                                           double *__restrict__ partial, Geo g) {
     const int b = blockIdx.z;
@@ -1071,6 +1096,12 @@ void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_inner_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, old_du, old_dv, du_out, dv_out, partials_of(c), g);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
+}
+void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red) {
+    dim3 grid = red_grid(g, g.nb);
+    const int per_elem = grid.x * grid.y;
+    hipLaunchKernelGGL(k_update_outer_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
 }
 void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red) {

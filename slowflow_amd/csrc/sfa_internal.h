@@ -165,6 +165,8 @@ void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const f
 // du,dv are not stored
 void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const SorOperandOut &x, const float *old_du,
                            const float *old_dv, float *du_out, float *dv_out, double *red);
+// flow update of the LAST inner iteration straight from the x plane, fused with the outer update below (uu, vv, wx, wy all written)
+void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red);
 // sum|uu-wx|, sum|vv-wy|; wx<-uu, wy<-vv (variational_mt.cpp:412-429)
 void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red);
 void launch_copy_planes(sfa_ctx *c, const Geo &g, float *dst, const float *src, int nplanes, long dst_es, long src_es);
