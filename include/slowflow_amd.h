@@ -160,6 +160,9 @@ int sfa_add_data_and_match(sfa_ctx *ctx, float *a11, float *a12, float *a22, flo
 /* pyramid arithmetic (cv::GaussianBlur / cv::resize as used at variational_mt.cpp:607,611,672,711) */
 int sfa_gaussian_blur(sfa_ctx *ctx, float *dst, const float *src, int w, int h, int stride, float sigma);
 int sfa_resize_linear(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride);
+/* optional presmoothing of level 0 (cfg `sigma` > 0, variational_mt.cpp:590-597): gaussian_filter (image.c:310-348) through
+ * convolve_horiz / convolve_vert (image.c:529-644; orders 1 and 2 take the 3 / 5-tap routines) */
+int sfa_gaussian_presmooth(sfa_ctx *ctx, float *dst, const float *src, int w, int h, int stride, float sigma);
 /* cv::resize(src, dst, Size(0,0), fx, fy, INTER_LINEAR) as the driver's input rescaling uses it (slow_flow.cpp:552): the caller
  * passes dw = cvRound(sw*fx), dh = cvRound(sh*fy); source coordinate = (dst + 0.5) / fx - 0.5 */
 int sfa_resize_linear_fx(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double fx, double fy);

@@ -116,6 +116,12 @@ class Oracle:
         h, stride = wx.shape
         self.lib.orc_variational_2frame(fptr(wx), fptr(wy), fptr(im1), fptr(im2), C.byref(p), w, h, stride)
 
+    def gaussian_presmooth(self, src, w, sigma):
+        h, stride = src.shape
+        dst = plane(h, stride)
+        self.lib.orc_gaussian_presmooth(fptr(dst), fptr(src), w, h, stride, C.c_float(sigma))
+        return dst
+
     def grid_cut(self, d0, d1, alpha, w):
         h, stride = d0.shape
         occ = plane(h, stride)
@@ -304,6 +310,21 @@ class RefLib:
         fn = self.lib.convolve_horiz if horiz else self.lib.convolve_vert
         d_i, s_i = as_image(dst, w), as_image(s2, w)
         fn(C.byref(d_i), C.byref(s_i), conv)
+        return dst
+
+    def gaussian_presmooth(self, src, w, sigma):
+        """gaussian_filter (image.c:310) + convolution_new(even) + convolve_horiz, convolve_vert: what variational_mt.cpp:590-597 applies per channel"""
+        h, stride = src.shape
+        L = self.lib
+        L.gaussian_filter.restype = _f
+        L.gaussian_filter.argtypes = [C.c_float, C.POINTER(C.c_int)]
+        n = C.c_int()
+        filt = L.gaussian_filter(C.c_float(sigma), C.byref(n))
+        conv = L.convolution_new(n.value, filt, 1)
+        s2 = aligned_zeros(src.shape); s2[...] = src
+        tmp, dst = plane(h, stride), plane(h, stride)
+        L.convolve_horiz(C.byref(as_image(tmp, w)), C.byref(as_image(s2, w)), conv)
+        L.convolve_vert(C.byref(as_image(dst, w)), C.byref(as_image(tmp, w)), conv)
         return dst
 
     def variational_2frame(self, wx, wy, im1, im2, w, p):

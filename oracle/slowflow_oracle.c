@@ -118,9 +118,7 @@ static void deriv_coeffs(int order, float c[5]) {
 static inline int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
 
 /* image.c:460-526: replicate border on both sides (the shifted copies src_m1/src_m2/src_p1/src_p2) */
-void orc_convolve_horiz(float *dst, const float *src, int w, int h, int stride, int order) {
-    float c[5];
-    deriv_coeffs(order, c);
+static void conv_horiz_fast(float *dst, const float *src, int w, int h, int stride, int order, const float c[5]) {
     for (int y = 0; y < h; y++) {
         const float *s = src + (size_t)y * stride;
         float *d = dst + (size_t)y * stride;
@@ -137,10 +135,14 @@ void orc_convolve_horiz(float *dst, const float *src, int w, int h, int stride, 
     }
 }
 
-/* image.c:400-458: border rows fold the coefficients at run time in fp32 */
-void orc_convolve_vert(float *dst, const float *src, int w, int h, int stride, int order) {
+void orc_convolve_horiz(float *dst, const float *src, int w, int h, int stride, int order) {
     float c[5];
     deriv_coeffs(order, c);
+    conv_horiz_fast(dst, src, w, h, stride, order, c);
+}
+
+/* image.c:400-458: border rows fold the coefficients at run time in fp32 */
+static void conv_vert_fast(float *dst, const float *src, int w, int h, int stride, int order, const float c[5]) {
     for (int y = 0; y < h; y++) {
         float *d = dst + (size_t)y * stride;
         const float *s0 = src + (size_t)y * stride;
@@ -166,6 +168,12 @@ void orc_convolve_vert(float *dst, const float *src, int w, int h, int stride, i
             }
         }
     }
+}
+
+void orc_convolve_vert(float *dst, const float *src, int w, int h, int stride, int order) {
+    float c[5];
+    deriv_coeffs(order, c);
+    conv_vert_fast(dst, src, w, h, stride, order, c);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1120,7 +1128,7 @@ static int stride_of(int w) { return ((w + 3) / 4) * 4; }                      /
 
 /* image.c:310-348 + :351-361 + generic convolve_horiz/vert :537-644 -- the optional Gaussian
  * presmoothing of level 0 (cfg sigma > 0, variational_mt.cpp:590-597) */
-static void gaussian_presmooth(float *dst, const float *src, int w, int h, int stride, float sigma) {
+void orc_gaussian_presmooth(float *dst, const float *src, int w, int h, int stride, float sigma) {
     const int order = gaussian_filter_order(sigma);
     const int n = 2 * order + 1;
     float *data = (float *)malloc(sizeof(float) * n), *coeffs = (float *)malloc(sizeof(float) * n), *accu = (float *)malloc(sizeof(float) * n);
@@ -1135,6 +1143,12 @@ static void gaussian_presmooth(float *dst, const float *src, int w, int h, int s
     const float *coeff = coeffs + order, *coeff_accu = accu + order;
     const int i0 = -order, i1 = order;
     float *tmp = plane_alloc((size_t)stride * h);
+    if (order <= 2) {                                           /* convolve_horiz / _vert dispatch on the order: image.c:529-535, 580-586 */
+        conv_horiz_fast(tmp, src, w, h, stride, order, coeffs);
+        conv_vert_fast(dst, tmp, w, h, stride, order, coeffs);
+        free(tmp); free(data); free(coeffs); free(accu);
+        return;
+    }
     /* horizontal, image.c:545-578 */
     for (int j = 0; j < h; j++) {
         const float *al = src + (size_t)j * stride;
@@ -1228,7 +1242,7 @@ int orc_variational(const orc_params *p, float *wx, float *wy, float *const *fra
             pyr[l][s] = plane_alloc(3 * lplane);
             if (l == 0) {
                 if (p->presmooth_sigma > 0) {
-                    for (int k = 0; k < 3; k++) gaussian_presmooth(pyr[0][s] + k * lplane, frames[s] + k * lplane, w, h, stride, p->presmooth_sigma);
+                    for (int k = 0; k < 3; k++) orc_gaussian_presmooth(pyr[0][s] + k * lplane, frames[s] + k * lplane, w, h, stride, p->presmooth_sigma);
                 } else memcpy(pyr[0][s], frames[s], 3 * lplane * sizeof(float));       /* :599 */
             } else {
                 const int pw = ws[l - 1], ph = hs[l - 1], ps = l - 1 == 0 ? stride : stride_of(pw);

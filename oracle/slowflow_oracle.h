@@ -150,6 +150,9 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
 void orc_gaussian_blur_cv(float *dst, const float *src, int w, int h, int stride, float sigma);
 void orc_resize_linear_cv(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride);
 int  orc_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs);
+/* optional presmoothing of level 0 (cfg sigma > 0, variational_mt.cpp:590-597): gaussian_filter (image.c:310-348) applied with the
+ * generic convolve_horiz / convolve_vert (image.c:537-644).  Pinned bit-exact against the compiled image.c. */
+void orc_gaussian_presmooth(float *dst, const float *src, int w, int h, int stride, float sigma);
 
 /* variational_mt.cpp:526-784 (chw == NULL: all ones, :534-539; as in the reference the level-0
  * weight planes are NOT rescaled per level) */

@@ -65,7 +65,7 @@ EXPORTS = [
     "sfa_device_count", "sfa_ctx_create", "sfa_ctx_destroy", "sfa_last_error", "sfa_ctx_sync", "sfa_params_default",
     "sfa_variational", "sfa_variational_2frame", "sfa_params_2frame_default", "variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sor_coupled",
     "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
-    "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_resize_linear_fx", "sfa_pyramid_sizes",
+    "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_resize_linear_fx", "sfa_gaussian_presmooth", "sfa_pyramid_sizes",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_mpix_iters",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
     "sfa_profile_enable", "sfa_profile_read", "sfa_timer_start", "sfa_timer_stop",
@@ -225,6 +225,12 @@ class Context:
         sh, sstride = src.shape
         dst = np.zeros((dh, stride_of(dw)), np.float32)
         self._ck(lib().sfa_resize_linear(self.h, fptr(dst), dw, dh, stride_of(dw), fptr(src), sw, sh, sstride), "sfa_resize_linear")
+        return dst
+
+    def gaussian_presmooth(self, src, w, sigma):
+        h, stride = src.shape
+        dst = np.zeros_like(src)
+        self._ck(lib().sfa_gaussian_presmooth(self.h, fptr(dst), fptr(src), w, h, stride, C.c_float(sigma)), "sfa_gaussian_presmooth")
         return dst
 
     def resize_linear_fx(self, src, sw, fx, fy):

@@ -666,6 +666,18 @@ int sfa_resize_linear(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, con
     return sfa_ctx_sync(ctx);
 }
 
+int sfa_gaussian_presmooth(sfa_ctx *ctx, float *dst, const float *src, int w, int h, int stride, float sigma) {
+    CHECK_ARGS(ctx && dst && src && w > 0 && h > 0 && stride >= w && sigma > 0, "bad arguments");
+    const int order = std::max(1, (int)floor(3 * sigma) + 1);
+    CHECK_ARGS(order <= 16 && w > 2 * order && h > 2 * order, "image smaller than the filter (image.c:545-574 assumes width > 2*order)");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 3));
+    SFA_TRY(s.up(0, src, stride));
+    launch_presmooth(ctx, s.geo(), s.plane(1), s.plane(2), s.plane(0), 1, sigma);
+    SFA_TRY(s.down(dst, stride, 1));
+    return sfa_ctx_sync(ctx);
+}
+
 int sfa_resize_linear_fx(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double fx, double fy) {
     CHECK_ARGS(ctx && dst && src && dw > 0 && dh > 0 && sw > 0 && sh > 0 && dstride >= dw && sstride >= sw && fx > 0 && fy > 0, "bad arguments");
     SFA_HIP(ctx, hipSetDevice(ctx->device));

@@ -1341,6 +1341,35 @@ __global__ void k_presmooth_v(float *__restrict__ dst, const float *__restrict__
     }
     dst[b * g.es + pl * g.pl + (size_t)i * st + j] = sum;
 }
+// filters of order 1 and 2 take the 3 / 5-tap routines of image.c (:529-535, :580-586 dispatch on conv->order) -- replicated columns,
+// folded row coefficients -- with the Gaussian's coefficients
+struct Coef5 { float c[5]; };
+__global__ void k_presmooth_small(float *__restrict__ dst, const float *__restrict__ src, Geo g, int nplanes, Coef5 k, int order, int horiz) {
+    const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const float *s = src + b * g.es + pl * g.pl;
+    const int w = g.w, h = g.h;
+    auto f = [&](int xx, int yy) { return s[(size_t)yy * g.pitch + xx]; };
+    const float *c = k.c;
+    float v;
+    if (horiz) {
+        if (order == 2) v = c[0] * f(clampi(x - 2, 0, w - 1), y) + c[1] * f(clampi(x - 1, 0, w - 1), y) + c[2] * f(x, y) + c[3] * f(clampi(x + 1, 0, w - 1), y) +
+                            c[4] * f(clampi(x + 2, 0, w - 1), y);                        // image.c:521
+        else            v = c[0] * f(clampi(x - 1, 0, w - 1), y) + c[1] * f(x, y) + c[2] * f(clampi(x + 1, 0, w - 1), y);   // image.c:482
+    } else if (order == 2) {                                                             // image.c:433-457
+        if (y == 0) v = (c[0] + c[1] + c[2]) * f(x, 0) + c[3] * f(x, 1) + c[4] * f(x, 2);
+        else if (y == 1) v = (c[0] + c[1]) * f(x, 0) + c[2] * f(x, 1) + c[3] * f(x, 2) + c[4] * f(x, 3);
+        else if (y == h - 2) v = c[0] * f(x, y - 2) + c[1] * f(x, y - 1) + c[2] * f(x, y) + (c[3] + c[4]) * f(x, y + 1);
+        else if (y == h - 1) v = c[0] * f(x, y - 2) + c[1] * f(x, y - 1) + (c[2] + c[3] + c[4]) * f(x, y);
+        else v = c[0] * f(x, y - 2) + c[1] * f(x, y - 1) + c[2] * f(x, y) + c[3] * f(x, y + 1) + c[4] * f(x, y + 2);
+    } else {                                                                             // image.c:407-422
+        if (y == 0) v = (c[0] + c[1]) * f(x, 0) + c[2] * f(x, 1);
+        else if (y == h - 1) v = c[0] * f(x, y - 1) + (c[1] + c[2]) * f(x, y);
+        else v = c[0] * f(x, y - 1) + c[1] * f(x, y) + c[2] * f(x, y + 1);
+    }
+    dst[b * g.es + pl * g.pl + (size_t)y * g.pitch + x] = v;
+}
 void launch_presmooth(sfa_ctx *c, const Geo &g, float *dst, float *tmp, const float *src, int nplanes, float sigma) {
     PreTaps t;
     int order = (int)floor(3 * sigma) + 1;                                               // image.c:320
@@ -1357,6 +1386,13 @@ void launch_presmooth(sfa_ctx *c, const Geo &g, float *dst, float *tmp, const fl
     for (int i = 0; i <= order; i++) t.c[order - i] = t.c[order + i] = half[i];          // image.c:355-357
     float acc = 0.0f;
     for (int i = 0; i <= order; i++) { acc += t.c[i]; t.accu[2 * order - i] = t.accu[i] = acc; }   // image.c:358-361
+    if (order <= 2) {
+        Coef5 k;
+        for (int i = 0; i < 5; i++) k.c[i] = i < n ? t.c[i] : 0.0f;
+        hipLaunchKernelGGL(k_presmooth_small, grid2d(g, nplanes), block2d(), 0, c->stream, tmp, src, g, nplanes, k, order, 1);
+        hipLaunchKernelGGL(k_presmooth_small, grid2d(g, nplanes), block2d(), 0, c->stream, dst, tmp, g, nplanes, k, order, 0);
+        return;
+    }
     hipLaunchKernelGGL(k_presmooth_h, grid2d(g, nplanes), block2d(), 0, c->stream, tmp, src, g, nplanes, t);
     hipLaunchKernelGGL(k_presmooth_v, grid2d(g, nplanes), block2d(), 0, c->stream, dst, tmp, g, nplanes, t);
 }

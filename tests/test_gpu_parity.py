@@ -746,3 +746,23 @@ def test_fused_pyramid_step_is_blur_then_resize(ctx, oracle, monkeypatch, w, h, 
         ctx.variational(ps, wx, wy, [c_(f) for f in frames], w, None)
         out.append((wx, wy))
     assert np.array_equal(valid(out[0][0], w), valid(out[1][0], w)) and np.array_equal(valid(out[0][1], w), valid(out[1][1], w))
+
+
+@pytest.mark.parametrize("sigma", [0.3, 0.5, 0.8, 1.7])
+def test_variational_with_presmoothing(ctx, oracle, sigma):
+    """cfg `sigma` > 0: level 0 is presmoothed with gaussian_filter + the generic / 3-tap / 5-tap convolutions of image.c (the oracle's
+    presmoothing is pinned bit-exact against the compiled image.c); orders 1 (sigma .3), 2 (.5), 3 (.8), 6 (1.7)"""
+    w, h = 130, 98
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=13)
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, layers=3, niter_outer=3, presmooth_sigma=sigma)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h, level_only=False)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_UV, d
+
+
+@pytest.mark.parametrize("w,h", [(67, 45), (130, 98)])
+@pytest.mark.parametrize("sigma", [0.3, 0.5, 0.8, 1.0, 2.3])
+def test_gaussian_presmooth_stage(ctx, oracle, w, h, sigma):
+    rng = np.random.default_rng(int(sigma * 10) + w)
+    src = noise_plane(rng, w, h, 0, 255)
+    assert np.array_equal(valid(oracle.gaussian_presmooth(src, w, sigma), w), valid(ctx.gaussian_presmooth(c_(src), w, sigma), w))

@@ -270,3 +270,12 @@ def test_two_frame_variational_end_to_end(oracle, reflib, w, h, kw):
     oracle.variational_2frame(wxo2, wyo2, a, b, w, p)
     assert np.array_equal(valid(wxr, w), valid(wxo2, w)) and np.array_equal(valid(wyr, w), valid(wyo2, w))
     assert np.abs(valid(wxr, w) - valid(wx0, w)).max() > 1e-3      # it did move
+
+
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (130, 98)])
+@pytest.mark.parametrize("sigma", [0.5, 0.8, 1.0, 2.3])
+def test_gaussian_presmooth_bit_exact(oracle, reflib, w, h, sigma):
+    """cfg sigma > 0 (variational_mt.cpp:590-597): gaussian_filter + the generic convolve_horiz / convolve_vert of image.c"""
+    rng = np.random.default_rng(int(sigma * 10) + w)
+    src = noise_plane(rng, w, h, 0, 255)
+    assert np.array_equal(valid(oracle.gaussian_presmooth(src, w, sigma), w), valid(reflib.gaussian_presmooth(src, w, sigma), w))
