@@ -766,3 +766,16 @@ def test_gaussian_presmooth_stage(ctx, oracle, w, h, sigma):
     rng = np.random.default_rng(int(sigma * 10) + w)
     src = noise_plane(rng, w, h, 0, 255)
     assert np.array_equal(valid(oracle.gaussian_presmooth(src, w, sigma), w), valid(ctx.gaussian_presmooth(c_(src), w, sigma), w))
+
+
+def test_smoothness_full_size_exact(ctx, oracle):
+    """~1.8 million psi' evaluations of the default penalty through the fast fp64 form with its exact fallback: every bit as the oracle"""
+    w, h = 1024, 436
+    rng = np.random.default_rng(77)
+    for scale in (2.0, 1e-3, 40.0):
+        uu, vv = noise_plane(rng, w, h, -scale, scale), noise_plane(rng, w, h, -scale, scale)
+        dps = noise_plane(rng, w, h, 0.05, 0.5)
+        a = oracle.smoothness(1, uu, vv, dps, w, 4.0, orc.Penalty(1, 0.001, 0.5))
+        b = ctx.smoothness(1, c_(uu), c_(vv), c_(dps), w, 4.0, sfa.Penalty(1, 0.001, 0.5))
+        for x, y in zip(a, b):
+            assert np.array_equal(valid(x, w), valid(y, w))
