@@ -257,7 +257,8 @@ SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1"}, "task_f2": {
 
 
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))
-@pytest.mark.parametrize("w,h,K", [(67, 45, 6), (130, 98, 12), (300, 70, 30), (64, 200, 6), (1024, 436, 30), (2, 2, 6), (700, 5, 30), (200, 150, 10)])
+@pytest.mark.parametrize("w,h,K", [(67, 45, 6), (130, 98, 12), (300, 70, 30), (64, 200, 6), (1024, 436, 30), (2, 2, 6), (700, 5, 30), (200, 150, 10),
+                                   (150, 130, 7), (90, 140, 15), (129, 65, 16), (100, 100, 1), (257, 33, 31)])
 def test_sor_kernel_variants(ctx, oracle, monkeypatch, variant, w, h, K):
     """every solver kernel (task pipeline with 1/2/3 fused sweeps per wave, band pipeline with 1/2/3) gives the
     raster-order result bit for bit, for each element of a batch of two different systems"""
