@@ -496,18 +496,19 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
             s0 += CH;
             // tell wave+1 / wave-1 (LDS words are written in order behind the ring writes)
             __hip_atomic_store(&lprog[wave], (unsigned)s0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // band b+1 (HBM): the previous macro chunk's edge store is older than the CH * 2 operand loads issued since (in-order
+            // vmcnt), so this counted wait covers it without draining the prefetch; its progress word goes out now, CH steps late
+            if (q == 0 && publishes && m > 0) {
+                if (CH >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(gmine, (unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         // lane 63's iterates of this macro chunk: sweep f, steps s0-MC .. s0-1 are MC consecutive columns of edge row f, one
         // 64-byte piece per sweep in a single store (instead of F stores per step)
         if (publishes && lane < F * MC) {
             const int fi = lane / MC, j = lane % MC;
             st_x(e_mine + (long)fi * a.Wp + (s0 - MC - 63 - fi + j), estage[fi][j]);
-        }
-        // ---- one macro chunk late, band b+1 (HBM): the previous macro chunk's edge store is older than the >= 16
-        // operand loads issued since (in-order vmcnt), so this counted wait covers it without draining the prefetch ----
-        if (publishes && !last) {
-            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-            if (m > 0 && lane == 0) __hip_atomic_store(gmine, (unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (has_up && !last && !pre) {
             known_up = wait_ge(g_up, need_up(m + 1), a.err);
