@@ -409,16 +409,17 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
         if (has_up) {
             known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up));
             if (!FIRST) known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2));
-            if (!last) {
-                pend_up = __hip_atomic_load(g_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!FIRST) pend_up2 = __hip_atomic_load(g_up2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             pre = !last && ready(m + 1);
         }
         const unsigned long long tv_cur = tv;
         if (pre && tv_lane) tv = ld_x(e_up + (s0 + MC) + tv_off);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
+            // the band above: look at its progress words as late as possible (one chunk before the next macro chunk decides on them)
+            if (q == NQ - 1 && has_up && !last) {
+                pend_up = __hip_atomic_load(g_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!FIRST) pend_up2 = __hip_atomic_load(g_up2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (!FIRST) {                                        // the previous stage: its last iterate through the LDS ring
                 const unsigned need = (unsigned)min(s0 + CH - 1 + F, NSP);
                 if (!wait_lds_ge(&lprog[wave - 1], need, a.err)) return;
