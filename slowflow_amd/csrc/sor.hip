@@ -663,7 +663,12 @@ static int band_shape(int K, int nb) {
     if (fits(1)) return 1;
     return 0;
 }
-constexpr int kBandCH = 2, kBandMC = 8;        // operand ring / LDS hand-over every 2 steps, HBM hand-over every 8
+// steps per operand refill / LDS hand-over (= depth of the operand prefetch) and per HBM hand-over to the band below.  Three steps
+// of prefetch hide the Infinity-Cache latency of the first-touch operand rows under load (2 -> 3: -6 .. -10 % solve time);
+// for the default F = 3 only: (F + 1) * MC lanes fetch the band above's values (F = 5: MC <= 10), and the 15 / 16-wave shapes of
+// F = 2 / 1 have 128 registers per lane, which the deeper ring does not fit.
+constexpr int band_ch(int F) { return F == 3 ? 3 : 2; }
+constexpr int band_mc(int F) { return F == 3 ? 12 : 8; }
 static int band_ring(int F) { return F == 2 ? 8 : 16; }      // LDS ring slots per wave pair, power of two
 static size_t band_window(int F) { return F > 1 ? (size_t)2 * (F - 1) * (64 + F - 1) * 32 : 0; }   // operand window bytes per wave
 
@@ -681,7 +686,7 @@ static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
 int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     int F_, CH_;
     const int band_ = band_shape(K_, nb_);
-    if (band_) { F_ = band_; CH_ = kBandMC; }
+    if (band_) { F_ = band_; CH_ = band_mc(band_); }
     else sor_shape(K_, nb_ * ((h_ + K_ - 1 + 63) / 64) * K_, F_, CH_);
     if (ctx == c && w == w_ && h == h_ && K == K_ && nb == nb_ && F == F_ && CHK == CH_ && band == band_) return SFA_OK;
     ctx = c; w = w_; h = h_; K = K_; nb = nb_; F = F_; CHK = CH_; band = band_;
@@ -768,14 +773,14 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         ba.sa = p.sa; ba.sb = p.sb; ba.x = p.x; ba.edge = (unsigned long long *)ws.edge.p; ba.gflags = p.flags; ba.err = c->d_err;
         ba.ent = ws.ent; ba.edge_job = ws.edge_job; ba.W = g.w; ba.H = g.h; ba.K = K; ba.NB = ws.NB; ba.NW = ws.NG; ba.RP = ws.RP; ba.G = ws.G;
         ba.lead = band_ring(ws.F);
-        if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(kBandCH + 2, std::min(atoi(e), band_ring(ws.F)));
+        if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(band_ch(ws.F) + 2, std::min(atoi(e), band_ring(ws.F)));
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
-        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F) + (size_t)ws.NG * ws.F * kBandMC * 8;
-        if (ws.F == 5)      hipLaunchKernelGGL((k_sor_band<5, 6, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
-        else if (ws.F == 3) hipLaunchKernelGGL((k_sor_band<3, 10, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
-        else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, kBandCH, kBandMC, 8>), bgrid, bblock, lds, c->stream, ba);
-        else                hipLaunchKernelGGL((k_sor_band<1, 16, kBandCH, kBandMC, 16>), bgrid, bblock, lds, c->stream, ba);
+        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F) + (size_t)ws.NG * ws.F * band_mc(ws.F) * 8;
+        if (ws.F == 5)      hipLaunchKernelGGL((k_sor_band<5, 6, band_ch(5), band_mc(5), 16>), bgrid, bblock, lds, c->stream, ba);
+        else if (ws.F == 3) hipLaunchKernelGGL((k_sor_band<3, 10, band_ch(3), band_mc(3), 16>), bgrid, bblock, lds, c->stream, ba);
+        else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, band_ch(2), band_mc(2), 8>), bgrid, bblock, lds, c->stream, ba);
+        else                hipLaunchKernelGGL((k_sor_band<1, 16, band_ch(1), band_mc(1), 16>), bgrid, bblock, lds, c->stream, ba);
     } else {
     const dim3 sgrid(g.nb * ws.ntasks), sblock(64);
     if (ws.F == 1)                      hipLaunchKernelGGL((k_sor_solve<1, 8>), sgrid, sblock, 0, c->stream, a);
