@@ -667,7 +667,7 @@ static int band_shape(int K, int nb) {
 // of prefetch hide the Infinity-Cache latency of the first-touch operand rows under load (2 -> 3: -6 .. -10 % solve time);
 // for the default F = 3 only: (F + 1) * MC lanes fetch the band above's values (F = 5: MC <= 10), and the 15 / 16-wave shapes of
 // F = 2 / 1 have 128 registers per lane, which the deeper ring does not fit.
-constexpr int band_ch(int F) { return F == 3 ? 3 : 2; }
+constexpr int band_ch(int F) { return F == 3 ? 3 : F == 5 ? 4 : 2; }
 constexpr int band_mc(int F) { return F == 3 ? 12 : 8; }
 static int band_ring(int F) { return F == 2 ? 8 : 16; }      // LDS ring slots per wave pair, power of two
 static size_t band_window(int F) { return F > 1 ? (size_t)2 * (F - 1) * (64 + F - 1) * 32 : 0; }   // operand window bytes per wave
