@@ -734,12 +734,13 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     constexpr int TR = TY + 2 * DT_H, AT_R1 = TY + 4, NR = NT / 64, NP = TY / NR;
     // one LDS block: staged planes during the terms, the operand tile of the solver afterwards
     constexpr int NM = TR * DT_W, N1 = AT_R1 * AT_W1;
-    __shared__ __attribute__((aligned(16))) float lds[6 * NM + 6 * N1];
-    float(*sM)[NM] = reinterpret_cast<float(*)[NM]>(lds);                       // M  = (I1+I2)/2, halo 4 (rows x DT_W)
-    float(*sZ)[NM] = reinterpret_cast<float(*)[NM]>(lds + 3 * NM);              // Iz = I1-I2, same geometry (aligned 16-byte rows)
-    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 6 * NM);              // Ix, Iy: halo 2 (rows x AT_W1)
-    float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 6 * NM + 3 * N1);
-    static_assert(TY * 65 * 10 <= 6 * NM + 6 * N1, "operand tile must fit the staging block");
+    // terms are staged two at a time (one exposed global-load latency and one barrier less per pair)
+    __shared__ __attribute__((aligned(16))) float lds[12 * NM + 6 * N1];
+    float(*sM2)[NM] = reinterpret_cast<float(*)[NM]>(lds);                      // [2 terms][3 ch] M  = (I1+I2)/2, halo 4 (rows x DT_W)
+    float(*sZ2)[NM] = reinterpret_cast<float(*)[NM]>(lds + 6 * NM);             // [2 terms][3 ch] Iz = I1-I2, same geometry (aligned 16-byte rows)
+    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM);             // Ix, Iy of the term in work: halo 2 (rows x AT_W1)
+    float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM + 3 * N1);
+    static_assert(TY * 65 * 10 <= 12 * NM + 6 * N1, "operand tile must fit the staging block");
     static_assert(DT_W % 4 == 0 && AT_W1 % 4 == 0 && NM % 4 == 0 && N1 % 4 == 0, "16-byte LDS rows");
     const int b = blockIdx.z;
     if (!elem_active(g.active, b)) return;
@@ -776,12 +777,20 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     constexpr int QM = DT_W / 4, Q1 = AT_W1 / 4;                     // float4 quads per staged row
     for (int t = 0; t < a.n; t++) {
         const Term &T = a.t[t];
-        const float *pa = base + eb + T.i1_off, *pb = base + eb + T.i2_off;
+        const int ub = t & 1;                                      // staging buffer of this term
+        float(*sM)[NM] = sM2 + 3 * ub;
+        float(*sZ)[NM] = sZ2 + 3 * ub;
+        if (ub == 0) {
         __syncthreads();                                           // the staged planes are free again
-        // stage 0: M and Iz (halo 4) of the three channels, one float4 of a row per item; columns outside the image are
-        // replicated (clamped source column), rows outside are never read
-        for (int item = threadIdx.x; item < TR * 3 * QM; item += NT) {
-            const int q = item % QM, ch = (item / QM) % 3, ly = item / (3 * QM);
+        // stage 0 for this term and the next: M and Iz (halo 4) of the three channels, one float4 of a row per item; columns outside
+        // the image are replicated (clamped source column), rows outside are never read
+        const int npair = t + 1 < a.n ? 2 : 1;
+        for (int item = threadIdx.x; item < npair * TR * 3 * QM; item += NT) {
+            const int q = item % QM, ch = (item / QM) % 3, ly = (item / (3 * QM)) % TR, uu_ = item / (TR * 3 * QM);
+            const Term &TT = a.t[t + uu_];
+            const float *pa = base + eb + TT.i1_off, *pb = base + eb + TT.i2_off;
+            float(*sM)[NM] = sM2 + 3 * uu_;
+            float(*sZ)[NM] = sZ2 + 3 * uu_;
             const int gy = y0 + ly, gx = x0 + 4 * q;
             if (gy < 0 || gy >= g.h) continue;
             const float *ra = pa + ch * g.pl + (size_t)gy * g.pitch, *rb = pb + ch * g.pl + (size_t)gy * g.pitch;
@@ -798,7 +807,8 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 make_float4(0.5f * (vb.x + va.x), 0.5f * (vb.y + va.y), 0.5f * (vb.z + va.z), 0.5f * (vb.w + va.w));        // variational_mt.cpp:120
             *reinterpret_cast<float4 *>(&sZ[ch][ly * DT_W + 4 * q]) = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);   // :122
         }
-        __syncthreads();
+        }
+        __syncthreads();                                           // staged planes complete / the previous term is done with Ix, Iy
         // stage 1: Ix, Iy on the halo-2 region, four columns per item (two aligned quads of M per tap row)
         for (int item = threadIdx.x; item < AT_R1 * 3 * Q1; item += NT) {
             const int q = item % Q1, ch = (item / Q1) % 3, ly = item / (3 * Q1);
