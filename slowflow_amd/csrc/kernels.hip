@@ -536,6 +536,9 @@ struct Px {   // per-pixel inputs of one term
     float wk[3], ix[3], iy[3], iz[3], ixx[3], ixy[3], iyy[3], ixz[3], iyz[3];
 };
 
+// ZUV: du = dv = 0 (first inner iteration): the flow products in the residuals are +-0 and only the squares of the residuals are used,
+// so r = wk * Iz (etc.) gives the same bits as the full expression
+template <bool ZUV = false>
 __device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u, float v, float hd, float hg, float s, int dt_norm,
                                           const PenaltyDev &color, const PenaltyDev &grad) {
     const float factor = s, factorp1 = s + 1;
@@ -543,7 +546,8 @@ __device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u,
         float r[3], tx[3], ty[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            r[k] = p.wk[k] * (p.iz[k] + p.ix[k] * factor * u + p.iy[k] * factor * v - p.ix[k] * factorp1 * u - p.iy[k] * factorp1 * v);   // :190-192
+            r[k] = ZUV ? p.wk[k] * p.iz[k]
+                       : p.wk[k] * (p.iz[k] + p.ix[k] * factor * u + p.iy[k] * factor * v - p.ix[k] * factorp1 * u - p.iy[k] * factorp1 * v);   // :190-192
             tx[k] = factor * p.ix[k] - factorp1 * p.ix[k];                               // :229-234
             ty[k] = factor * p.iy[k] - factorp1 * p.iy[k];
         }
@@ -578,8 +582,10 @@ __device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u,
     float r[6], X[3], Y[3], Z[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {                                                        // :269-276, 316-324
-        r[2 * k] = p.wk[k] * (p.ixz[k] + p.ixx[k] * factor * u + p.ixy[k] * factor * v - p.ixx[k] * factorp1 * u - p.ixy[k] * factorp1 * v);
-        r[2 * k + 1] = p.wk[k] * (p.iyz[k] + p.ixy[k] * factor * u + p.iyy[k] * factor * v - p.ixy[k] * factorp1 * u - p.iyy[k] * factorp1 * v);
+        r[2 * k] = ZUV ? p.wk[k] * p.ixz[k]
+                       : p.wk[k] * (p.ixz[k] + p.ixx[k] * factor * u + p.ixy[k] * factor * v - p.ixx[k] * factorp1 * u - p.ixy[k] * factorp1 * v);
+        r[2 * k + 1] = ZUV ? p.wk[k] * p.iyz[k]
+                           : p.wk[k] * (p.iyz[k] + p.ixy[k] * factor * u + p.iyy[k] * factor * v - p.ixy[k] * factorp1 * u - p.iyy[k] * factorp1 * v);
         X[k] = factor * p.ixx[k] - factorp1 * p.ixx[k];
         Y[k] = factor * p.iyy[k] - factorp1 * p.iyy[k];
         Z[k] = factor * p.ixy[k] - factorp1 * p.ixy[k];
@@ -618,6 +624,7 @@ __device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u,
     }
 }
 
+template <bool ZUV = false>
 __device__ __forceinline__ void term_ref(Acc &A, const Px &p, float m, float u, float v, float hd, float hg, float s, int dt_norm,
                                          const PenaltyDev &color, const PenaltyDev &grad) {
     float factor = s;
@@ -626,7 +633,7 @@ __device__ __forceinline__ void term_ref(Acc &A, const Px &p, float m, float u, 
     if (hd) {                                                                            // :439
         float r[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) r[k] = p.wk[k] * (p.iz[k] + p.ix[k] * factor * u + p.iy[k] * factor * v);   // :441-443
+        for (int k = 0; k < 3; k++) r[k] = ZUV ? p.wk[k] * p.iz[k] : p.wk[k] * (p.iz[k] + p.ix[k] * factor * u + p.iy[k] * factor * v);   // :441-443
         if (!dt_norm) {
             float t = m * hd * psi_vec(color, __fdiv_rn(r[0] * r[0], factorsq) + __fdiv_rn(r[1] * r[1], factorsq) + __fdiv_rn(r[2] * r[2], factorsq));   // :447
             t = __fdiv_rn(t, factorsq);
@@ -673,8 +680,8 @@ __device__ __forceinline__ void term_ref(Acc &A, const Px &p, float m, float u, 
     float r[6];
 #pragma unroll
     for (int k = 0; k < 3; k++) {                                                        // :511-516
-        r[2 * k] = p.wk[k] * (p.ixz[k] + p.ixx[k] * factor * u + p.ixy[k] * factor * v);
-        r[2 * k + 1] = p.wk[k] * (p.iyz[k] + p.ixy[k] * factor * u + p.iyy[k] * factor * v);
+        r[2 * k] = ZUV ? p.wk[k] * p.ixz[k] : p.wk[k] * (p.ixz[k] + p.ixx[k] * factor * u + p.ixy[k] * factor * v);
+        r[2 * k + 1] = ZUV ? p.wk[k] * p.iyz[k] : p.wk[k] * (p.iyz[k] + p.ixy[k] * factor * u + p.iyy[k] * factor * v);
     }
     if (!dt_norm) {
         float t = m * hg * psi_vec(grad, __fdiv_rn(r[0] * r[0], factorsq) + __fdiv_rn(r[1] * r[1], factorsq) + __fdiv_rn(r[2] * r[2], factorsq) +
@@ -790,7 +797,7 @@ __device__ __forceinline__ float d5y_in(const float *t, int c) { return tap5(t[c
 // Column borders: the staged planes carry REPLICATED columns outside the image, so the clamped taps of image.c:501-516
 // become fixed LDS offsets.  Row borders use folded coefficients (different expressions, image.c:433-457): rows are
 // wave-uniform here, so that is a scalar branch.
-template <int TY, int NT, int MINB>
+template <int TY, int NT, int MINB, bool ZUV>
 __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, const float *__restrict__ base, float *__restrict__ a11, float *__restrict__ a12,
                                                               float *__restrict__ a22, float *__restrict__ b1, float *__restrict__ b2,
                                                               const float *__restrict__ du, const float *__restrict__ dv, const float *__restrict__ uu,
@@ -826,7 +833,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         wk[k][0] = wk[k][1] = wk[k][2] = 1.0f;
         if (!ok[k]) continue;
         const size_t o = (size_t)y * g.pitch + x;
-        if (!a.zero_duv) { u[k] = du[eb + o]; v[k] = dv[eb + o]; }
+        if (!ZUV) { u[k] = du[eb + o]; v[k] = dv[eb + o]; }
         if (a.chw) {                                                                   // see k_assemble
             const long lin = (long)y * a.lstride + x;
             const long r0 = lin / a.chw_stride0, c0 = lin % a.chw_stride0;
@@ -945,8 +952,8 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             if (!ok[k]) continue;
             float m = base[eb + T.mask_off + (size_t)y * g.pitch + x];
             if (!a.one_direction || !T.backward) m = T.backward ? 1.0f * bwd[k] * m : 1.0f * fwd[k] * m;   // :314,316
-            if (T.is_ref) term_ref(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
-            else          term_succ(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
+            if (T.is_ref) term_ref<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
+            else          term_succ<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
         }
     }
     float4(*tA)[65] = reinterpret_cast<float4(*)[65]>(lds);                     // [TY][65] each; live after the last barrier below
@@ -1009,8 +1016,11 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, con
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
     static const int shape = getenv("SFA_ASSEMBLE_SHAPE") ? atoi(getenv("SFA_ASSEMBLE_SHAPE")) : 0;
 #define SFA_LAUNCH_AI(TY, NT, MINB)                                                                                                                       \
-    hipLaunchKernelGGL((k_assemble_images<TY, NT, MINB>), dim3((g.w + DT_X - 1) / DT_X, (g.h + TY - 1) / TY, g.nb), dim3(NT), 0, c->stream, a, base, a11, a12, a22, \
-                       b1, b2, du, dv, uu, vv, sh, sv, occ, g)
+    do {                                                                                                                                                \
+        const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + TY - 1) / TY, g.nb);                                                                          \
+        if (a.zero_duv) hipLaunchKernelGGL((k_assemble_images<TY, NT, MINB, true>), grid_, dim3(NT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g);  \
+        else            hipLaunchKernelGGL((k_assemble_images<TY, NT, MINB, false>), grid_, dim3(NT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g); \
+    } while (0)
     switch (shape) {
     case 1: SFA_LAUNCH_AI(8, 256, 2); break;
     case 2: SFA_LAUNCH_AI(8, 256, 4); break;
