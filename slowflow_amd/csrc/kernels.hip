@@ -1105,22 +1105,41 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ u
 }
 // last inner iteration of an outer one, solver result still in its x plane: flow update (:396-397) and the outer change norms and
 // wx <- uu (:412-429) in one pass; the inner norms are not formed (nobody reads them after the last inner iteration)
+// The x plane is diagonal-major: a row-major reader would touch one 8-byte entry per 5 KB.  A block therefore takes 64x16 tiles, reads them
+// along the anti-diagonals (16 consecutive entries = 128 B each, as k_sor_prepare writes them) into LDS and works row-major from there.
 __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ uu, float *__restrict__ vv, float *__restrict__ wx, float *__restrict__ wy,
                                                             const unsigned long long *__restrict__ xs, long ent, int RP, int G, double *__restrict__ partial, Geo g) {
+    __shared__ unsigned long long tX[16][65];
     const int b = blockIdx.z;
-    const int x = blockIdx.x * BX + threadIdx.x;
+    const int tid = threadIdx.y * BX + threadIdx.x;
+    const int c0 = blockIdx.x * 64;
     double sa = 0, sb = 0;
-    if (elem_active(g.active, b) && x < g.w)
-        for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
-            const size_t o = b * g.es + (size_t)y * g.pitch + x;
-            const unsigned long long xv = xs[(size_t)b * ent + (size_t)(x + y + G) * RP + (y + G)];
-            const float d = __uint_as_float((unsigned)(xv & 0xffffffffu)), e = __uint_as_float((unsigned)(xv >> 32));
-            const float ox = wx[o], oy = wy[o];
-            const float u = ox + d, v = oy + e;                                           // :396-397
-            sa += (double)fabsf(u - ox);                                                 // :415-419
-            sb += (double)fabsf(v - oy);
-            uu[o] = u; vv[o] = v;
-            wx[o] = u; wy[o] = v;                                                         // :428-429
+    if (elem_active(g.active, b))
+        for (int r0 = blockIdx.y * 16; r0 < g.h; r0 += gridDim.y * 16) {
+            __syncthreads();
+            for (int item = tid; item < (64 + 16 - 1) * 16; item += BX * BY) {
+                const int dl = item / 16, rl = item % 16, cl = dl - rl;
+                if (cl < 0 || cl >= 64) continue;
+                const int r = r0 + rl, c = c0 + cl;
+                if (r < g.h && c < g.w) tX[rl][cl] = xs[(size_t)b * ent + (size_t)(c + r + G) * RP + (r + G)];
+            }
+            __syncthreads();
+            const int x = c0 + threadIdx.x;
+            if (x < g.w)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int rl = threadIdx.y + 4 * k, y = r0 + rl;
+                    if (y >= g.h) break;
+                    const size_t o = b * g.es + (size_t)y * g.pitch + x;
+                    const unsigned long long xv = tX[rl][threadIdx.x];
+                    const float d = __uint_as_float((unsigned)(xv & 0xffffffffu)), e = __uint_as_float((unsigned)(xv >> 32));
+                    const float ox = wx[o], oy = wy[o];
+                    const float u = ox + d, v = oy + e;                                   // :396-397
+                    sa += (double)fabsf(u - ox);                                         // :415-419
+                    sb += (double)fabsf(v - oy);
+                    uu[o] = u; vv[o] = v;
+                    wx[o] = u; wy[o] = v;                                                 // :428-429
+                }
         }
     block_sum2(sa, sb);
     if (threadIdx.x == 0 && threadIdx.y == 0) {
@@ -1184,7 +1203,7 @@ void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
 }
 void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red) {
-    dim3 grid = red_grid(g, g.nb);
+    dim3 grid((g.w + 63) / 64, std::min((g.h + 15) / 16, kRedRows), g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_outer_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);

@@ -417,7 +417,8 @@ def test_fused_assembly_is_the_unfused_pipeline(ctx, oracle, monkeypatch, kw, w,
         ch, _ = ctx.compute_one_level(ps, wx, wy, [c_(f) for f in frames], w, [c_(x) for x in chw])
         out.append((wx, wy, ch))
     assert np.array_equal(valid(out[0][0], w), valid(out[1][0], w)) and np.array_equal(valid(out[0][1], w), valid(out[1][1], w))
-    assert tuple(out[0][2]) == tuple(out[1][2])
+    # the change norms are fp64 sums taken in another order by the two pipelines: equal to fp64 rounding, not bit for bit
+    assert np.allclose(out[0][2], out[1][2], rtol=1e-6, atol=0)
 
 
 def test_level_channel_weights_and_initial_flow(ctx, oracle):
