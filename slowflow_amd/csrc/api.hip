@@ -965,10 +965,11 @@ int sfa_job_run(sfa_job *j) {
     for (int l = 1; l < L; l++) {
         Level Lp = j->level(l - 1), Lc = j->level(l);
         float *tmp = Lp.base + Lp.off_tmp;
+        // all F frames (3 F consecutive planes per window) in one pass: :607 + :611 fused
+        if (!getenv("SFA_PYRAMID_UNFUSED") &&
+            launch_pyr_down(ctx, Lc.frame(0), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Lp.frame(0), Lp.w, Lp.h, Lp.pitch, Lp.pl, Lp.es, 3 * F, nb, taps, radius))
+            continue;
         for (int f = 0; f < F; f++) {
-            if (!getenv("SFA_PYRAMID_UNFUSED") &&
-                launch_pyr_down(ctx, Lc.frame(f), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Lp.frame(f), Lp.w, Lp.h, Lp.pitch, Lp.pl, Lp.es, 3, nb, taps, radius))
-                continue;                                                                                        // :607 + :611 in one pass
             launch_gauss_blur(ctx, Lp.geo(all), tmp + 3 * Lp.pl, tmp, Lp.frame(f), 3, taps, radius);            // :607
             launch_resize(ctx, Lc.frame(f), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, tmp + 3 * Lp.pl, Lp.w, Lp.h, Lp.pitch, Lp.pl, Lp.es, 3, nb, 1.0f);   // :611
         }
