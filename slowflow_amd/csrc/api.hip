@@ -109,10 +109,15 @@ static const float *pair_image(const Level &L, int s, int sp1) { return (s + sp1
 static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, unsigned long long active, const bool need_toref[2 * SFA_MAX_REF]) {
     const Geo g = L.geo(active);
     const int ref = L.ref;
+    WarpJobs J;
+    J.n = 0;
     for (int s = p.one_direction ? ref : 0; s < 2 * ref; s++) {
         // the warp that also yields the slot's mask: w_s backwards (:100), w_sp1 forwards (:109); a zero-step warp is a copy (:723-728)
-        if (s - ref != 0) launch_warp(c, g, L.warp(s, 0), s < ref ? L.mask(s) : nullptr, L.frame(s), L.plane(P_WX), L.plane(P_WY), s - ref, L.es);
-        if (s - ref + 1 != 0) launch_warp(c, g, L.warp(s, 1), s < ref ? nullptr : L.mask(s), L.frame(s + 1), L.plane(P_WX), L.plane(P_WY), s - ref + 1, L.es);
+        if (s - ref != 0) J.job[J.n++] = WarpJob{L.frame(s) - L.base, L.warp(s, 0) - L.base, s < ref ? L.mask(s) - L.base : -1L, s - ref};
+        if (s - ref + 1 != 0) J.job[J.n++] = WarpJob{L.frame(s + 1) - L.base, L.warp(s, 1) - L.base, s < ref ? -1L : L.mask(s) - L.base, s - ref + 1};
+    }
+    launch_warp_jobs(c, g, J, L.base, L.plane(P_WX), L.plane(P_WY));
+    for (int s = p.one_direction ? ref : 0; s < 2 * ref; s++) {
         if (L.fused) continue;
         const float *w_s = pair_image(L, s, 0), *w_sp1 = pair_image(L, s, 1);
         launch_deriv_stack(c, g, L.stack(s, 0), w_s, w_sp1, L.es, L.es);                                        // :113-133

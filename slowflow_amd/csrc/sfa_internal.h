@@ -91,6 +91,10 @@ struct Geo { int w, h, pitch; long pl; long es; int nb; unsigned long long activ
 
 struct PenaltyDev { int id; float eps, trunc; };
 
+// several warps (factor != 0) of one flow field in one pass; offsets are arena offsets of element 0 like Term::i1_off, mask_off < 0: no mask
+struct WarpJob { long src_off, dst_off, mask_off; int factor; };
+struct WarpJobs { WarpJob job[4 * SFA_MAX_REF]; int n; };
+void launch_warp_jobs(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base, const float *wx, const float *wy);
 void launch_warp(sfa_ctx *c, const Geo &g, float *dst3, float *mask, const float *src3, const float *wx, const float *wy, int factor,
                  long src_es /* batch stride of src3 (frames) */);
 void launch_deriv_stack(sfa_ctx *c, const Geo &g, float *out24, const float *I1, const float *I2, long es1, long es2);
