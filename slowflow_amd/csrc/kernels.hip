@@ -1357,10 +1357,12 @@ void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl,
 // 64x8 tile of the DESTINATION; the source footprint (+ blur radius, replicated at the image border) is staged in LDS,
 // blurred along rows, then along columns, and sampled bilinearly -- the same operations in the same order as k_gauss_h,
 // k_gauss_v, k_resize, without the two intermediate images.
+template <int R>
 __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int dw, int dh, int dpitch, long dpl, long des, const float *__restrict__ src, int sw, int sh,
                                                   int spitch, long spl, long ses, int nplanes, double scale_x, double scale_y, Taps t, int CM, int RM) {
-    extern __shared__ float pyr_lds[];
-    const int r = t.r, CS = CM + 2 * r, RS = RM + 2 * r;
+    extern __shared__ __attribute__((aligned(16))) float pyr_lds[];
+    constexpr int r = R;                                              // compile-time radius: the tap loops unroll, the row buffer stays in registers
+    const int CS = (CM + 2 * r + 3) / 4 * 4 + 4, RS = RM + 2 * r;       // CM, CS multiples of 4; CS leaves room for the aligned quads of the row pass
     float *S = pyr_lds, *Hb = S + RS * CS, *V = Hb + RS * CM;
     const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
     const int dx0 = blockIdx.x * 64, dy0 = blockIdx.y * 8;
@@ -1369,25 +1371,54 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
     int mx0 = (int)floorf((float)((dx0 + 0.5) * scale_x - 0.5)), my0 = (int)floorf((float)((dy0 + 0.5) * scale_y - 0.5));
     mx0 = mx0 < 0 ? 0 : mx0; my0 = my0 < 0 ? 0 : my0;
     const float *s = src + b * ses + pl * spl;
-    for (int i = tid; i < RS * CS; i += 256) {
-        const int j = i / CS, c = i % CS;
-        S[i] = s[(size_t)clampi(my0 - r + j, 0, sh - 1) * spitch + clampi(mx0 - r + c, 0, sw - 1)];
+    // (row, column) of a thread's items advance incrementally: one division per thread and loop instead of one per item
+    {
+        int j = tid / CS, c = tid % CS;
+        const int dj = 256 / CS, dc = 256 % CS;
+        while (j < RS) {
+            S[j * CS + c] = s[(size_t)clampi(my0 - r + j, 0, sh - 1) * spitch + clampi(mx0 - r + c, 0, sw - 1)];
+            c += dc; j += dj;
+            if (c >= CS) { c -= CS; j++; }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < RS * CM; i += 256) {                       // k_gauss_h on the rows of the footprint
-        const int j = i / CM, c = i % CM;
-        const float *row = S + j * CS + c + r;
-        float acc = t.k[r] * row[0];
-        for (int q = 1; q <= r; q++) acc += t.k[r + q] * (row[-q] + row[q]);
-        Hb[i] = acc;
+    // k_gauss_h on the rows of the footprint, four columns per item: the 4 + 2r inputs come as aligned float4 reads
+    const int CQ = CM / 4, djq = 256 / CQ, dcq = 256 % CQ;
+    for (int j = tid / CQ, cq = tid % CQ; j < RS;) {
+        const int c = 4 * cq;
+        constexpr int nq = (4 + 2 * r + 3) / 4;
+        float in[4 * nq];                                            // columns c - r .. of the tile  (S column c + r is tile column c)
+        const float4 *row4 = reinterpret_cast<const float4 *>(S + j * CS + c);     // c is a multiple of 4, CS too
+#pragma unroll
+        for (int q = 0; q < nq; q++) { const float4 v = row4[q]; in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w; }
+        float out[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float acc = t.k[r] * in[e + r];
+#pragma unroll
+            for (int q = 1; q <= r; q++) acc += t.k[r + q] * (in[e + r - q] + in[e + r + q]);
+            out[e] = acc;
+        }
+        *reinterpret_cast<float4 *>(Hb + j * CM + c) = make_float4(out[0], out[1], out[2], out[3]);
+        cq += dcq; j += djq;
+        if (cq >= CQ) { cq -= CQ; j++; }
     }
     __syncthreads();
-    for (int i = tid; i < RM * CM; i += 256) {                       // k_gauss_v
-        const int j = i / CM, c = i % CM;
+    // k_gauss_v, four columns per item
+    for (int j = tid / CQ, cq = tid % CQ; j < RM;) {
+        const int c = 4 * cq;
         const float *col = Hb + (j + r) * CM + c;
-        float acc = t.k[r] * col[0];
-        for (int q = 1; q <= r; q++) acc += t.k[r + q] * (col[-q * CM] + col[q * CM]);
-        V[i] = acc;
+        const float4 ctr = *reinterpret_cast<const float4 *>(col);
+        float4 acc = make_float4(t.k[r] * ctr.x, t.k[r] * ctr.y, t.k[r] * ctr.z, t.k[r] * ctr.w);
+#pragma unroll
+        for (int q = 1; q <= r; q++) {
+            const float4 up = *reinterpret_cast<const float4 *>(col - q * CM), dn = *reinterpret_cast<const float4 *>(col + q * CM);
+            const float kq = t.k[r + q];
+            acc.x += kq * (up.x + dn.x); acc.y += kq * (up.y + dn.y); acc.z += kq * (up.z + dn.z); acc.w += kq * (up.w + dn.w);
+        }
+        *reinterpret_cast<float4 *>(V + j * CM + c) = acc;
+        cq += dcq; j += djq;
+        if (cq >= CQ) { cq -= CQ; j++; }
     }
     __syncthreads();
     const int dx = dx0 + threadIdx.x;
@@ -1419,14 +1450,19 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
 bool launch_pyr_down(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
                      int nplanes, int nb, const float *taps, int radius) {
     const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
-    const int CM = (int)ceil(64 * scale_x) + 2, RM = (int)ceil(8 * scale_y) + 2, CS = CM + 2 * radius, RS = RM + 2 * radius;
+    const int CM = (((int)ceil(64 * scale_x) + 2) + 3) / 4 * 4, RM = (int)ceil(8 * scale_y) + 2, CS = (CM + 2 * radius + 3) / 4 * 4 + 4, RS = RM + 2 * radius;
     const size_t lds = (size_t)(RS * CS + RS * CM + RM * CM) * sizeof(float);
     if (lds > 60 * 1024 || radius > 8) return false;
     Taps t;
     t.r = radius;
     for (int i = 0; i < 2 * radius + 1; i++) t.k[i] = taps[i];
-    hipLaunchKernelGGL(k_pyr_down, dim3((dw + 63) / 64, (dh + 7) / 8, nb * nplanes), dim3(64, 4), lds, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl,
-                       ses, nplanes, scale_x, scale_y, t, CM, RM);
+    const dim3 grid((dw + 63) / 64, (dh + 7) / 8, nb * nplanes), block(64, 4);
+#define SFA_PYR(RR) case RR: hipLaunchKernelGGL(k_pyr_down<RR>, grid, block, lds, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes, scale_x, scale_y, t, CM, RM); break
+    switch (radius) {
+        SFA_PYR(1); SFA_PYR(2); SFA_PYR(3); SFA_PYR(4); SFA_PYR(5); SFA_PYR(6); SFA_PYR(7); SFA_PYR(8);
+    default: return false;
+    }
+#undef SFA_PYR
     return true;
 }
 
