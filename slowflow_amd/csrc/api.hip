@@ -928,6 +928,7 @@ int sfa_job_upload(sfa_job *j, int b, const float *const *frames, int n_frames, 
     else SFA_HIP(ctx, hipMemsetAsync(f0 + L0.pl, 0, L0.pl * sizeof(float), ctx->stream));
     if (chw) {
         // weights keep the level-0 host geometry, padding lanes included (the reference indexes them linearly)
+        CHECK_ARGS((long)stride * j->h < (1L << 31), "channel weights: the linear pixel index must fit 31 bits");
         if (!j->has_chw) {
             SFA_TRY(j->chw.alloc(ctx, (size_t)j->nb * 3 * dev_pitch(stride) * j->h * sizeof(float)));
             launch_fill(ctx, j->chw.f(), (size_t)j->nb * 3 * dev_pitch(stride) * j->h, 1.0f);

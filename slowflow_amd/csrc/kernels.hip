@@ -776,8 +776,8 @@ __global__ void __launch_bounds__(BX *BY) k_assemble(AssembleArgs a, const float
     Px p;
     if (a.chw) {
         // the reference walks the LEVEL-0 weight planes with this level's linear index (variational_aux_mt.cpp:177,366-371)
-        const long lin = (long)y * a.lstride + x;
-        const long r0 = lin / a.chw_stride0, c0 = lin % a.chw_stride0;
+        const unsigned lin = (unsigned)y * (unsigned)a.lstride + (unsigned)x;          // < 2^31: checked where the weights are attached
+        const unsigned r0 = lin / (unsigned)a.chw_stride0, c0 = lin % (unsigned)a.chw_stride0;
         const float *cw = a.chw + b * a.chw_es + r0 * a.chw_pitch + c0;
         p.wk[0] = cw[0]; p.wk[1] = cw[a.chw_pl]; p.wk[2] = cw[2 * a.chw_pl];
     } else { p.wk[0] = p.wk[1] = p.wk[2] = 1.0f; }
@@ -866,8 +866,8 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         const size_t o = (size_t)y * g.pitch + x;
         if (!ZUV) { u[k] = du[eb + o]; v[k] = dv[eb + o]; }
         if (a.chw) {                                                                   // see k_assemble
-            const long lin = (long)y * a.lstride + x;
-            const long r0 = lin / a.chw_stride0, c0 = lin % a.chw_stride0;
+            const unsigned lin = (unsigned)y * (unsigned)a.lstride + (unsigned)x;      // < 2^31: checked where the weights are attached
+            const unsigned r0 = lin / (unsigned)a.chw_stride0, c0 = lin % (unsigned)a.chw_stride0;
             const float *cw = a.chw + b * a.chw_es + r0 * a.chw_pitch + c0;
             wk[k][0] = cw[0]; wk[k][1] = cw[a.chw_pl]; wk[k][2] = cw[2 * a.chw_pl];
         }
