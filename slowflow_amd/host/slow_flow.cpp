@@ -239,7 +239,9 @@ int main(int argc, char **argv) {
                     std::vector<const float *> fr(F);
                     for (int k = 0; k < F; k++) fr[k] = im[k]->c1;
                     const float *chw[3] = {channel_weights->c1, channel_weights->c2, channel_weights->c3};
-                    rc = sfa_job_upload(job, (int)e, fr.data(), F, nullptr, nullptr, im[0]->stride, wd.backward ? nullptr : chw);   // :876 vs :1018
+                    // only the forward solver gets the channel weights (:876 vs :1018); without raw weighting they are all ones (:597-598), which is
+                    // what a NULL pointer means to the library (x * 1.0f is exact: same bits, three planes less to read per pixel)
+                    rc = sfa_job_upload(job, (int)e, fr.data(), F, nullptr, nullptr, im[0]->stride, (wd.backward || !raw) ? nullptr : chw);
                 }
                 if (rc == SFA_OK) rc = sfa_job_run(job);
                 for (size_t e = 0; e < idx.size() && rc == SFA_OK; e++) {
