@@ -78,16 +78,16 @@ __global__ void k_warp(float *__restrict__ dst3, float *__restrict__ mask, const
                            + s[(size_t)y2 * g.pitch + x1] * ax * dy + s[(size_t)y2 * g.pitch + x2] * dx * dy;   // :748-753
     }
 }
-// all warps of one get_derivatives call in a single pass: the flow is read once per pixel, then every job gathers its frame
+// all warps of one get_derivatives call in a single launch (grid z = window x job)
 __global__ void k_warp_jobs(WarpJobs J, float *__restrict__ base, const float *__restrict__ wx, const float *__restrict__ wy, Geo g) {
-    const int b = blockIdx.z;
+    const int b = blockIdx.z / J.n, j0 = blockIdx.z % J.n;
     if (!elem_active(g.active, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     const long eb = b * g.es;
     const size_t o = (size_t)y * g.pitch + x;
     const float fx0 = wx[eb + o], fy0 = wy[eb + o];
-    for (int j = 0; j < J.n; j++) {
+    for (int j = j0; j <= j0; j++) {
         const int factor = J.job[j].factor;
         const float *src3 = base + eb + J.job[j].src_off;
         float *dst3 = base + eb + J.job[j].dst_off;
@@ -99,15 +99,19 @@ __global__ void k_warp_jobs(WarpJobs J, float *__restrict__ base, const float *_
         const int x1 = clampi(xi, 0, g.w - 1), x2 = clampi(xi + 1, 0, g.w - 1);
         const int y1 = clampi(yi, 0, g.h - 1), y2 = clampi(yi + 1, 0, g.h - 1);
         const float ax = 1.0f - dx, ay = 1.0f - dy;
+        float out[3];                                                // all gathers before the stores (source and destination share `base`)
+#pragma unroll
         for (int k = 0; k < 3; k++) {
             const float *s = src3 + k * g.pl;
-            dst3[k * g.pl + o] = s[(size_t)y1 * g.pitch + x1] * ax * ay + s[(size_t)y1 * g.pitch + x2] * dx * ay
-                               + s[(size_t)y2 * g.pitch + x1] * ax * dy + s[(size_t)y2 * g.pitch + x2] * dx * dy;   // :748-753
+            out[k] = s[(size_t)y1 * g.pitch + x1] * ax * ay + s[(size_t)y1 * g.pitch + x2] * dx * ay
+                   + s[(size_t)y2 * g.pitch + x1] * ax * dy + s[(size_t)y2 * g.pitch + x2] * dx * dy;               // :748-753
         }
+#pragma unroll
+        for (int k = 0; k < 3; k++) dst3[k * g.pl + o] = out[k];
     }
 }
 void launch_warp_jobs(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base, const float *wx, const float *wy) {
-    if (J.n > 0) hipLaunchKernelGGL(k_warp_jobs, grid2d(g), block2d(), 0, c->stream, J, base, wx, wy, g);
+    if (J.n > 0) hipLaunchKernelGGL(k_warp_jobs, grid2d(g, J.n), block2d(), 0, c->stream, J, base, wx, wy, g);
 }
 void launch_warp(sfa_ctx *c, const Geo &g, float *dst3, float *mask, const float *src3, const float *wx, const float *wy, int factor, long src_es) {
     hipLaunchKernelGGL(k_warp, grid2d(g), block2d(), 0, c->stream, dst3, mask, src3, wx, wy, g, factor, src_es);
