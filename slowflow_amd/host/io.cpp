@@ -1,5 +1,6 @@
 // io.cpp -- see io.h
 #include "io.h"
+#include "png.h"
 
 #include <cctype>
 #include <cstdio>
@@ -61,6 +62,22 @@ static bool next_token(FILE *f, std::string &tok) {
 color_image_t *color_image_load(const char *filename, int *maxval_out) {
     FILE *f = fopen(filename, "rb");
     if (!f) { fprintf(stderr, "could not open %s\n", filename); return nullptr; }
+    unsigned char sig[4] = {0, 0, 0, 0};
+    if (fread(sig, 1, 4, f) == 4 && sig[0] == 0x89 && sig[1] == 'P' && sig[2] == 'N' && sig[3] == 'G') {   // PNG (what the reference's sequences are stored as)
+        fclose(f);
+        png_image png;
+        if (!png_read(filename, png)) { fprintf(stderr, "%s: not a PNG this reader handles (non-interlaced, 8/16 bit)\n", filename); return nullptr; }
+        color_image_t *pim = color_image_new(png.width, png.height);
+        color_image_erase(pim);
+        for (int y = 0; y < png.height; y++)
+            for (int x = 0; x < png.width; x++)
+                for (int k = 0; k < 3; k++)          // file order R,G,B = the order after the reference's BGR2RGB (slow_flow.cpp:527)
+                    (k == 0 ? pim->c1 : k == 1 ? pim->c2 : pim->c3)[(size_t)y * pim->stride + x] =
+                        (float)png.samples[((size_t)y * png.width + x) * png.channels + (png.channels == 3 ? k : 0)];
+        if (maxval_out) *maxval_out = png.depth == 16 ? 65535 : 255;
+        return pim;
+    }
+    rewind(f);
     std::string magic, t;
     if (!next_token(f, magic)) { fclose(f); return nullptr; }
     color_image_t *im = nullptr;

@@ -1,6 +1,6 @@
 // io.h -- the file formats either side of the path, without third-party image libraries:
 //   .flo  Middlebury flow (float 202021.25, int w, int h, interleaved u,v rows) -- io.c:53-101 of the reference
-//   .ppm / .pgm  binary P6 / P5, 8 or 16 bit (big-endian samples), and .pfm (Pf / PF, float)
+//   .ppm / .pgm  binary P6 / P5, 8 or 16 bit (big-endian samples), .pfm (Pf / PF, float) and .png (png.h)
 #ifndef SLOWFLOW_AMD_HOST_IO_H
 #define SLOWFLOW_AMD_HOST_IO_H
 

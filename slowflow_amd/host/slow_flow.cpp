@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 
+#include "flow_vis.h"
 #include "image.h"
 #include "ingest.h"
 #include "io.h"
@@ -63,8 +64,8 @@ static string fmt1(const string &format, int a) { char b[1024]; snprintf(b, size
 static string fmt2(const string &format, int a, int c) { char b[1024]; snprintf(b, sizeof b, format.c_str(), a, c); return b; }
 
 struct Window {
-    unsigned jet; bool backward; string out; double seconds; int gpu;
-    Window(unsigned j, bool b, const string &o) : jet(j), backward(b), out(o), seconds(0), gpu(-1) {}
+    unsigned jet; bool backward; string out; double seconds; int gpu; double epe, aae;   // epe/aae < 0: no ground truth
+    Window(unsigned j, bool b, const string &o) : jet(j), backward(b), out(o), seconds(0), gpu(-1), epe(-1), aae(-1) {}
 };
 
 int main(int argc, char **argv) {
@@ -132,7 +133,7 @@ int main(int argc, char **argv) {
     }
     if (start_f > end_f) return 0;
 
-    // ---- read the image sequence (:447-592, without OpenCV: binary PPM / PGM / PFM) ------------------------------
+    // ---- read the image sequence (:447-592, without OpenCV: PNG, binary PPM / PGM / PFM) ------------------------------
     std::vector<color_image_t *> seq(frames, nullptr), seq_back(frames, nullptr);
     sfa_ctx *ingest_ctx = nullptr;
     for (unsigned f = start_f; f < end_f; f++) {
@@ -147,7 +148,7 @@ int main(int argc, char **argv) {
         std::cout << "Reading " << img_file << "..." << std::endl;
         int maxval = 255;
         seq[f] = color_image_load(img_file.c_str(), &maxval);
-        if (!seq[f]) { std::cerr << "cannot read frame " << img_file << " (binary PPM/PGM/PFM expected)" << std::endl; return 3; }
+        if (!seq[f]) { std::cerr << "cannot read frame " << img_file << " (PNG or binary PPM/PGM/PFM expected)" << std::endl; return 3; }
         if (raw) {                                                                   // demosaicing (:482-527): the mosaic is the grey image
             image_t mosaic = {seq[f]->width, seq[f]->height, seq[f]->stride, seq[f]->c1};
             color_image_t *rgb = color_image_new(seq[f]->width, seq[f]->height);
@@ -178,6 +179,47 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < (size_t)3 * channel_weights->stride * height; i++) channel_weights->c1[i] = 1.0f;
     if (raw) rawWeighting(channel_weights, red_loc.size() > 0 ? red_loc[0] : 0, red_loc.size() > 1 ? red_loc[1] : 0, params.parameter<float>("raw_weight", "1.0"));   // :599-600
     if (ingest_ctx) { sfa_ctx_destroy(ingest_ctx); ingest_ctx = nullptr; }
+
+    // ---- ground truth, if the cfg names it (:603-661): .flo -> crop -> nearest resize * scale -> gt/flow_%05i.{png,flo} --------
+    std::vector<image_t **> gt(params.Jets, nullptr);
+    if (!params.file_gt.empty()) {
+        mkdirs(params.output + "gt/");
+        for (unsigned j = start_j; j < end_j; j++) {
+            string path;
+            if (!sintel) path = fmt1(params.file_gt, (int)start + (int)j * steps);
+            else {
+                int sintel_frame = start / 1000, hfr = (int)j * steps + (int)(start % 1000);
+                while (hfr < 0) { sintel_frame--; hfr += 42; }
+                while (hfr > 41) { sintel_frame++; hfr -= 42; }
+                path = fmt2(params.file_gt, sintel_frame, hfr);
+            }
+            std::cout << path << std::endl;
+            if (!file_exists(path)) continue;
+            image_t **g = readFlowFile(path.c_str());
+            if (!g) { std::cout << "No gt flow for frame " << std::endl; continue; }
+            if (params.center.x > 0) {                                               // crop like the frames (:634-637)
+                for (int c = 0; c < 2; c++) {
+                    const int x0 = params.center.x - params.extent.x / 2, y0 = params.center.y - params.extent.y / 2;
+                    const int cw = 2 * (params.extent.x / 2), chh = 2 * (params.extent.y / 2);
+                    if (x0 < 0 || y0 < 0 || x0 + cw > g[c]->width || y0 + chh > g[c]->height) { std::cerr << "center / extent do not fit the ground truth" << std::endl; return 3; }
+                    image_t *part = image_new(cw, chh);
+                    image_erase(part);
+                    for (int y = 0; y < chh; y++) memcpy(part->data + (size_t)y * part->stride, g[c]->data + (size_t)(y0 + y) * g[c]->stride + x0, sizeof(float) * cw);
+                    image_delete(g[c]);
+                    g[c] = part;
+                }
+            }
+            for (int c = 0; c < 2; c++) {                                            // nearest, not linear: motion discontinuities (:640-641)
+                image_t *r = flow_resize_nearest(g[c], scale);
+                image_delete(g[c]);
+                g[c] = r;
+            }
+            gt[j] = g;
+            const string base = params.output + "gt/" + fmt1("flow_%05i", (int)params.sequence_start + (int)j * steps);
+            png_write((base + ".png").c_str(), flowColorImg(g[0], g[1], params.verbosity(VER_CMD)));
+            writeFlowFile((base + ".flo").c_str(), g[0], g[1]);
+        }
+    }
 
     normalize(&seq[start_f], end_f - start_f, params);                               // :673
     {
@@ -255,6 +297,15 @@ int main(int argc, char **argv) {
                         image_mul_scalar(wy, (float)steps);
                         if (writeFlowFile(wd.out.c_str(), wx, wy) != 0) rc = SFA_ERR_ARG;
                     }
+                    if (rc == SFA_OK && !wd.backward) {                              // the flow as a colour image next to the .flo (:913-925)
+                        const int fnum = (int)start + (int)wd.jet * steps * skip;
+                        png_write((params.output + "frame_" + std::to_string(fnum) + ".png").c_str(), flowColorImg(wx, wy, 0));
+                        image_t **g = gt[wd.jet];
+                        if (g && g[0]->width == width && g[0]->height == height) {   // additive: error against the ground truth, reported in timings.json
+                            wd.epe = computeEPE(wx, wy, g[0], g[1]);
+                            wd.aae = computeAAE(wx, wy, g[0], g[1]);
+                        }
+                    }
                     if (rc == SFA_OK && sp.occlusion_reasoning && !wd.backward && tp.parameter<bool>("slow_flow_output_occlusions", "0")) {
                         // the final occlusion labels of the forward window as an image, (occ + 1) / 2 * 255 like :276-279 (there: one PNG per
                         // alternation; here the last one, as PGM)
@@ -295,10 +346,12 @@ int main(int argc, char **argv) {
         tj << "[";
         for (size_t i = 0; i < todo.size(); i++)
             tj << (i ? "," : "") << "\n  {\"jet\": " << todo[i].jet << ", \"direction\": \"" << (todo[i].backward ? "backward" : "forward") << "\", \"gpu\": " << todo[i].gpu
-               << ", \"seconds\": " << todo[i].seconds << ", \"flo\": \"" << todo[i].out << "\"}";
+               << ", \"seconds\": " << todo[i].seconds << ", \"flo\": \"" << todo[i].out << "\""
+               << (todo[i].epe >= 0 ? ", \"epe\": " + std::to_string(todo[i].epe) + ", \"aae\": " + std::to_string(todo[i].aae) : string()) << "}";
         tj << "\n]\n";
     }
     for (unsigned f = start_f; f < end_f; f++) color_image_delete(seq[f]);
+    for (auto g : gt) if (g) { image_delete(g[0]); image_delete(g[1]); free(g); }
     color_image_delete(channel_weights);
     std::cout << (failed ? "Failed!" : "Done!") << std::endl;
     return failed ? 5 : 0;

@@ -1,16 +1,19 @@
 // CPU-side checks of the host mirror (no GPU needed): ParameterList syntax and accessors, the cfg -> sfa_params
-// mapping of Variational_MT, the .flo wire format and the PPM/PGM/PFM loaders.
+// mapping of Variational_MT, the .flo wire format, the PPM/PGM/PFM/PNG loaders, ingest, flow colour coding and EPE/AAE.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <vector>
 
+#include "flow_vis.h"
 #include "image.h"
 #include "ingest.h"
 #include "io.h"
 #include "parameter_list.h"
+#include "png.h"
 #include "variational_mt.h"
 
 static int fails = 0;
@@ -167,6 +170,93 @@ int main(int argc, char **argv) {
         CHECK(color_image_crop(img, 2, 2, 8, 4) == nullptr);          // does not fit
         if (part) color_image_delete(part);
         color_image_delete(img);
+    }
+    // ---- PNG in and out (png.h) -----------------------------------------------------------------------------------------
+    {
+        for (int depth = 8; depth <= 16; depth += 8)
+            for (int ch = 1; ch <= 3; ch += 2) {
+                png_image a;
+                a.width = 13; a.height = 7; a.channels = ch; a.depth = depth;
+                a.samples.resize((size_t)13 * 7 * ch);
+                for (size_t i = 0; i < a.samples.size(); i++) a.samples[i] = (uint16_t)((i * 2654435761u >> 7) & (depth == 16 ? 0xffff : 0xff));
+                const std::string f = tmp + "/rt.png";
+                png_image b;
+                CHECK(png_write(f.c_str(), a) && png_read(f.c_str(), b));
+                CHECK(b.width == 13 && b.height == 7 && b.channels == ch && b.depth == depth && b.samples == a.samples);
+                int maxv = 0;
+                color_image_t *c = color_image_load(f.c_str(), &maxv);             // same loader entry as the PPM frames
+                CHECK(c && maxv == (depth == 16 ? 65535 : 255) && c->width == 13 && c->height == 7);
+                if (c) {
+                    bool same = true;
+                    for (int y = 0; y < 7; y++) for (int x = 0; x < 13; x++) for (int k = 0; k < 3; k++)
+                        same &= (k == 0 ? c->c1 : k == 1 ? c->c2 : c->c3)[y * c->stride + x] == (float)a.samples[(y * 13 + x) * ch + (ch == 3 ? k : 0)];
+                    CHECK(same);
+                    color_image_delete(c);
+                }
+            }
+        // files written by an independent encoder (the Python side of this test: all filters, palette, alpha, sub-byte depths)
+        std::ifstream list((tmp + "/png_cases.txt").c_str());
+        std::string name;
+        int w, h, ch, depth, cases = 0;
+        while (list >> name >> w >> h >> ch >> depth) {
+            png_image b;
+            CHECK(png_read((tmp + "/" + name + ".png").c_str(), b));
+            std::ifstream rawf((tmp + "/" + name + ".raw").c_str(), std::ios::binary);
+            std::vector<uint16_t> want((size_t)w * h * ch);
+            rawf.read((char *)want.data(), want.size() * 2);
+            CHECK(b.width == w && b.height == h && b.channels == ch && b.depth == depth && b.samples == want);
+            cases++;
+        }
+        if (list.is_open()) CHECK(cases >= 10);
+        { std::ofstream o((tmp + "/bad.png").c_str(), std::ios::binary); o << "\x89PNG\r\n\x1a\nnot really"; }
+        png_image bad;
+        CHECK(!png_read((tmp + "/bad.png").c_str(), bad) && !png_read((tmp + "/missing.png").c_str(), bad));
+    }
+    // ---- flow colour coding and error measures (flow_vis.h) -----------------------------------------------------------------
+    {
+        unsigned char pix[3];
+        computeColor(0.0f, 0.0f, pix);   CHECK(pix[0] == 255 && pix[1] == 255 && pix[2] == 255);       // no motion: white
+        computeColor(1.0f, 0.0f, pix);   CHECK(pix[0] == 255 && pix[1] == 0 && pix[2] == 0);           // right: red (hue 0 of the wheel)
+        computeColor(-1.0f, 0.0f, pix);  CHECK(pix[0] == 0 && pix[1] > 200 && pix[2] == 255);          // left: cyan-blue
+        computeColor(0.0f, 1.0f, pix);   CHECK(pix[0] > 200 && pix[1] > 200 && pix[2] == 0);           // down: yellow
+        computeColor(0.0f, -1.0f, pix);  CHECK(pix[0] < 120 && pix[1] == 0 && pix[2] == 255);          // up: blue-violet
+        computeColor(0.5f, 0.0f, pix);   CHECK(pix[0] == 255 && pix[1] == 127 && pix[2] == 127);       // half radius: half saturation
+        computeColor(2.0f, 0.0f, pix);   CHECK(pix[0] == 191 && pix[1] == 0 && pix[2] == 0);           // beyond the radius: darkened
+        image_t *u = image_new(6, 4), *v = image_new(6, 4), *gu = image_new(6, 4), *gv = image_new(6, 4);
+        for (int y = 0; y < 4; y++) for (int x = 0; x < 6; x++) {
+            u->data[y * u->stride + x] = 3.0f; v->data[y * v->stride + x] = 0.0f;
+            gu->data[y * gu->stride + x] = 0.0f; gv->data[y * gv->stride + x] = 4.0f;
+        }
+        CHECK(std::fabs(computeEPE(u, v, gu, gv) - 5.0) < 1e-12);
+        CHECK(std::fabs(computeAAE(u, v, gu, gv) - std::acos(1.0 / (std::sqrt(10.0) * std::sqrt(17.0)))) < 1e-6);
+        gu->data[0] = 2e9f;                                             // unknown ground truth there: skipped, mean unchanged
+        u->data[1] = 0.0f; v->data[1] = 4.0f;                           // one exact pixel among the 23 counted
+        CHECK(std::fabs(computeEPE(u, v, gu, gv) - 5.0 * 22 / 23) < 1e-12);
+        image_t *m = image_new(6, 4);
+        for (int i = 0; i < m->stride * 4; i++) m->data[i] = 0.0f;
+        m->data[1] = 1.0f;
+        CHECK(computeEPE(u, v, gu, gv, m) == 0.0 && computeAAE(u, v, gu, gv, m) < 1e-3);
+        image_t *other = image_new(5, 4);
+        CHECK(computeEPE(other, other, gu, gv) == -1 && computeAAE(other, other, gu, gv) == -1);
+        u->data[1] = 3.0f; v->data[1] = 0.0f;
+        u->data[2 * u->stride + 3] = 1e4f;                              // outside the frame: black, and not part of the radius
+        v->data[3] = NAN;
+        png_image col = flowColorImg(u, v);
+        CHECK(col.width == 6 && col.height == 4 && col.channels == 3 && col.depth == 8);
+        CHECK(col.samples[0] == 255 && col.samples[1] == 0 && col.samples[2] == 0);                     // |(3,0)| is the radius: pure red
+        CHECK(col.samples[(2 * 6 + 3) * 3] == 0 && col.samples[(2 * 6 + 3) * 3 + 2] == 0 && col.samples[3 * 3] == 0 && col.samples[3 * 3 + 1] == 0);
+        png_image half = flowColorImg(u, v, 0, 6.0f);
+        CHECK(half.samples[0] == 255 && half.samples[1] == 127 && half.samples[2] == 127);
+        for (int i = 0; i < u->stride * 4; i++) { u->data[i] = 0.0f; v->data[i] = 0.0f; }
+        CHECK(flowColorImg(u, v).samples[5] == 255);                    // zero flow: radius 1, all white
+        image_t *src = image_new(4, 2);
+        for (int y = 0; y < 2; y++) for (int x = 0; x < 4; x++) src->data[y * src->stride + x] = (float)(10 * y + x);
+        image_t *halfsz = flow_resize_nearest(src, 0.5f), *dbl = flow_resize_nearest(src, 2.0f), *same = flow_resize_nearest(src, 1.0f);
+        CHECK(halfsz && halfsz->width == 2 && halfsz->height == 1 && halfsz->data[0] == 0.0f && halfsz->data[1] == 1.0f);      // picks 0 and 2, times 0.5
+        CHECK(dbl && dbl->width == 8 && dbl->height == 4 && dbl->data[3 * dbl->stride + 7] == 26.0f && dbl->data[1 * dbl->stride + 2] == 2.0f);
+        CHECK(same && same->width == 4 && same->data[1 * same->stride + 3] == 13.0f);
+        image_delete(u); image_delete(v); image_delete(gu); image_delete(gv); image_delete(m); image_delete(other);
+        image_delete(src); image_delete(halfsz); image_delete(dbl); image_delete(same);
     }
     printf(fails ? "host tests FAILED (%d)\n" : "host tests OK\n", fails);
     return fails ? 1 : 0;

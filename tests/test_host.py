@@ -21,10 +21,83 @@ def host_build():
     return HOST
 
 
+def png_bytes(w, h, ctype, depth, rows, palette=None, filt=None):
+    """a PNG written here, independently of png.cpp: `rows` = packed scanline bytes; filt = per-row filter type (None: cycle 0..4)"""
+    import zlib
+    comps = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, comps * depth // 8)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+    raw = bytearray()
+    prev = bytes(len(rows[0]))
+    for y, cur in enumerate(rows):
+        ft = (y % 5) if filt is None else filt
+        raw.append(ft)
+        for i, v in enumerate(cur):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            pred = [0, a, b, (a + b) >> 1, paeth(a, b, c)][ft]
+            raw.append((v - pred) & 255)
+        prev = cur
+    z = zlib.compress(bytes(raw), 9)
+    idats = b"".join(chunk(b"IDAT", z[i:i + 97]) for i in range(0, len(z), 97))      # split over many IDAT chunks
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"tEXt", b"Comment\0x")
+            + (chunk(b"PLTE", palette) if palette is not None else b"") + idats + chunk(b"IEND", b""))
+
+
+def write_png_cases(tmp_path):
+    """PNG files of every kind the reader claims (png.h) + the samples it must return, for tests/host/test_host.cpp"""
+    rng = np.random.default_rng(5)
+    w, h = 19, 11
+    lines = []
+
+    def emit(name, ctype, depth, rows, want, ch, out_depth, palette=None, filt=None):
+        (tmp_path / (name + ".png")).write_bytes(png_bytes(w, h, ctype, depth, rows, palette, filt))
+        np.ascontiguousarray(want, dtype="<u2").tofile(str(tmp_path / (name + ".raw")))
+        lines.append("%s %d %d %d %d" % (name, w, h, ch, out_depth))
+    for depth in (8, 16):
+        hi = 256 if depth == 8 else 65536
+        dt = ">u1" if depth == 8 else ">u2"
+        for ctype, comps in ((0, 1), (2, 3), (4, 2), (6, 4)):
+            px = rng.integers(0, hi, size=(h, w, comps))
+            px[0, :3] = hi - 1
+            smooth = (np.arange(w)[None, :, None] * 3 + np.arange(h)[:, None, None] * 5 + np.arange(comps)[None, None, :]) % hi
+            for tag, data in (("n", px), ("s", smooth)):
+                rows = [data[y].astype(dt).tobytes() for y in range(h)]
+                keep = data[..., :1] if comps <= 2 else data[..., :3]                 # alpha dropped
+                emit("c%d_d%d_%s" % (ctype, depth, tag), ctype, depth, rows, keep, keep.shape[2], depth)
+    for f in range(5):                                                                # each filter on its own for every row
+        px = rng.integers(0, 256, size=(h, w, 3))
+        emit("filter%d" % f, 2, 8, [px[y].astype(np.uint8).tobytes() for y in range(h)], px, 3, 8, filt=f)
+    pal = rng.integers(0, 256, size=(16, 3)).astype(np.uint8)
+    for depth in (1, 2, 4, 8):
+        n = min(16, 1 << depth)
+        idx = rng.integers(0, n, size=(h, w))
+        per = 8 // depth
+        rows = []
+        for y in range(h):
+            line = bytearray((w + per - 1) // per)
+            for x in range(w):
+                line[x // per] |= int(idx[y, x]) << ((per - 1 - x % per) * depth)
+            rows.append(bytes(line))
+        emit("pal_d%d" % depth, 3, depth, rows, pal[idx], 3, 8, palette=pal[:n].tobytes())
+        if depth < 8:
+            emit("grey_d%d" % depth, 0, depth, rows, (idx * 255 // ((1 << depth) - 1))[..., None], 1, 8)
+    (tmp_path / "png_cases.txt").write_text("\n".join(lines) + "\n")
+
+
 def test_host_mirror_cpu(host_build, tmp_path):
+    write_png_cases(tmp_path)
     exe = str(tmp_path / "test_host")
     r = subprocess.run(["g++", "-std=c++11", "-O1", "-pthread", "-I", HOST, os.path.join(ROOT, "tests", "host", "test_host.cpp"),
-                        os.path.join(HOST, "libslowflow_host.a"), "-L", os.path.join(ROOT, "slowflow_amd"), "-lslowflow_amd",
+                        os.path.join(HOST, "libslowflow_host.a"), "-L", os.path.join(ROOT, "slowflow_amd"), "-lslowflow_amd", "-lz",
                         "-Wl,-rpath," + os.path.join(ROOT, "slowflow_amd"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
@@ -67,13 +140,24 @@ def test_slow_flow_driver_end_to_end(host_build, tmp_path, alter, occ):
     steps = S - 1
     nframes = 1 + (jets + 2) * steps
     frames = [np.clip(np.round(texture_frame(w, h, k)[:, :, :w]), 0, 255) for k in range(nframes)]
+    ext = "png" if occ else "ppm"                                 # the second case reads PNG frames (filtered scanlines) and has ground truth
     for k, f in enumerate(frames):
-        write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), f)
+        if occ:
+            rows = [f[:, y, :].T.astype(np.uint8).tobytes() for y in range(h)]
+            (tmp_path / ("f_%03d.png" % (10 - steps + k))).write_bytes(png_bytes(w, h, 2, 8, rows))
+        else:
+            write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), f)
+    gt_line = ""
+    if occ:
+        with open(str(tmp_path / "gt_010.flo"), "wb") as g:       # ground truth for jet 0 only: the synthetic translation
+            g.write(struct.pack("<fii", 202021.25, w, h))
+            g.write(np.tile(np.array([1.5 * steps, -0.75 * steps], np.float32), w * h).tobytes())
+        gt_line = "file_gt\t%s/gt_%%03i.flo\n" % tmp_path
     cfg = tmp_path / "run.cfg"
-    cfg.write_text(
-        "file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\n"
+    cfg.write_text(gt_line +
+        "file\t%s/f_%%03i.%s\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\n"
         "slow_flow_S\t%d\nslow_flow_layers\t2\nslow_flow_niter_alter\t%d\nslow_flow_niter_outer\t3\nslow_flow_occlusion_reasoning\t%d\n"
-        "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\ngpu_batch\t4\n" % (tmp_path, tmp_path, jets, S, alter, occ))
+        "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\ngpu_batch\t4\n" % (tmp_path, ext, tmp_path, jets, S, alter, occ))
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Done!" in r.stdout
@@ -109,6 +193,19 @@ def test_slow_flow_driver_end_to_end(host_build, tmp_path, alter, occ):
         for j in range(jets):
             with open(str(out / "occlusion" / ("f_%03d_occ.pgm" % (10 + j * steps))), "rb") as f:
                 assert f.readline() == b"P5\n" and f.readline().split() == [b"%d" % w, b"%d" % h]
+    for j in range(jets):                                         # the colour-coded forward flows: a constant translation = one colour
+        with open(str(out / ("frame_%d.png" % (10 + j * steps))), "rb") as f:
+            assert f.read(8) == b"\x89PNG\r\n\x1a\n"
+    if occ:
+        import json
+        tj = json.load(open(str(out / "timings.json")))
+        fwd0 = [t for t in tj if t["jet"] == 0 and t["direction"] == "forward"][0]
+        uu, vv = read_flo(str(out / "f_010.flo"))
+        assert abs(fwd0["epe"] - np.mean(np.hypot(uu - 1.5 * steps, vv + 0.75 * steps))) < 1e-4 and 0 <= fwd0["aae"] < 0.2
+        assert all("epe" not in t for t in tj if t["jet"] != 0 or t["direction"] != "forward")
+        assert (out / "gt" / "flow_00010.png").exists()
+        gu, gv = read_flo(str(out / "gt" / "flow_00010.flo"))
+        assert np.all(gu == 1.5 * steps) and np.all(gv == -0.75 * steps)
     # -resume skips what exists
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-resume"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.count("already exist") == 2 * jets
