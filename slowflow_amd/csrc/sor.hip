@@ -61,18 +61,40 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f f2v(float2 a) { return (v2f){a.x, a.y}; }
 __device__ __forceinline__ v2f sor_point(v2f self, v2f right, v2f top, v2f bottom, v2f left, float hl, const float4 &SA, const float4 &SB, float omega) {
     // SA = (inv11, inv12, inv22, vt)   SB = (b1, b2, hp, vp)
-    v2f s = SB.z * right;
-    s = s + SA.w * top;
-    s = s + SB.w * bottom;
-    s = s + (v2f){SB.x, SB.y};
+    // written on the register pairs the loads deliver, with explicit broadcasts: the packed ops then select their halves
+    // (op_sel) instead of copying scalars into fresh pairs -- 8 VALU instructions less per step of the band kernel
+    const v2f SAxy = {SA.x, SA.y}, SAzw = {SA.z, SA.w}, SBxy = {SB.x, SB.y}, SBzw = {SB.z, SB.w};
+    v2f s = __builtin_shufflevector(SBzw, SBzw, 0, 0) * right;
+    s = s + __builtin_shufflevector(SAzw, SAzw, 1, 1) * top;
+    s = s + __builtin_shufflevector(SBzw, SBzw, 1, 1) * bottom;
+    s = s + SBxy;
     const v2f B = hl * left + s;
-    const v2f t = (v2f){SA.x, SA.y} * B.x + (v2f){SA.y, SA.z} * B.y;
+    const v2f t = SAxy * __builtin_shufflevector(B, B, 0, 0) + __builtin_shufflevector(SAxy, SAzw, 1, 2) * __builtin_shufflevector(B, B, 1, 1);
     return self + omega * (t - self);
 }
 
 // value of lane-1 (lane 0 receives `fill`): DPP wave_shr:1, no LDS
 __device__ __forceinline__ float lane_shr1(float v, float fill) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
+// lane 0 <- lane X of the same register (X < 16): one DPP row shift confined to row 0; the other lanes are don't-care
+template <int X>
+__device__ __forceinline__ int row0_from(int v) {
+    if constexpr (X == 0) return v;
+    else return __builtin_amdgcn_mov_dpp(v, 0x100 + X /* row_shl:X: lane i <- lane i+X */, 0x1, 0xf, false);   // other lanes: undefined
+}
+__device__ __forceinline__ int lane0_from(int v, int X) {        // X is a constant after unrolling
+    switch (X) {
+        case 0: return row0_from<0>(v);   case 1: return row0_from<1>(v);   case 2: return row0_from<2>(v);   case 3: return row0_from<3>(v);
+        case 4: return row0_from<4>(v);   case 5: return row0_from<5>(v);   case 6: return row0_from<6>(v);   case 7: return row0_from<7>(v);
+        case 8: return row0_from<8>(v);   case 9: return row0_from<9>(v);   case 10: return row0_from<10>(v); case 11: return row0_from<11>(v);
+        case 12: return row0_from<12>(v); case 13: return row0_from<13>(v); case 14: return row0_from<14>(v); default: return row0_from<15>(v);
+    }
+}
+// value of lane-1; lane 0 keeps lane 0 of `fillvec`
+__device__ __forceinline__ float lane_shr1_vec(float v, int fillvec) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(fillvec, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
 __device__ __forceinline__ unsigned long long ld_x(const unsigned long long *p) {
@@ -365,8 +387,12 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     const bool has_up = b > 0, publishes = b + 1 < a.NB;
     // lane t = fi*MC + j fetches lane 0's "lane -1" value of step j of the macro chunk: fi = 0: right of f = 0 (sweep
     // k0-1, column s+1); fi = f+1: top of f (sweep k0+f, column s-f)
-    const int tfi = lane / MC, tj = lane % MC;
-    const bool tv_lane = has_up && lane < (F + 1) * MC && (tfi > 0 || !FIRST);
+    // ROT (all shapes with (F+1)*CH <= 16): the fetch covers one CH-step chunk, 12 lanes for the default shape, all within DPP row 0,
+    // so a row shift brings a step's value to lane 0 and the lane shift keeps it there -- no SGPR round trip (v_readlane + v_mov)
+    constexpr bool ROT = (F + 1) * CH <= 16;
+    constexpr int TN = ROT ? CH : MC;                            // steps covered by one fetch
+    const int tfi = lane / TN, tj = lane % TN;
+    const bool tv_lane = has_up && lane < (F + 1) * TN && (tfi > 0 || !FIRST);
     const long tv_off = tfi == 0 ? (long)(-1) * a.Wp + tj + 1 : (long)(tfi - 1) * a.Wp + tj - (tfi - 1);
 
     float4 sa0[CH], sb0[CH];
@@ -411,10 +437,14 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
             if (!FIRST) known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2));
             pre = !last && ready(m + 1);
         }
-        const unsigned long long tv_cur = tv;
-        if (pre && tv_lane) tv = ld_x(e_up + (s0 + MC) + tv_off);
+        unsigned long long tv_cur = tv;
+        if (!ROT && pre && tv_lane) tv = ld_x(e_up + (s0 + MC) + tv_off);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
+            if (ROT) {                                           // this chunk's lane-0 values; fetch the next chunk's (the whole macro chunk is published)
+                tv_cur = tv;
+                if ((q < NQ - 1 || pre) && tv_lane) tv = ld_x(e_up + (s0 + CH) + tv_off);
+            }
             // the band above: look at its progress words as late as possible (one chunk before the next macro chunk decides on them)
             if (q == NQ - 1 && has_up && !last) {
                 pend_up = __hip_atomic_load(g_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -435,19 +465,24 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                 const int s = s0 + j, jj = q * CH + j;
                 float2 sh[F], right0, bottom0;
                 bottom0 = u2f(xb[j]);
+                const int tvx = (int)(unsigned)(tv_cur & 0xffffffffu), tvy = (int)(unsigned)(tv_cur >> 32);
                 if (FIRST) right0 = u2f(xr[j]);
-                else {
-                    const float fx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), jj));
-                    const float fy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), jj));
-                    right0.x = lane_shr1(bottom0.x, fx);
-                    right0.y = lane_shr1(bottom0.y, fy);
+                else if (ROT) {
+                    right0.x = lane_shr1_vec(bottom0.x, lane0_from(tvx, j));
+                    right0.y = lane_shr1_vec(bottom0.y, lane0_from(tvy, j));
+                } else {
+                    right0.x = lane_shr1(bottom0.x, __int_as_float(__builtin_amdgcn_readlane(tvx, jj)));
+                    right0.y = lane_shr1(bottom0.y, __int_as_float(__builtin_amdgcn_readlane(tvy, jj)));
                 }
 #pragma unroll
                 for (int f = 0; f < F; f++) {
-                    const float fx = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur & 0xffffffffu), (f + 1) * MC + jj));
-                    const float fy = __int_as_float(__builtin_amdgcn_readlane((int)(unsigned)(tv_cur >> 32), (f + 1) * MC + jj));
-                    sh[f].x = lane_shr1(res[f].x, fx);
-                    sh[f].y = lane_shr1(res[f].y, fy);
+                    if (ROT) {
+                        sh[f].x = lane_shr1_vec(res[f].x, lane0_from(tvx, (f + 1) * CH + j));
+                        sh[f].y = lane_shr1_vec(res[f].y, lane0_from(tvy, (f + 1) * CH + j));
+                    } else {
+                        sh[f].x = lane_shr1(res[f].x, __int_as_float(__builtin_amdgcn_readlane(tvx, (f + 1) * MC + jj)));
+                        sh[f].y = lane_shr1(res[f].y, __int_as_float(__builtin_amdgcn_readlane(tvy, (f + 1) * MC + jj)));
+                    }
                 }
                 // operands of the trailing sweeps: the window row written 2f steps ago, f positions down
                 float4 oa[F], ob[F];
