@@ -14,6 +14,7 @@
 //      GCO v3.0 is not vendored: parity unpinned; the oracle is an exact fp64 Dinic cut and the tests compare energies.
 #include "sfa_device.h"
 
+#include <cstdlib>
 #include <utility>
 
 #pragma clang fp contract(off)
@@ -120,6 +121,23 @@ void launch_occ_costs(sfa_ctx *c, const Geo &g, const OccArgs &a, const float *b
 // ---------------------------------------------------------------------------------------------------
 constexpr int kCutInf = 1 << 30;
 struct CutPlanes { float *e, *tc, *c[4], *f[4]; int *hgt, *hgt_next; };   // collect reads hgt, writes hgt_next (deterministic rounds)
+// raise a grid-wide flag: read first, thousands of blocks raising the same word would serialise in the L2 atomic unit
+__device__ __forceinline__ void cut_raise(unsigned *flag) {
+    if (!__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(flag, 1u);
+}
+// Per-tile (= per-block footprint) bookkeeping, so that a round costs what the active region costs and not the whole image:
+//   idle[t]: executed rounds in a row that left tile t unchanged (0 = has active nodes, saturates at 2).  A tile with idle >= 2 has
+//   zero flow buffers and identical height buffers, so its push and collect are no-ops unless a 4-neighbour tile is active
+//   (idle == 0: it may push flow across the border) -- those blocks return after reading the flags.  The arithmetic of the
+//   blocks that run is unchanged, so the rounds are the same rounds.
+//   dirty[t]: tile t changed in the previous breadth-first sweep; a tile is relaxed again only if it or a neighbour is dirty.
+struct CutTiles { int *idle, *idle_next, *dirty, *dirty_next; };
+__device__ __forceinline__ int cut_tile(int b) { return (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
+template <class Pred>
+__device__ __forceinline__ bool cut_tile_nb_any(const int *flag, int t, Pred pred) {      // any 4-neighbour tile of the same window satisfying pred
+    return (blockIdx.x > 0 && pred(flag[t - 1])) || (blockIdx.x + 1 < gridDim.x && pred(flag[t + 1])) ||
+           (blockIdx.y > 0 && pred(flag[t - (int)gridDim.x])) || (blockIdx.y + 1 < gridDim.y && pred(flag[t + (int)gridDim.x]));
+}
 __device__ __forceinline__ long cut_nb(int d, int x, int y, int w, int h, int pitch) {   // offset of neighbour d or 0 if outside
     switch (d) {
     case 0: return x + 1 < w ? 1 : 0;
@@ -129,20 +147,28 @@ __device__ __forceinline__ long cut_nb(int d, int x, int y, int w, int h, int pi
     }
 }
 
-// counts[b] = {#(D1 > D0), #(D1 < D0)}
-__global__ void k_cut_count(const float *__restrict__ d0, const float *__restrict__ d1, unsigned *__restrict__ counts, Geo g) {
+// counts[b] = {#(D1 > D0), #(D1 < D0)}.  gridDim.y row-strided blocks per window, one atomic pair per block
+constexpr int kCountRows = 8;
+__global__ void __launch_bounds__(BX *BY) k_cut_count(const float *__restrict__ d0, const float *__restrict__ d1, unsigned *__restrict__ counts, Geo g) {
+    __shared__ unsigned s_cnt[2];
     const int b = blockIdx.z;
-    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
-    int pos = 0, neg = 0;
-    if (x < g.w && y < g.h) {
-        const size_t o = b * g.pl + (size_t)y * g.pitch + x;
-        const float u = d1[o] - d0[o];
-        pos = u > 0; neg = u < 0;
-    }
-    const unsigned long long mp = __ballot(pos), mn = __ballot(neg);
-    if ((threadIdx.x & 63) == 0) {
-        if (mp) atomicAdd(&counts[2 * b], (unsigned)__popcll(mp));
-        if (mn) atomicAdd(&counts[2 * b + 1], (unsigned)__popcll(mn));
+    const int x = blockIdx.x * BX + threadIdx.x;
+    if (threadIdx.x == 0 && threadIdx.y == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
+    unsigned pos = 0, neg = 0;
+    if (x < g.w)
+        for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
+            const size_t o = b * g.pl + (size_t)y * g.pitch + x;
+            const float u = d1[o] - d0[o];
+            pos += u > 0; neg += u < 0;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { pos += __shfl_down(pos, off); neg += __shfl_down(neg, off); }
+    if ((threadIdx.x & 63) == 0) { if (pos) atomicAdd(&s_cnt[0], pos); if (neg) atomicAdd(&s_cnt[1], neg); }
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        if (s_cnt[0]) atomicAdd(&counts[2 * b], s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&counts[2 * b + 1], s_cnt[1]);
     }
 }
 __global__ void k_cut_init(CutPlanes P, const float *__restrict__ d0, const float *__restrict__ d1, const unsigned *__restrict__ counts, float alpha, Geo g) {
@@ -170,36 +196,74 @@ __global__ void k_cut_bfs_init(CutPlanes P, Geo g) {
     const size_t o = b * g.pl + (size_t)y * g.pitch + x;
     P.hgt[o] = P.tc[o] > 0 ? 1 : kCutInf;
 }
-__global__ void k_cut_bfs_sweep(CutPlanes P, unsigned *__restrict__ changed, Geo g) {
+// One launch relaxes every tile that is dirty or has a dirty 4-neighbour tile: the tile (64 x kBfsRows pixels, 4 rows per thread) and
+// a one-pixel halo of heights go to LDS, the residual-arc masks to registers, and the block iterates to the tile's fixpoint with
+// the halo frozen (any value read there is a valid upper bound of a monotone relaxation, so the order of the tiles does not
+// matter; the global fixpoint -- no tile changes -- is the exact distance).  Distances travel a tile per launch, not a pixel.
+constexpr int kBfsRows = 16, kBfsPer = kBfsRows / BY, kBfsIters = 96;
+__global__ void __launch_bounds__(BX *BY) k_cut_bfs_sweep(CutPlanes P, CutTiles T, unsigned *__restrict__ changed, Geo g) {
+    __shared__ int sh[kBfsRows + 2][BX + 2];
     const int b = blockIdx.z;
-    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
-    bool ch = false;
-    if (x < g.w && y < g.h) {
-        const size_t o = b * g.pl + (size_t)y * g.pitch + x;
-        int hb = P.hgt[o];
-        if (hb > 1) {
-            int best = hb;
+    const int t = cut_tile(b);
+    const bool first = threadIdx.x == 0 && threadIdx.y == 0;
+    if (!T.dirty[t] && !cut_tile_nb_any(T.dirty, t, [](int v) { return v != 0; })) {      // nothing it reads has changed since it last ran
+        if (first) T.dirty_next[t] = 0;
+        return;
+    }
+    const int x0 = blockIdx.x * BX, y0 = blockIdx.y * kBfsRows, tid = threadIdx.y * BX + threadIdx.x;
+    const size_t wb = (size_t)b * g.pl;
+    for (int i = tid; i < (kBfsRows + 2) * (BX + 2); i += BX * BY) {                          // tile + halo (outside the image: unreachable)
+        const int ly = i / (BX + 2), lx = i % (BX + 2), x = x0 + lx - 1, y = y0 + ly - 1;
+        sh[ly][lx] = (x >= 0 && x < g.w && y >= 0 && y < g.h) ? P.hgt[wb + (size_t)y * g.pitch + x] : kCutInf;
+    }
+    const int x = x0 + threadIdx.x;
+    unsigned mask = 0;                                                                        // 4 bits per pixel: residual arc to neighbour d
+    int h0[kBfsPer];
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const long off = cut_nb(d, x, y, g.w, g.h, g.pitch);
-                if (off && P.c[d][o] > 0) {
-                    const int hn = P.hgt[o + off];
-                    if (hn < kCutInf && hn + 1 < best) best = hn + 1;
-                }
-            }
-            if (best < hb) { P.hgt[o] = best; ch = true; }       // neighbours read this sweep's or the last sweep's value: both valid lower bounds of a monotone relaxation
+    for (int k = 0; k < kBfsPer; k++) {
+        const int y = y0 + threadIdx.y + BY * k;
+        if (x < g.w && y < g.h) {
+            const size_t o = wb + (size_t)y * g.pitch + x;
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+                if (cut_nb(d, x, y, g.w, g.h, g.pitch) && P.c[d][o] > 0) mask |= 1u << (4 * k + d);
         }
     }
-    if (__ballot(ch) && (threadIdx.x & 63) == 0) atomicOr(changed, 1u);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBfsPer; k++) h0[k] = sh[threadIdx.y + BY * k + 1][threadIdx.x + 1];
+    for (int it = 0; it < kBfsIters; it++) {
+        bool ch = false;
+#pragma unroll
+        for (int k = 0; k < kBfsPer; k++) {
+            const int ly = threadIdx.y + BY * k + 1, lx = threadIdx.x + 1;
+            const int hb = sh[ly][lx];
+            if (hb > 1 && ((mask >> (4 * k)) & 15u)) {
+                int best = hb;
+                const unsigned m = mask >> (4 * k);
+                if (m & 1u) best = min(best, sh[ly][lx + 1] + 1);                              // kCutInf + 1 does not overflow and never wins
+                if (m & 2u) best = min(best, sh[ly][lx - 1] + 1);
+                if (m & 4u) best = min(best, sh[ly + 1][lx] + 1);
+                if (m & 8u) best = min(best, sh[ly - 1][lx] + 1);
+                if (best < hb) { sh[ly][lx] = best; ch = true; }
+            }
+        }
+        if (!__syncthreads_or(ch)) break;
+    }
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < kBfsPer; k++) {
+        const int y = y0 + threadIdx.y + BY * k;
+        const int hn = sh[threadIdx.y + BY * k + 1][threadIdx.x + 1];
+        if (x < g.w && y < g.h && hn < h0[k]) { P.hgt[wb + (size_t)y * g.pitch + x] = hn; any = true; }
+    }
+    const int tile_changed = __syncthreads_or(any);
+    if (first) { T.dirty_next[t] = tile_changed; if (tile_changed) cut_raise(changed); }
 }
 // push: decisions from the heights of the previous phase only; flows go to per-direction buffers (no atomics)
-__global__ void k_cut_push(CutPlanes P, Geo g, int hmax) {
-    const int b = blockIdx.z;
-    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
-    if (x >= g.w || y >= g.h) return;
-    const size_t o = b * g.pl + (size_t)y * g.pitch + x;
+__device__ __forceinline__ void cut_push_node(const CutPlanes &P, const int *__restrict__ hgt, size_t o, int x, int y, const Geo &g, int hmax) {
     float e = P.e[o];
-    const int hp = P.hgt[o];
+    const int hp = hgt[o];
     float f[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (e > 0 && hp < hmax) {
         float tc = P.tc[o];
@@ -213,7 +277,7 @@ __global__ void k_cut_push(CutPlanes P, Geo g, int hmax) {
             const long off = cut_nb(d, x, y, g.w, g.h, g.pitch);
             if (!off || !(e > 0)) continue;
             const float cd = P.c[d][o];
-            if (cd > 0 && P.hgt[o + off] == hp - 1) {
+            if (cd > 0 && hgt[o + off] == hp - 1) {
                 const float dlt = fminf(e, cd);
                 e -= dlt;
                 P.c[d][o] = cd - dlt;
@@ -225,47 +289,150 @@ __global__ void k_cut_push(CutPlanes P, Geo g, int hmax) {
 #pragma unroll
     for (int d = 0; d < 4; d++) P.f[d][o] = f[d];
 }
-// collect the flows the neighbours sent, then relabel an active node that has no admissible arc left
-__global__ void k_cut_collect(CutPlanes P, unsigned *__restrict__ active, Geo g, int hmax) {
+// collect the flows the neighbours sent, then relabel an active node that has no admissible arc left; true if the node stays active
+__device__ __forceinline__ bool cut_collect_node(const CutPlanes &P, const int *__restrict__ hgt, int *__restrict__ hgt_next, size_t o, int x, int y,
+                                                 const Geo &g, int hmax) {
+    float e = P.e[o];
+    float c[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        c[d] = P.c[d][o];
+        const long off = cut_nb(d, x, y, g.w, g.h, g.pitch);
+        if (off) {
+            const float in = P.f[d ^ 1][o + off];                 // what neighbour d pushed towards this node
+            if (in > 0) { e += in; c[d] += in; P.c[d][o] = c[d]; }
+        }
+    }
+    P.e[o] = e;
+    const int hp = hgt[o];
+    if (e > 0 && hp < hmax) {
+        int best = kCutInf;
+        bool admissible = P.tc[o] > 0;
+        if (admissible) best = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const long off = cut_nb(d, x, y, g.w, g.h, g.pitch);
+            if (off && c[d] > 0) {
+                const int hn = hgt[o + off];
+                if (hn == hp - 1) admissible = true;
+                if (hn < best) best = hn;
+            }
+        }
+        int hnew = hp;
+        if (!admissible) hnew = best >= hmax ? hmax : best + 1;
+        hgt_next[o] = hnew;
+        return hnew < hmax;
+    }
+    hgt_next[o] = hp;
+    return false;
+}
+__global__ void __launch_bounds__(BX *BY) k_cut_push(CutPlanes P, CutTiles T, Geo g, int hmax) {
     const int b = blockIdx.z;
+    if (T.idle[cut_tile(b)] >= 2) return;                        // no excess to push and the flow buffers are already zero
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    cut_push_node(P, P.hgt, b * g.pl + (size_t)y * g.pitch + x, x, y, g, hmax);
+}
+__global__ void __launch_bounds__(BX *BY) k_cut_collect(CutPlanes P, CutTiles T, unsigned *__restrict__ active, Geo g, int hmax) {
+    __shared__ int s_act;
+    const int b = blockIdx.z;
+    const int t = cut_tile(b);
+    const bool first = threadIdx.x == 0 && threadIdx.y == 0;
+    const int self = T.idle[t];
+    if (self >= 2 && !cut_tile_nb_any(T.idle, t, [](int v) { return v == 0; })) {          // settled, and no neighbour tile pushed this round
+        if (first) T.idle_next[t] = 2;
+        return;
+    }
+    if (first) s_act = 0;
+    __syncthreads();
+    const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+    bool act = false;
+    if (x < g.w && y < g.h) act = cut_collect_node(P, P.hgt, P.hgt_next, b * g.pl + (size_t)y * g.pitch + x, x, y, g, hmax);
+    if (__ballot(act) && (threadIdx.x & 63) == 0) s_act = 1;
+    __syncthreads();
+    if (first) { T.idle_next[t] = s_act ? 0 : min(self + 1, 2); if (s_act) cut_raise(active); }
+}
+// after a global relabelling: both height buffers carry the new heights, and the tile bookkeeping is rebuilt from the nodes --
+// a tile is active if it holds an active node, cooling (one more round, to clear its flow buffers) if it took part before, else settled
+__global__ void __launch_bounds__(BX *BY) k_cut_mark(CutPlanes P, CutTiles T, unsigned *__restrict__ n_active, unsigned cap, Geo g, int hmax) {
+    __shared__ int s_act;
+    const int b = blockIdx.z;
+    const int t = cut_tile(b);
+    const bool first = threadIdx.x == 0 && threadIdx.y == 0;
+    if (first) s_act = 0;
+    __syncthreads();
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     bool act = false;
     if (x < g.w && y < g.h) {
         const size_t o = b * g.pl + (size_t)y * g.pitch + x;
-        float e = P.e[o];
-        float c[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            c[d] = P.c[d][o];
-            const long off = cut_nb(d, x, y, g.w, g.h, g.pitch);
-            if (off) {
-                const float in = P.f[d ^ 1][o + off];             // what neighbour d pushed towards this node
-                if (in > 0) { e += in; c[d] += in; P.c[d][o] = c[d]; }
-            }
-        }
-        P.e[o] = e;
         const int hp = P.hgt[o];
-        if (e > 0 && hp < hmax) {
-            int best = kCutInf;
-            bool admissible = P.tc[o] > 0;
-            if (admissible) best = 0;
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const long off = cut_nb(d, x, y, g.w, g.h, g.pitch);
-                if (off && c[d] > 0) {
-                    const int hn = P.hgt[o + off];
-                    if (hn == hp - 1) admissible = true;
-                    if (hn < best) best = hn;
-                }
-            }
-            int hnew = hp;
-            if (!admissible) hnew = best >= hmax ? hmax : best + 1;
-            P.hgt_next[o] = hnew;
-            act = hnew < hmax;
-        } else
-            P.hgt_next[o] = hp;
+        P.hgt_next[o] = hp;
+        act = P.e[o] > 0 && hp < hmax;
     }
-    if (__ballot(act) && (threadIdx.x & 63) == 0) atomicOr(active, 1u);
+    if (__ballot(act) && (threadIdx.x & 63) == 0) s_act = 1;
+    __syncthreads();
+    if (first) {
+        T.idle[t] = s_act ? 0 : (T.idle[t] < 2 ? 1 : 2);
+        // active tiles, counted up to `cap` (beyond it only "many" matters, and thousands of atomics on one word would cost more than the pass)
+        if (s_act && __hip_atomic_load(n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= cap) atomicAdd(n_active, 1u);
+    }
+}
+// The sparse phase.  Once the global relabelling has stranded what cannot reach the terminal, a handful of tiles per window stay
+// active for dozens of rounds, and a round of grid launches costs its launch overhead.  Here ONE workgroup per window runs the same
+// rounds (same node functions, same tile bookkeeping, __syncthreads as the round barrier -- windows are independent problems) on
+// the listed tiles only, `rounds` (even: the height buffers end where the host expects them) at most, stopping early when the
+// window has no active tile left.  flags[0] |= 1 if a window still has active tiles at the end.
+constexpr int kTailThreads = 1024;
+__global__ void __launch_bounds__(kTailThreads) k_cut_tail(CutPlanes P, CutTiles T, unsigned *__restrict__ flags, Geo g, int hmax, int tiles_x, int tiles_y, int rounds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+    const int NT = tiles_x * tiles_y, b = blockIdx.x, tid = threadIdx.x;
+    unsigned char *idle = tail_smem, *idle_next = tail_smem + NT;                             // [NT] each
+    int *list = reinterpret_cast<int *>(tail_smem + ((2 * NT + 15) & ~15));                  // [NT]: tile | push-flag << 30
+    __shared__ int s_cnt, s_active;
+    int *gidle = T.idle + (size_t)b * NT;
+    for (int t = tid; t < NT; t += kTailThreads) idle[t] = (unsigned char)min(gidle[t], 2);
+    const int *hgt = P.hgt;
+    int *hgt_next = P.hgt_next;
+    bool still_active = true;
+    for (int r = 0; r < rounds; r++) {
+        if (tid == 0) { s_cnt = 0; s_active = 0; }
+        __syncthreads();
+        for (int t = tid; t < NT; t += kTailThreads) {                                          // who takes part in this round
+            const int self = idle[t], bx = t % tiles_x, by = t / tiles_x;
+            const bool nb0 = (bx > 0 && idle[t - 1] == 0) || (bx + 1 < tiles_x && idle[t + 1] == 0) || (by > 0 && idle[t - tiles_x] == 0) ||
+                             (by + 1 < tiles_y && idle[t + tiles_x] == 0);
+            if (self == 0) s_active = 1;
+            if (self < 2 || nb0) {
+                list[atomicAdd(&s_cnt, 1)] = t | ((self < 2) << 30);
+                idle_next[t] = (unsigned char)min(self + 1, 2);                                  // unless a node stays active (below)
+            } else
+                idle_next[t] = 2;
+        }
+        __syncthreads();
+        still_active = s_active != 0;
+        if (!still_active && (r & 1) == 0) break;                                             // settled, and an even number of rounds done
+        const int cnt = s_cnt;
+        for (int i = tid / (BX * BY); i < cnt; i += kTailThreads / (BX * BY)) {                 // push
+            const int e = list[i];
+            if (!(e >> 30)) continue;
+            const int t = e & 0x3fffffff, x = (t % tiles_x) * BX + (tid % BX), y = (t / tiles_x) * BY + (tid / BX) % BY;
+            if (x < g.w && y < g.h) cut_push_node(P, hgt, b * g.pl + (size_t)y * g.pitch + x, x, y, g, hmax);
+        }
+        __syncthreads();
+        for (int i = tid / (BX * BY); i < cnt; i += kTailThreads / (BX * BY)) {                 // collect + relabel
+            const int t = list[i] & 0x3fffffff, x = (t % tiles_x) * BX + (tid % BX), y = (t / tiles_x) * BY + (tid / BX) % BY;
+            bool act = false;
+            if (x < g.w && y < g.h) act = cut_collect_node(P, hgt, hgt_next, b * g.pl + (size_t)y * g.pitch + x, x, y, g, hmax);
+            if (__ballot(act) && (tid & 63) == 0) idle_next[t] = 0;
+        }
+        __syncthreads();
+        { const int *h = hgt; hgt = hgt_next; hgt_next = const_cast<int *>(h); }
+        { unsigned char *q = idle; idle = idle_next; idle_next = q; }
+    }
+    __syncthreads();
+    bool any = false;
+    for (int t = tid; t < NT; t += kTailThreads) { gidle[t] = idle[t]; any |= idle[t] == 0; }
+    if (__ballot(any) && (tid & 63) == 0) cut_raise(&flags[0]);
 }
 // after the final breadth-first pass: a node that still reaches the passive terminal lies on its side
 __global__ void k_cut_labels(float *__restrict__ occ, long occ_es, CutPlanes P, const unsigned *__restrict__ counts, Geo g) {
@@ -280,7 +447,7 @@ __global__ void k_cut_labels(float *__restrict__ occ, long occ_es, CutPlanes P, 
     occ[b * occ_es + (size_t)y * g.pitch + x] = (float)(2 * l - 1);                  // variational_aux_mt.cpp:876
 }
 
-// Runs the cut for every window of the batch.  d0, d1: cost planes [nb][pl]; work: kCutWorkPlanes planes [nb][pl] of scratch;
+// Runs the cut for every window of the batch.  d0, d1: cost planes [nb][pl]; work: kCutWorkPlanes planes [nb][pl] of scratch (the last one: tile flags);
 // occ: output planes of element 0 (+occ_es per window).  Bounded: gives up (SFA_ERR_TIMEOUT) after max_rounds.
 int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float *d0, const float *d1, float *work, float alpha) {
     CutPlanes P;
@@ -296,35 +463,67 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
     gc.es = g.pl;                                                 // the cut planes are packed [nb][pl]
     const dim3 grid = grid2d(gc), block = block2d();
     const int hmax = g.w * g.h;
+    const size_t ntiles = (size_t)grid.x * grid.y * grid.z;       // far fewer than the n floats of work plane 12 (one tile = BX * BY pixels)
+    CutTiles T;
+    T.idle = reinterpret_cast<int *>(work + 12 * n);
+    T.idle_next = T.idle + ntiles;
+    T.dirty = T.idle + 2 * ntiles;
+    T.dirty_next = T.idle + 3 * ntiles;
     SFA_HIP(c, hipMemsetAsync(flags, 0, (2 + 2 * g.nb) * sizeof(unsigned), c->stream));
-    hipLaunchKernelGGL(k_cut_count, grid, block, 0, c->stream, d0, d1, counts, gc);
+    hipLaunchKernelGGL(k_cut_count, dim3(grid.x, std::min((int)grid.y, kCountRows), grid.z), block, 0, c->stream, d0, d1, counts, gc);
     hipLaunchKernelGGL(k_cut_init, grid, block, 0, c->stream, P, d0, d1, counts, alpha, gc);
+    SFA_HIP(c, hipMemsetAsync(T.idle, 0, ntiles * sizeof(int), c->stream));                  // no tile is settled yet (k_cut_mark refines this)
+    const dim3 bfs_grid(grid.x, (g.h + kBfsRows - 1) / kBfsRows, grid.z);          // its own, taller tiles; the dirty flags are indexed by this grid
+    constexpr unsigned kTailMaxTiles = 48;                        // active tiles per window up to which one workgroup per window is the faster way
+    unsigned n_active = ~0u;                                      // tiles with active nodes (counted up to that bound), as of the last global relabelling
     auto global_relabel = [&]() -> int {
         hipLaunchKernelGGL(k_cut_bfs_init, grid, block, 0, c->stream, P, gc);
-        for (long guard = 0; guard < (long)g.w * g.h + 8; guard += 8) {
-            SFA_HIP(c, hipMemsetAsync(flags, 0, sizeof(unsigned), c->stream));
-            for (int i = 0; i < 8; i++) hipLaunchKernelGGL(k_cut_bfs_sweep, grid, block, 0, c->stream, P, flags, gc);
-            SFA_HIP(c, hipMemcpyAsync(h_flag, flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        SFA_HIP(c, hipMemsetAsync(T.dirty, 1, ntiles * sizeof(int), c->stream));            // every tile starts dirty (any non-zero value)
+        constexpr int kSweeps = 4;                                 // per convergence check (even: the dirty buffers end where they started)
+        for (long guard = 0; guard < (long)g.w * g.h + 8; guard += kSweeps) {
+            SFA_HIP(c, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));
+            for (int i = 0; i < kSweeps; i++) {
+                hipLaunchKernelGGL(k_cut_bfs_sweep, bfs_grid, block, 0, c->stream, P, T, flags, gc);
+                std::swap(T.dirty, T.dirty_next);
+            }
+            // new heights everywhere: resynchronise the height buffers and the tile states, and count the active tiles -- valid if this
+            // batch of sweeps changed nothing (then the heights were final before it); otherwise repeated after the next batch
+            hipLaunchKernelGGL(k_cut_mark, grid, block, 0, c->stream, P, T, flags + 1, kTailMaxTiles * (unsigned)g.nb, gc, hmax);
+            SFA_HIP(c, hipMemcpyAsync(h_flag, flags, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             SFA_HIP(c, hipStreamSynchronize(c->stream));
-            if (!*h_flag) return SFA_OK;
+            if (!h_flag[0]) { n_active = h_flag[1]; return SFA_OK; }
         }
         return set_error(c, SFA_ERR_TIMEOUT, "grid cut: breadth-first relabelling did not settle");   // unreachable: distances are < w*h
     };
     SFA_TRY(global_relabel());
     const int max_rounds = 64 * (g.w + g.h);
+    // Rounds come in batches between two global relabellings (which strand the excess that can no longer reach the terminal):
+    // grid launches (kGridRounds rounds of push + collect over all tiles) while many tiles are active, the one-workgroup-per-window
+    // kernel (kTailRounds rounds at most) once few are.  flags[0]: some node still active.
+    constexpr int kGridRounds = 8, kTailRounds = 32;           // both even: the height / tile-state buffers end where they started
+    const int tiles_w = (int)(grid.x * grid.y);
+    const size_t tail_lds = (((size_t)2 * tiles_w + 15) & ~(size_t)15) + (size_t)4 * tiles_w;
+    const bool tail_fits = tail_lds <= 150 * 1024 && !getenv("SFA_CUT_NO_TAIL");   // the switch: grid rounds only (cross-check in the tests)
     bool done = false;
-    for (int round = 0; round < max_rounds && !done; round += 8) {
-        SFA_HIP(c, hipMemsetAsync(flags, 0, sizeof(unsigned), c->stream));
-        for (int i = 0; i < 8; i++) {
-            hipLaunchKernelGGL(k_cut_push, grid, block, 0, c->stream, P, gc, hmax);
-            if (i == 7) SFA_HIP(c, hipMemsetAsync(flags, 0, sizeof(unsigned), c->stream));   // only the last collect's verdict counts
-            hipLaunchKernelGGL(k_cut_collect, grid, block, 0, c->stream, P, flags, gc, hmax);
-            std::swap(P.hgt, P.hgt_next);
+    for (int round = 0; round < max_rounds && !done;) {
+        SFA_HIP(c, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));
+        if (tail_fits && n_active <= kTailMaxTiles * (unsigned)g.nb) {
+            hipLaunchKernelGGL(k_cut_tail, dim3(g.nb), dim3(kTailThreads), tail_lds, c->stream, P, T, flags, gc, hmax, (int)grid.x, (int)grid.y, kTailRounds);
+            round += kTailRounds;
+        } else {
+            for (int i = 0; i < kGridRounds; i++) {
+                hipLaunchKernelGGL(k_cut_push, grid, block, 0, c->stream, P, T, gc, hmax);
+                if (i == kGridRounds - 1) SFA_HIP(c, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));   // only the last collect's verdict counts
+                hipLaunchKernelGGL(k_cut_collect, grid, block, 0, c->stream, P, T, flags, gc, hmax);
+                std::swap(P.hgt, P.hgt_next);
+                std::swap(T.idle, T.idle_next);
+            }
+            round += kGridRounds;
         }
-        SFA_HIP(c, hipMemcpyAsync(h_flag, flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        SFA_HIP(c, hipMemcpyAsync(h_flag, flags, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         SFA_HIP(c, hipStreamSynchronize(c->stream));
-        done = !*h_flag;
-        if (!done && (round / 8) % 4 == 3) SFA_TRY(global_relabel());   // strands excess that can no longer reach the terminal
+        done = !h_flag[0];
+        if (!done) SFA_TRY(global_relabel());
     }
     if (!done) return set_error(c, SFA_ERR_TIMEOUT, "grid cut: push-relabel did not settle in %d rounds", max_rounds);
     SFA_TRY(global_relabel());

@@ -158,7 +158,7 @@ struct OccSlot {
 };
 struct OccArgs { OccSlot slot[2 * SFA_MAX_REF]; int nslots; float hd, hg, penalty; PenaltyDev color, grad; };
 void launch_occ_costs(sfa_ctx *c, const Geo &g, const OccArgs &a, const float *base, float *d0, float *d1, long d_es /* window stride of d0,d1 */);
-constexpr int kCutWorkPlanes = 12;
+constexpr int kCutWorkPlanes = 13;
 // exact two-label cut of sum D_l(p) + alpha * [l_p != l_q] over 4-neighbours; occ = 2*l - 1.  d0, d1, work: planes packed [nb][pl]
 int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float *d0, const float *d1, float *work, float alpha);
 

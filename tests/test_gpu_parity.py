@@ -673,6 +673,17 @@ def test_grid_cut_full_size(ctx, oracle):
     assert abs(oracle.grid_cut_energy(og, a0, a1, 0.5, w) - e_o) <= 1e-5 * abs(e_o)
 
 
+@pytest.mark.parametrize("kind,w,h", [("blobs", 1024, 436), ("stripes", 300, 200), ("noise", 130, 98), ("blobs", 67, 45)])
+def test_grid_cut_sparse_phase_runs_the_same_rounds(ctx, monkeypatch, kind, w, h):
+    """the one-workgroup-per-window kernel of the sparse phase executes the rounds the grid launches would: identical labels"""
+    rng = np.random.default_rng(w + h)
+    d0, d1 = _cut_case(rng, w, h, kind)
+    occ_tail = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
+    monkeypatch.setenv("SFA_CUT_NO_TAIL", "1")
+    occ_grid = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
+    assert np.array_equal(occ_tail, occ_grid)
+
+
 @pytest.mark.parametrize("S,rho,omega", [(2, [1], [0]), (3, [1, 1], [0, 2])])
 def test_level_with_occlusion_reasoning(ctx, oracle, S, rho, omega):
     """alternations with the discrete occlusion step (cfgs/slow_flow.cfg: occlusion reasoning on): same labels, same flow"""

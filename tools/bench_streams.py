@@ -9,6 +9,7 @@ windows=[bench.synth_window(b) for b in range(4)]
 allf=[f for w in windows for f in w]
 avg,std=ctxs[0].normalize(allf,bench.W)
 p=bench.bench_params()
+if os.environ.get('SOLVER_K'): p.niter_solver=int(os.environ['SOLVER_K'])   # experiment: K=15 band workgroups (77 KB LDS) can share a CU with the assembly's
 for k in range(3): p.norm_avg[k]=float("%g"%avg[k]); p.norm_std[k]=float("%g"%std[k])
 jobs=[sfa.Job(c,p,bench.W,bench.H,B) for c in ctxs]
 for j in jobs:
