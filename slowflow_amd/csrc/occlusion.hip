@@ -503,7 +503,9 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
     constexpr int kGridRounds = 8, kTailRounds = 32;           // both even: the height / tile-state buffers end where they started
     const int tiles_w = (int)(grid.x * grid.y);
     const size_t tail_lds = (((size_t)2 * tiles_w + 15) & ~(size_t)15) + (size_t)4 * tiles_w;
-    const bool tail_fits = tail_lds <= 150 * 1024 && !getenv("SFA_CUT_NO_TAIL");   // the switch: grid rounds only (cross-check in the tests)
+    // worth it only when a grid launch is mostly block scheduling (many windows); a single window's grid is a few thousand blocks.
+    // SFA_CUT_NO_TAIL / SFA_CUT_TAIL force one way (cross-check in the tests)
+    const bool tail_fits = tail_lds <= 150 * 1024 && !getenv("SFA_CUT_NO_TAIL") && (ntiles >= 6000 || getenv("SFA_CUT_TAIL"));
     bool done = false;
     for (int round = 0; round < max_rounds && !done;) {
         SFA_HIP(c, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));

@@ -678,7 +678,9 @@ def test_grid_cut_sparse_phase_runs_the_same_rounds(ctx, monkeypatch, kind, w, h
     """the one-workgroup-per-window kernel of the sparse phase executes the rounds the grid launches would: identical labels"""
     rng = np.random.default_rng(w + h)
     d0, d1 = _cut_case(rng, w, h, kind)
+    monkeypatch.setenv("SFA_CUT_TAIL", "1")                     # a single window would not take it by itself
     occ_tail = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
+    monkeypatch.delenv("SFA_CUT_TAIL")
     monkeypatch.setenv("SFA_CUT_NO_TAIL", "1")
     occ_grid = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
     assert np.array_equal(occ_tail, occ_grid)
