@@ -507,6 +507,7 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
     // SFA_CUT_NO_TAIL / SFA_CUT_TAIL force one way (cross-check in the tests)
     const bool tail_fits = tail_lds <= 150 * 1024 && !getenv("SFA_CUT_NO_TAIL") && (ntiles >= 6000 || getenv("SFA_CUT_TAIL"));
     bool done = false;
+    int batches = 0;
     for (int round = 0; round < max_rounds && !done;) {
         SFA_HIP(c, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));
         if (tail_fits && n_active <= kTailMaxTiles * (unsigned)g.nb) {
@@ -525,7 +526,12 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
         SFA_HIP(c, hipMemcpyAsync(h_flag, flags, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         SFA_HIP(c, hipStreamSynchronize(c->stream));
         done = !h_flag[0];
-        if (!done) SFA_TRY(global_relabel());
+        // relabel after every batch while few tiles are active (it strands what only climbs) and after the first batch; with many
+        // active tiles the flow is still moving and a relabelling per 8 rounds would cost more than the rounds: every 4th batch
+        constexpr int dense_every = 4;
+        batches++;
+        const bool dense = n_active > kTailMaxTiles * (unsigned)g.nb;
+        if (!done && (!dense || batches == 1 || batches % dense_every == 0)) SFA_TRY(global_relabel());
     }
     if (!done) return set_error(c, SFA_ERR_TIMEOUT, "grid cut: push-relabel did not settle in %d rounds", max_rounds);
     SFA_TRY(global_relabel());
