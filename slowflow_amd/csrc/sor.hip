@@ -334,6 +334,12 @@ __device__ __forceinline__ bool wait_lds_ge(unsigned *p, unsigned target, unsign
     return true;
 }
 
+#ifdef SFA_BAND_TIMING
+__device__ unsigned long long g_band_timing[16 * 16 * 6];
+} // namespace sfa
+extern "C" int sfa_debug_band_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sfa::g_band_timing), sizeof(unsigned long long) * 16 * 16 * 6); }
+namespace sfa {
+#endif
 // ROLE of a wave in the band pipeline: 0 first stage (reads the initial x), 1 middle, 2 last (stores the final x),
 // 3 the only stage (K == F).  The role is a template parameter so that the per-step code carries no role branches.
 // Two granularities: operands are refilled and the LDS hand-over to the next stage happens every CH steps; the
@@ -403,6 +409,14 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     auto need_up2 = [&](int m) { return (unsigned)min(m + 1 + (64 + F + MC - 1) / MC, NMC); };
     auto ready = [&](int m) { return !has_up || (known_up >= need_up(m) && (FIRST || known_up2 >= need_up2(m))); };
 
+#ifdef SFA_BAND_TIMING
+    unsigned long long t_begin = __builtin_readcyclecounter(), t_up = 0, t_down = 0, t_band = 0, t_tmp = 0, t_first = 0;
+#define SFA_T0() t_tmp = __builtin_readcyclecounter()
+#define SFA_T1(acc) acc += __builtin_readcyclecounter() - t_tmp
+#else
+#define SFA_T0()
+#define SFA_T1(acc)
+#endif
     // ---- prologue ---------------------------------------------------------------------------------------
     if (has_up) {
         // start one macro chunk further behind the band above than strictly needed: its progress is seen one macro chunk
@@ -429,6 +443,9 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     if (tv_lane) tv = ld_x(e_up + tv_off);
 
     int s0 = 0;
+#ifdef SFA_BAND_TIMING
+    t_first = __builtin_readcyclecounter();
+#endif
     for (int m = 0; m < NMC; m++) {
         const bool last = m + 1 >= NMC;
         bool pre = false;
@@ -452,13 +469,17 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
             }
             if (!FIRST) {                                        // the previous stage: its last iterate through the LDS ring
                 const unsigned need = (unsigned)min(s0 + CH - 1 + F, NSP);
+                SFA_T0();
                 if (!wait_lds_ge(&lprog[wave - 1], need, a.err)) return;
+                SFA_T1(t_up);
 #pragma unroll
                 for (int j = 0; j < CH; j++) xb[j] = ring[wave - 1][(s0 + j + F - 1) & (RING - 1)][lane];
             }
             if (!LASTW) {                                        // back-pressure: do not overrun slots wave+1 has not read
                 const int need = s0 + CH - 1 - a.lead - F + 2;
+                SFA_T0();
                 if (need > 0 && !wait_lds_ge(&lprog[wave + 1], (unsigned)need, a.err)) return;
+                SFA_T1(t_down);
             }
 #pragma unroll
             for (int j = 0; j < CH; j++) {
@@ -502,11 +523,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                     nres[f] = make_float2(xn.x, xn.y);
                     // lane 63's iterate of every sweep is band b+1's lane-0 input (zeros outside the image land in the row pads)
                     if (publishes && lane == 63) estage[f][jj] = f2u(xn.x, xn.y);      // staged in LDS, stored once per macro chunk
-                    if (f == F - 1) {
-                        if (!LASTW) ring[wave][s & (RING - 1)][lane] = f2u(xn.x, xn.y);
-                        else if (row_ok_last && (unsigned)(s - lane - f) < (unsigned)W)
-                            *reinterpret_cast<unsigned long long *>(bx - (long)f * FOFF * 8 + vo8) = f2u(xn.x, xn.y);   // final iterate
-                    }
+                    if (f == F - 1 && !LASTW) ring[wave][s & (RING - 1)][lane] = f2u(xn.x, xn.y);
                     hl[f] = ob[f].z;
                     selfv[f] = right;
                 }
@@ -526,6 +543,10 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                     xr[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8));
                     xb[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8 + 8));
                 }
+                // the final iterate leaves behind this step's refills: vmcnt retires in order, so a store queued ahead of the operand
+                // loads would have to be acknowledged before they count as arrived (one step of prefetch depth lost to the write latency)
+                if (LASTW && row_ok_last && (unsigned)(s - lane - (F - 1)) < (unsigned)W)
+                    *reinterpret_cast<unsigned long long *>(bx - (long)(F - 1) * FOFF * 8 + vo8) = f2u(res[F - 1].x, res[F - 1].y);
                 vo16 += st16;
                 vo8 += st8;
             }
@@ -547,16 +568,24 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
             st_x(e_mine + (long)fi * a.Wp + (s0 - MC - 63 - fi + j), estage[fi][j]);
         }
         if (has_up && !last && !pre) {
+            SFA_T0();
             known_up = wait_ge(g_up, need_up(m + 1), a.err);
             if (known_up == 0xffffffffu) return;
             if (!FIRST) { known_up2 = wait_ge(g_up2, need_up2(m + 1), a.err); if (known_up2 == 0xffffffffu) return; }
             if (tv_lane) tv = ld_x(e_up + s0 + tv_off);
+            SFA_T1(t_band);
         }
     }
     if (publishes) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(gmine, (unsigned)NMC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef SFA_BAND_TIMING
+    if (job == 0 && lane == 0 && b < 16 && wave < 16) {
+        unsigned long long *o = g_band_timing + (b * 16 + wave) * 6;
+        o[0] = t_begin; o[1] = __builtin_readcyclecounter(); o[2] = t_up; o[3] = t_down; o[4] = t_band; o[5] = t_first;
+    }
+#endif
 }
 
 template <int F, int MAXW, int CH, int MC, int RING>
