@@ -715,9 +715,10 @@ __global__ void k_sor_readable(float *du_, float *dv_, const float *a11_, const 
 // ---------------------------------------------------------------------------------------------------
 // band kernel (all K sweeps of a band in one workgroup): F fused sweeps per wave, NW = K/F waves; 0 = not applicable
 static int band_shape(int K, int nb) {
-    // default: batches (>= 16 systems in lockstep) take the band kernel, single solves the task kernel whose K stages
+    // default: batches (>= 8 systems in lockstep: the two kernels tie at 8, and the band kernel leaves most CUs to a second stream) take
+    // the band kernel, single solves the task kernel whose K stages
     // spread over K CUs (shorter critical path); SFA_SOR_BAND = 0 (never) / 1..3 (always, that many fused sweeps)
-    int F = nb >= 16 ? 3 : 0;
+    int F = nb >= 8 ? 3 : 0;
     if (const char *e = getenv("SFA_SOR_BAND")) F = atoi(e);
     if (F <= 0 || F > 5 || F == 4) return 0;
     auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f <= (f == 5 ? 6 : f == 3 ? 10 : 16); };
