@@ -7,7 +7,7 @@
 // demosaicers (raw_demosaicing 1, 2), DeepMatching/EpicFlow initialisation, adaptive frame rates -- they
 // live in third-party code (OpenCV, MATLAB SED, DeepMatching) outside the path.
 //
-// New, additive keys: gpus (default: all visible), gpu_batch (default 8), gpu_device (first device, default 0).
+// New, additive keys: gpus (default: all visible), gpu_batch (windows refined in lockstep per job, default 32), gpu_streams (default 2), gpu_device (first device, default 0).
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -244,7 +244,7 @@ int main(int argc, char **argv) {
     if (ngpu <= 0) { std::cerr << "no HIP device: slowflow_amd has no CPU fallback" << std::endl; return 4; }
     if (params.exists("gpus")) ngpu = std::max(1, std::min(ngpu, params.parameter<int>("gpus")));
     const int dev0 = params.parameter<int>("gpu_device", "0");
-    const int batch = std::max(1, std::min(64, params.parameter<int>("gpu_batch", "8")));
+    const int batch = std::max(1, std::min(64, params.parameter<int>("gpu_batch", "32")));
     const int F = 2 * ref + 1;
     const bool backward_forward_only = params.exists("method") && params.parameter("method") == "forward";   // :1019-1020
 
@@ -264,11 +264,12 @@ int main(int argc, char **argv) {
         ParameterList tp(params);                                                    // one copy per thread (:708)
         for (size_t b0 = lo; b0 < hi && !failed; b0 += batch) {
             const size_t nb = std::min((size_t)batch, hi - b0);
-            // forward and backward windows may differ in one_direction: split by direction flag
-            for (int dirpass = 0; dirpass < 2; dirpass++) {
+            // forward and backward windows share one lockstep job (the channel weights are per window) unless the backward solver runs with
+            // different parameters ("method forward", :1019-1020): then one job per direction
+            for (int dirpass = 0; dirpass < (backward_forward_only ? 2 : 1); dirpass++) {
                 std::vector<size_t> idx;
                 for (size_t i = 0; i < nb; i++)
-                    if ((int)todo[b0 + i].backward == dirpass) idx.push_back(b0 + i);
+                    if (!backward_forward_only || (int)todo[b0 + i].backward == dirpass) idx.push_back(b0 + i);
                 if (idx.empty()) continue;
                 sfa_params sp = sfa_params_from_cfg(tp, dirpass == 1 ? backward_forward_only : false);
                 sfa_job *job = nullptr;
