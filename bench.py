@@ -118,6 +118,23 @@ def cpu_baseline(budget_s=12.0):
     return out
 
 
+def hbm_triad_gbs(torch):
+    """what this box's HBM delivers to a plain streaming kernel (a = b + s * c on 3 x 1 GiB, torch elementwise): printed beside the
+    8 TB/s vendor peak that `roofline.frac` divides by (SURVEY.md 8d asks for both)"""
+    n = 1 << 28
+    b = torch.ones(n, dtype=torch.float32, device="cuda"); c = torch.ones(n, dtype=torch.float32, device="cuda"); a = torch.empty_like(b)
+    for _ in range(2):
+        torch.add(b, c, alpha=2.0, out=a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        torch.add(b, c, alpha=2.0, out=a)
+    e1.record(); torch.cuda.synchronize()
+    return 3.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def measured_traffic(batch):
     """HBM-side bytes per SOR launch from the PMC passes of profiles/collect_traffic.sh (FETCH_SIZE x2 on gfx950 for wide
     reads + WRITE_SIZE, separate passes; MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process,
@@ -285,6 +302,10 @@ def main():
             out["roofline"]["sor_1024x436_single"] = {"batch": 1, "avg_launch_ms": round(ms2 / n2, 4), "achieved": round(by2 / (ms2 * 1e-3) / 1e9, 1),
                                                       "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                       "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}
+        try:
+            out["roofline"]["measured_triad_gbs"] = round(hbm_triad_gbs(torch), 1)
+        except Exception as e:                                    # a measurement aid only
+            out["roofline"]["measured_triad_gbs"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
