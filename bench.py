@@ -8,8 +8,10 @@ config 2: 1024x436, S=2 (3 frames), 5 pyramid levels, 5 outer x 1 inner x 30 SOR
 uploaded to HBM before the timed region.  value = (sum over all ranks and SOR solves of w*h*K) / wall time / 1e6.
 
   python bench.py --gpus N --steps K --warmup W [--batch B]
-N > 1 is launched by torch.distributed.run (one rank per GPU over RCCL); frame windows shard across ranks with no
-data-path collective (weak scaling); the only exchange is a gather of per-rank timings.
+N > 1 runs one rank per GPU over RCCL: either the caller starts the ranks (`python -m torch.distributed.run ... bench.py
+--gpus N ...`: RANK / WORLD_SIZE are in the environment) or, when they are not, bench.py starts them itself as a CHILD
+torch.distributed.run process before anything touches the GPU and relays its output and exit code (launch_ranks).  Frame
+windows shard across ranks with no data-path collective (weak scaling); the only exchange is a gather of per-rank timings.
 
 The JSON line also carries `roofline` (SOR solve kernel: algorithmic bytes / HIP-event duration over the timed
 region) and, on rank 0 at N=1, `cpu_baseline` (the reference's own sor_coupled from oracle/_ref, or the oracle port,
@@ -207,6 +209,62 @@ def sor_only(ctx, B, rank):
     return n1, ms1, by1, n2, ms2, by2
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n, argv, port):
+    """the command line that runs this script as n ranks on one node (the form the round driver itself uses)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    """`--gpus N` without a torch.distributed environment: start the N ranks as a child process (never exec: nothing in this
+    process has touched the GPU, and nothing will) and hand back its exit code; the child's rank 0 prints the JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(launch_command(n, argv, free_port()), env=env).returncode
+
+
+def selftest_launch(args):
+    """CPU rehearsal of the N>1 plumbing (tests/test_bench_launch.py): the ranks meet over gloo, run the same barrier / max-over-ranks /
+    timing-gather sequence as the real bench around a sleep, and rank 0 prints a line that is labelled as a selftest -- no GPU work,
+    no throughput claim."""
+    import torch
+    import torch.distributed as dist
+    from slowflow_amd import shard
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    d = dist if world > 1 else None
+    B = args.batch
+    if d is not None:
+        d.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps * (1 + rank))
+    elapsed = time.perf_counter() - t0
+    if d is not None:
+        d.barrier()
+    elapsed_max = shard.max_over_ranks(d, elapsed)
+    lo, hi = shard.partition(B * world, world, rank)
+    ws = shard.gather_timings(d, {i: elapsed / args.steps / B for i in range(lo, hi)}, B * world)
+    if rank == 0:
+        print(json.dumps({"metric": "selftest (launcher + torch.distributed plumbing on CPU, no GPU work)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
+                          "seconds_per_window": {"n": int(ws.size), "nonzero": int((ws > 0).sum())}}), flush=True)
+    if d is not None:
+        d.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,7 +275,16 @@ def main():
                     "(the reference drives its windows from OpenMP threads, slow_flow.cpp:706): the groups fill each other's ramp-up / drain phases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path-only", action="store_true", help="skip the SOR-only section (used for the PMC passes: every SOR dispatch then belongs to the path)")
+    ap.add_argument("--selftest-launch", action="store_true", help="CPU rehearsal of the multi-rank launch and exchange (gloo); prints a selftest line, never a result")
     args = ap.parse_args()
+
+    # N > 1 and nobody started the ranks: do it here, as a child process, before torch / HIP are touched
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.selftest_launch:
+        return selftest_launch(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: start one rank per GPU")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,0 +1,47 @@
+"""bench.py --gpus N must really run N ranks: the launch line, the child-process launch itself and the
+exchange sequence (barrier, max over ranks, gather of per-window timings), rehearsed on CPU over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_launch_line_is_the_drivers_form():
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # exactly one JSON line: rank 0's
+    return json.loads(lines[0])
+
+
+def test_gpus_2_starts_two_ranks():
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--selftest-launch"])
+    assert out["n_gpus"] == 2 and out["steps"] == 3
+    assert out["seconds_per_window"] == {"n": 8, "nonzero": 8}      # both ranks' windows arrived
+    assert out["ms_per_step"] >= 19.0                                  # the MAX over ranks (rank 1 sleeps twice as long)
+
+
+def test_gpus_1_stays_in_process():
+    out = _run(["--gpus", "1", "--steps", "2", "--selftest-launch"])
+    assert out["n_gpus"] == 1
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)
