@@ -178,10 +178,16 @@ void sfa_job_destroy(sfa_job *job);
 int  sfa_job_upload(sfa_job *job, int b, const float *const *frames, int n_frames, const float *wx, const float *wy,
                     int stride, const float *const chw[3]);
 int  sfa_job_reset_flow(sfa_job *job);               /* re-arm every element with the uploaded initial flow */
-int  sfa_job_run(sfa_job *job);                      /* the whole coarse-to-fine path, asynchronous on the ctx stream */
+int  sfa_job_run(sfa_job *job);                      /* the whole coarse-to-fine path on the ctx stream; may be called again on the same uploads
+                                                        (same result: presmoothing, cfg sigma > 0, is applied once per upload) */
 int  sfa_job_download(sfa_job *job, int b, float *wx, float *wy, int stride, float change[2]);
 /* Variational_MT::getOcclusions() of window b after the run: -1 occluded in the past / forward terms only, +1 in the future, 0 none */
 int  sfa_job_download_occlusions(sfa_job *job, int b, float *occ, int stride);
+/* Per-alternation labels (key slow_flow_occlusions_output: the reference writes <prefix><alter>.png after the discrete step of every alternation
+ * alter >= 1, variational_mt.cpp:275-285; every pyramid level overwrites the file, the finest level's survives).  Enable before the run; after it
+ * download the finest level's labels of alternation 1 <= alter < niter_alter of window b. */
+int  sfa_job_keep_alternation_occlusions(sfa_job *job, int on);
+int  sfa_job_download_alternation_occlusions(sfa_job *job, int b, int alter, float *occ, int stride);
 double sfa_job_mpix_iters(const sfa_job *job);       /* sum over the job's SOR solves of w*h*K / 1e6, per run */
 
 /* SOR-only resident batch: `batch` independent systems of one size */

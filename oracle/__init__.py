@@ -236,6 +236,20 @@ class Oracle:
         self.lib.orc_gaussian_blur_cv(fptr(dst), fptr(src), w, h, stride, C.c_float(sigma))
         return dst
 
+    def resize_linear_fx(self, src, sw, fx, fy):
+        """cv::resize(src, Size(0,0), fx, fy): dsize = cvRound(size * f) (round half to even), source coordinate (dst + .5) / f - .5"""
+        sh, sstride = src.shape
+        dw, dh = int(np.rint(sw * fx)), int(np.rint(sh * fy))
+        dst = plane(dh, stride_of(dw))
+        self.lib.orc_resize_linear_fx(fptr(dst), dw, dh, stride_of(dw), fptr(src), sw, sh, sstride, C.c_double(fx), C.c_double(fy))
+        return dst, dw
+
+    def mask_weight(self, masks, occ, ref, data_norm, one_direction, w):
+        """masks (2ref,h,stride) weighted in place (variational_mt.cpp:293-320)"""
+        _, h, stride = masks.shape
+        self.lib.orc_mask_weight(fptr(masks), fptr(occ), int(ref), C.c_float(data_norm), int(one_direction), w, h, stride)
+        return masks
+
     def resize_linear_cv(self, src, sw, dw, dh):
         sh, sstride = src.shape
         dst = plane(dh, stride_of(dw))

@@ -854,6 +854,25 @@ double orc_grid_cut(float *occ, const float *d0, const float *d1, float alpha, i
 /* ------------------------------------------------------------------------------------------
  * variational_mt.cpp:169-493 -- one pyramid level
  * ---------------------------------------------------------------------------------------- */
+/* variational_mt.cpp:293-320: the occlusion / direction weighting of the warp masks, in place.
+ * masks: 2*ref planes; occ: -1 / 0 / +1 per pixel; data_norm = sum_a (rho[a] + omega[a]) (:223-226) */
+void orc_mask_weight(float *masks, const float *occ, int ref, float data_norm, int one_direction, int w, int h, int stride) {
+    const size_t plane = (size_t)stride * h;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t o = (size_t)y * stride + x;
+            float factor = (occ[o] == 0.0f) ? 1.0f : 0.0f;                      /* :295 */
+            factor = (1 + factor) * data_norm;                                  /* :297-300 */
+            const float backward = ((occ[o] >= 0.0f) ? 1.0f : 0.0f) / factor;   /* :302 */
+            const float forward = ((occ[o] <= 0.0f) ? 1.0f : 0.0f) / factor;    /* :303 */
+            for (int s = one_direction ? ref : 0; s < 2 * ref; s++) {           /* :305-318 */
+                float *m = masks + s * plane + o;
+                if (s < ref) *m = 1.0f * backward * (*m);
+                else         *m = 1.0f * forward * (*m);
+            }
+        }
+}
+
 int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *const *frames,
                           const float *const chw[3], float *occ_out, int w, int h, int stride, float change[2]) {
     const int ref = p->S - 1;
@@ -915,20 +934,7 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
                     occ_pending = 0;
                 }
             }
-            /* mask weighting :293-320 */
-            for (int y = 0; y < h; y++)
-                for (int x = 0; x < w; x++) {
-                    const size_t o = (size_t)y * stride + x;
-                    float factor = (occ[o] == 0.0f) ? 1.0f : 0.0f;
-                    factor = (1 + factor) * data_norm;
-                    const float backward = ((occ[o] >= 0.0f) ? 1.0f : 0.0f) / factor;
-                    const float forward = ((occ[o] <= 0.0f) ? 1.0f : 0.0f) / factor;
-                    for (int s = p->one_direction ? ref : 0; s < nslots; s++) {
-                        float *m = mask + s * plane + o;
-                        if (s < ref) *m = 1.0f * backward * (*m);
-                        else         *m = 1.0f * forward * (*m);
-                    }
-                }
+            orc_mask_weight(mask, occ, ref, data_norm, p->one_direction, w, h, stride);   /* :293-320 */
             memset(du, 0, plane * sizeof(float));
             memset(dv, 0, plane * sizeof(float));
 
@@ -1065,8 +1071,18 @@ void orc_gaussian_blur_cv(float *dst, const float *src, int w, int h, int stride
 /* cv::resize(..., INTER_LINEAR) on CV_32F: fx = (float)((dx+0.5)*(sw/dw) - 0.5); sx = floor(fx);
  * fx -= sx; sx<0 -> (0, fx=0); sx>=sw-1 -> (sw-1, fx=0); horizontal pass on the two source rows
  * S[sx]*(1-fx) + S[sx+1]*fx, then vertical R0*(1-fy) + R1*fy, all fp32 */
+static void resize_linear_scaled(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double scale_x, double scale_y);
 void orc_resize_linear_cv(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride) {
-    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    /* explicit dsize: inv_scale = dsize / ssize, scale = 1 / inv_scale (imgproc resize.cpp) */
+    resize_linear_scaled(dst, dw, dh, dstride, src, sw, sh, sstride, (double)sw / dw, (double)sh / dh);
+}
+/* cv::resize(src, dst, Size(0,0), fx, fy, INTER_LINEAR) as the driver's input rescaling calls it (slow_flow.cpp:552): dsize =
+ * (cvRound(sw*fx), cvRound(sh*fy)) is the caller's business; the source coordinate uses scale = 1/fx, NOT ssize/dsize (they differ when
+ * sw*fx is not an integer).  OpenCV is not vendored: PARITY UNPINNED like the rest of the pyramid arithmetic. */
+void orc_resize_linear_fx(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double fx, double fy) {
+    resize_linear_scaled(dst, dw, dh, dstride, src, sw, sh, sstride, 1.0 / fx, 1.0 / fy);
+}
+static void resize_linear_scaled(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double scale_x, double scale_y) {
     int *xofs = (int *)malloc(sizeof(int) * dw);
     float *xa = (float *)malloc(sizeof(float) * dw);
     for (int dx = 0; dx < dw; dx++) {

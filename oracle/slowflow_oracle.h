@@ -141,6 +141,9 @@ void orc_sor_coupled_readable(float *du, float *dv, const float *a11, const floa
 void orc_normalize(float **frames, int F, int w, int h, int stride, double avg[3], double std[3]);
 void orc_normalize_publish(const double avg[3], const double std[3], float avg_f[3], float std_f[3]);
 
+/* variational_mt.cpp:293-320: occlusion / direction weighting of the 2*ref warp masks, in place */
+void orc_mask_weight(float *masks, const float *occ, int ref, float data_norm, int one_direction, int w, int h, int stride);
+
 /* variational_mt.cpp:169-493.  frames: 2*ref+1 colour images of this level; wx,wy in/out;
  * chw[3]: channel weight planes; occ: out occlusion plane (h*stride) or NULL; change[2] out */
 int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *const *frames,
@@ -149,6 +152,8 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
 /* OpenCV-defined pyramid arithmetic, restated from the documented semantics (UNPINNED) */
 void orc_gaussian_blur_cv(float *dst, const float *src, int w, int h, int stride, float sigma);
 void orc_resize_linear_cv(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride);
+/* cv::resize(src, dst, Size(0,0), fx, fy, INTER_LINEAR) (slow_flow.cpp:552): source coordinate (dst + .5) / f - .5 */
+void orc_resize_linear_fx(float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double fx, double fy);
 int  orc_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs);
 /* optional presmoothing of level 0 (cfg sigma > 0, variational_mt.cpp:590-597): gaussian_filter (image.c:310-348) applied with the
  * generic convolve_horiz / convolve_vert (image.c:537-644).  Pinned bit-exact against the compiled image.c. */

@@ -66,7 +66,7 @@ EXPORTS = [
     "sfa_variational", "sfa_variational_2frame", "sfa_params_2frame_default", "variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sor_coupled",
     "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
     "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_resize_linear_fx", "sfa_gaussian_presmooth", "sfa_pyramid_sizes",
-    "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_mpix_iters",
+    "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
     "sfa_profile_enable", "sfa_profile_read", "sfa_timer_start", "sfa_timer_stop",
 ]
@@ -321,6 +321,15 @@ class Job:
         stride = stride_of(self.w)
         occ = np.zeros((self.h, stride), np.float32)
         self.ctx._ck(lib().sfa_job_download_occlusions(self.h_, b, fptr(occ), stride), "sfa_job_download_occlusions")
+        return occ
+
+    def keep_alternation_occlusions(self, on=True):
+        self.ctx._ck(lib().sfa_job_keep_alternation_occlusions(self.h_, int(on)), "sfa_job_keep_alternation_occlusions")
+
+    def download_alternation_occlusions(self, b, alter):
+        stride = stride_of(self.w)
+        occ = np.zeros((self.h, stride), np.float32)
+        self.ctx._ck(lib().sfa_job_download_alternation_occlusions(self.h_, b, int(alter), fptr(occ), stride), "sfa_job_download_alternation_occlusions")
         return occ
 
     def mpix_iters(self):

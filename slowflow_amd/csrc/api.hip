@@ -151,7 +151,10 @@ static int optimize_occlusions(sfa_ctx *c, const Level &L, const sfa_params &p, 
     return run_grid_cut(c, g, L.plane(P_OCC), L.es, d0, d1, work, p.occlusion_alpha);
 }
 
-static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const ChannelWeights &cw, SorWorkspace &sorws, DevMem &cut_scratch, float *change) {
+// occ_log (level 0 only, or null): [nb][niter_alter][pl] floats, the labels after the discrete step of alternation a >= 1 -- what the
+// reference writes as <slow_flow_occlusions_output><a>.png at every level, the finest level's file surviving (:275-285)
+static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const ChannelWeights &cw, SorWorkspace &sorws, DevMem &cut_scratch, float *change,
+                     float *occ_log) {
     const int ref = L.ref;
     const float gamma_over3 = p.gamma / 3.0f, delta_over3 = p.delta / 3.0f;                                   // :548-549
     unsigned long long active = L.nb >= 64 ? ~0ull : ((1ull << L.nb) - 1);
@@ -218,19 +221,23 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
         g.active = active;
         get_derivatives(c, L, p, active, need_toref);                                                       // :266
         if (alter > 0 && p.occlusion_reasoning && !p.one_direction) SFA_TRY(optimize_occlusions(c, L, p, g, cut_scratch));   // :269-272
+        if (alter > 0 && p.occlusion_reasoning && occ_log)                                                  // :275-285
+            launch_copy_planes(c, g, occ_log + (long)alter * L.pl, L.plane(P_OCC), 1, (long)p.niter_alter * L.pl, L.es);
         for (int outer = 0; outer < p.niter_outer; outer++) {
             g.active = active;
             if (outer > 0) get_derivatives(c, L, p, active, need_toref);                                    // :289-290
             if (!L.fused) launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);   // :293-320
-            // in the direct form the first inner iteration never touches du / dv / old du / old dv: they are zeros by construction
-            const bool direct_outer = L.fused && active == all && !getenv("SFA_NO_DIRECT_OPERANDS");
+            // in the direct form the first inner iteration never touches du / dv / old du / old dv: they are zeros by construction.
+            // Windows that already met a threshold stay in the lockstep launches as passengers: every kernel but the solver skips them
+            // (Geo::active), the solver re-solves their stale operands into its own x plane, which nobody reads -- cheaper than leaving
+            // the batched path for single solves (one window costs 0.87 ms alone, a batch of 32 costs 1.5 ms).
+            const bool direct_outer = L.fused && !getenv("SFA_NO_DIRECT_OPERANDS");
             if (!direct_outer) launch_zero_planes(c, g, L.plane(P_DU), 2);                                   // :323-324 (du, dv adjacent)
-            unsigned long long in_active = active;
-            bool outer_done = false;
+            unsigned long long in_active = active, outer_done = 0;
             for (int inner = 0; inner < p.niter_inner; inner++) {
                 Geo gi = g;
                 gi.active = in_active;
-                const bool direct = direct_outer && in_active == all;
+                const bool direct = direct_outer;
                 const bool first_zero = direct && inner == 0;        // du = dv = 0 known, planes possibly stale
                 if (!first_zero) {
                     launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                // :329-330
@@ -268,7 +275,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 if (direct && inner + 1 == p.niter_inner) {
                     // last inner iteration: nothing reads its inner norms or du/dv; the flow update and the outer update run as one pass
                     launch_update_outer_x(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, red);   // :396-397 + :412-429
-                    outer_done = true;
+                    outer_done = in_active;
                 } else if (direct) {
                     const bool keep = inner + 1 < p.niter_inner;      // du, dv are read again only by a further inner iteration
                     launch_update_inner_x(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, first_zero ? nullptr : L.plane(P_ODU),
@@ -287,7 +294,13 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                     if (!in_active) break;
                 }
             }
-            if (!outer_done) launch_update_outer(c, g, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);      // :412-429
+            if (outer_done != active) {
+                // windows that left the inner loop early (or the unfused form): their outer update.  The reductions only write the result
+                // words of the windows of their Geo::active, so the norms of the windows updated above stay in `red`.
+                Geo go = g;
+                go.active = active & ~outer_done;
+                launch_update_outer(c, go, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);                      // :412-429
+            }
             const bool last_iter = (alter == p.niter_alter - 1 && outer == p.niter_outer - 1);
             if (use_thres_out || last_iter) {
                 SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -374,6 +387,9 @@ struct sfa_job {
     }
     int host_stride0 = 0;
     bool fused = true;                 // false: SFA_UNFUSED=1 at creation (stack planes materialised; cross-check only)
+    unsigned long long presmoothed = 0;   // windows whose level-0 frames already hold the presmoothed images (cfg sigma > 0): smoothing is applied once per upload
+    bool keep_alt_occ = false;         // record the occlusion labels of every alternation (slow_flow_occlusions_output, variational_mt.cpp:275-285)
+    DevMem occ_log;                    // [nb][niter_alter][pl(level 0)]
 };
 
 extern "C" {
@@ -916,6 +932,7 @@ int sfa_job_upload(sfa_job *j, int b, const float *const *frames, int n_frames, 
     SFA_HIP(ctx, hipSetDevice(ctx->device));
     Level L0 = j->level(0);
     j->host_stride0 = stride;
+    j->presmoothed &= ~(1ull << b);
     for (int f = 0; f < j->F; f++) {
         CHECK_ARGS(frames[f], "null frame");
         for (int k = 0; k < 3; k++)
@@ -941,6 +958,9 @@ int sfa_job_upload(sfa_job *j, int b, const float *const *frames, int n_frames, 
             CHECK_ARGS(chw[k], "null weight plane");
             SFA_TRY(upload_plane(ctx, j->chw.f() + ((long)b * 3 + k) * cp * j->h, cp, chw[k], stride, stride, j->h));
         }
+    } else if (j->has_chw) {
+        // a slot that held weighted channels before (jobs are reused for batch after batch) goes back to all ones
+        launch_fill(ctx, j->chw.f() + (long)b * 3 * dev_pitch(j->chw_stride0) * j->h, (size_t)3 * dev_pitch(j->chw_stride0) * j->h, 1.0f);
     }
     SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SFA_OK;
@@ -960,13 +980,15 @@ int sfa_job_run(sfa_job *j) {
     float taps[64];
     const int radius = cv_gauss_taps(sigma, taps);
     Level L0 = j->level(0);
-    if (p.presmooth_sigma > 0) {                                                      // :590-597
+    if (p.presmooth_sigma > 0 && (j->presmoothed & all) != all) {                     // :590-597
+        // the smoothed frames replace the uploaded ones, once per upload: a job may be run again (warm-up + timed runs, a second pass
+        // over the same windows) and must then start from the same images
         float *tmp = L0.base + L0.off_tmp;
         for (int f = 0; f < F; f++) {
-            Geo g = L0.geo(all);
-            launch_presmooth(ctx, g, tmp + 3 * L0.pl, tmp, L0.frame(f), 3, p.presmooth_sigma);
-            launch_copy_planes(ctx, g, L0.frame(f), tmp + 3 * L0.pl, 3, L0.es, L0.es);
+            launch_presmooth(ctx, L0.geo(all), tmp + 3 * L0.pl, tmp, L0.frame(f), 3, p.presmooth_sigma);
+            launch_copy_planes(ctx, L0.geo(all & ~j->presmoothed), L0.frame(f), tmp + 3 * L0.pl, 3, L0.es, L0.es);
         }
+        j->presmoothed = all;
     }
     for (int l = 1; l < L; l++) {
         Level Lp = j->level(l - 1), Lc = j->level(l);
@@ -1002,7 +1024,7 @@ int sfa_job_run(sfa_job *j) {
             launch_resize(ctx, Lc.plane(P_WX), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WX), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fx);   // :711,716
             launch_resize(ctx, Lc.plane(P_WY), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WY), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fy);
         }
-        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[l], j->cut_scratch, j->change.data()));                                           // :761
+        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[l], j->cut_scratch, j->change.data(), l == 0 && j->keep_alt_occ ? j->occ_log.f() : nullptr));   // :761
     }
     SFA_HIP(ctx, hipGetLastError());
     return SFA_OK;
@@ -1016,6 +1038,31 @@ int sfa_job_download(sfa_job *j, int b, float *wx, float *wy, int stride, float 
     SFA_TRY(download_plane(ctx, wx, stride, L0.plane(P_WX) + b * j->es, L0.pitch, j->w, j->h));
     SFA_TRY(download_plane(ctx, wy, stride, L0.plane(P_WY) + b * j->es, L0.pitch, j->w, j->h));
     if (change) { change[0] = j->change[2 * b]; change[1] = j->change[2 * b + 1]; }
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_job_keep_alternation_occlusions(sfa_job *j, int on) {
+    sfa_ctx *ctx = j ? j->ctx : nullptr;
+    CHECK_ARGS(j, "null job");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    j->keep_alt_occ = on != 0;
+    if (on) {
+        const size_t n = (size_t)j->nb * std::max(1, j->p.niter_alter) * dev_pitch(j->w) * j->h * sizeof(float);
+        SFA_TRY(j->occ_log.alloc(ctx, n));
+        SFA_HIP(ctx, hipMemsetAsync(j->occ_log.p, 0, n, ctx->stream));
+    }
+    return SFA_OK;
+}
+
+int sfa_job_download_alternation_occlusions(sfa_job *j, int b, int alter, float *occ, int stride) {
+    sfa_ctx *ctx = j ? j->ctx : nullptr;
+    CHECK_ARGS(j && b >= 0 && b < j->nb && occ && stride >= j->w, "bad arguments");
+    CHECK_ARGS(j->keep_alt_occ && j->occ_log.p, "sfa_job_keep_alternation_occlusions was not enabled before the run");
+    CHECK_ARGS(alter >= 1 && alter < j->p.niter_alter, "alternation out of range: labels exist for 1 <= alter < niter_alter (variational_mt.cpp:269)");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    const int pitch = dev_pitch(j->w);
+    const long pl = (long)pitch * j->h;
+    SFA_TRY(download_plane(ctx, occ, stride, j->occ_log.f() + ((long)b * j->p.niter_alter + alter) * pl, pitch, j->w, j->h));
     return sfa_ctx_sync(ctx);
 }
 

@@ -1203,8 +1203,9 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx,
     }
 }
 // one block per batch element sums that element's partials in a fixed order
-__global__ void k_reduce_partials(const double *__restrict__ partial, int per_elem, double *__restrict__ out) {
+__global__ void k_reduce_partials(const double *__restrict__ partial, int per_elem, double *__restrict__ out, unsigned long long active) {
     const int b = blockIdx.x;
+    if (!elem_active(active, b)) return;                              // the result words of passengers keep their last values
     double sa = 0, sb = 0;
     for (int i = threadIdx.x; i < per_elem; i += 256) { sa += partial[2 * ((size_t)b * per_elem + i)]; sb += partial[2 * ((size_t)b * per_elem + i) + 1]; }
     __shared__ double s0[256], s1[256];
@@ -1228,26 +1229,26 @@ void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const f
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_inner, grid, block2d(), 0, c->stream, uu, vv, wx, wy, du, dv, old_du, old_dv, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active);
 }
 void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const SorOperandOut &x, const float *old_du,
                            const float *old_dv, float *du_out, float *dv_out, double *red) {
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_inner_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, old_du, old_dv, du_out, dv_out, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active);
 }
 void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red) {
     dim3 grid((g.w + 63) / 64, std::min((g.h + 15) / 16, kRedRows), g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_outer_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active);
 }
 void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red) {
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_outer, grid, block2d(), 0, c->stream, wx, wy, uu, vv, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active);
 }
 
 __global__ void k_copy_planes(float *__restrict__ dst, const float *__restrict__ src, Geo g, int nplanes, long dst_es, long src_es) {
@@ -1594,7 +1595,7 @@ __global__ void __launch_bounds__(BX *BY) k_norm_sums(const float *__restrict__ 
 void launch_normalize_sums(sfa_ctx *c, const Geo &g, const float *frames3, double *red) {
     dim3 grid = red_grid(g, 3);
     hipLaunchKernelGGL(k_norm_sums, grid, block2d(), 0, c->stream, frames3, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, c->stream, partials_of(c), (int)(grid.x * grid.y), red);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, c->stream, partials_of(c), (int)(grid.x * grid.y), red, 7ull);
 }
 __global__ void k_norm_apply(float *__restrict__ frames3, Geo g, double a0, double a1, double a2, double s0, double s1, double s2) {
     const int ch = blockIdx.z;
