@@ -244,6 +244,17 @@ class Oracle:
         self.lib.orc_resize_linear_fx(fptr(dst), dw, dh, stride_of(dw), fptr(src), sw, sh, sstride, C.c_double(fx), C.c_double(fy))
         return dst, dw
 
+    def force_labels(self, labels):
+        """labels: (n_alter, h, stride) array kept alive by the caller, or None to switch the hook off (orc_force_labels)"""
+        if labels is None:
+            self.lib.orc_force_labels(None, 0)
+        else:
+            self.lib.orc_force_labels(fptr(labels), int(labels.shape[0]))
+
+    def forced_gap(self, alter):
+        self.lib.orc_forced_gap.restype = C.c_double
+        return self.lib.orc_forced_gap(int(alter))
+
     def mask_weight(self, masks, occ, ref, data_norm, one_direction, w):
         """masks (2ref,h,stride) weighted in place (variational_mt.cpp:293-320)"""
         _, h, stride = masks.shape

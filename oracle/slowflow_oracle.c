@@ -854,6 +854,19 @@ double orc_grid_cut(float *occ, const float *d0, const float *d1, float alpha, i
 /* ------------------------------------------------------------------------------------------
  * variational_mt.cpp:169-493 -- one pyramid level
  * ---------------------------------------------------------------------------------------- */
+/* Test hook for the discrete step: a minimum cut is not unique, so two exact solvers may return different labellings of equal energy and
+ * the flows computed under them differ.  orc_force_labels hands orc_compute_one_level the labels to use after the discrete step of
+ * alternation a = 1 .. n-1 (labels + a*h*stride; entry 0 unused); each alternation records the relative energy excess of the forced
+ * labelling over this run's own exact minimum in gap[a].  NULL switches the hook off.  Single level, single thread. */
+static const float *g_forced_labels = NULL;
+static int g_forced_n = 0;
+static double g_forced_gap[64];
+void orc_force_labels(const float *labels, int n) {
+    g_forced_labels = labels; g_forced_n = n < 64 ? n : 64;
+    for (int i = 0; i < 64; i++) g_forced_gap[i] = 0;
+}
+double orc_forced_gap(int alter) { return alter >= 0 && alter < 64 ? g_forced_gap[alter] : 0; }
+
 /* variational_mt.cpp:293-320: the occlusion / direction weighting of the warp masks, in place.
  * masks: 2*ref planes; occ: -1 / 0 / +1 per pixel; data_norm = sum_a (rho[a] + omega[a]) (:223-226) */
 void orc_mask_weight(float *masks, const float *occ, int ref, float data_norm, int one_direction, int w, int h, int stride) {
@@ -929,7 +942,14 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
                     float *d0 = plane_alloc(plane), *d1 = plane_alloc(plane);
                     orc_occlusion_costs(d0, d1, mask, succ, toref, ref, p->rho, p->omega, delta_over3, gamma_over3, p->occlusion_penalty,
                                         &p->robust_color, &p->robust_grad, w, h, stride);
-                    orc_grid_cut(occ, d0, d1, p->occlusion_alpha, w, h, stride);
+                    const double e_min = orc_grid_cut(occ, d0, d1, p->occlusion_alpha, w, h, stride);
+                    if (g_forced_labels && alter < g_forced_n) {
+                        /* test hook (orc_force_labels): the labelling comes from outside; how far it is from this run's own optimum
+                         * is recorded, and the continuous optimisation goes on under it */
+                        const float *fl = g_forced_labels + (size_t)alter * plane;
+                        g_forced_gap[alter] = (orc_grid_cut_energy(fl, d0, d1, p->occlusion_alpha, w, h, stride) - e_min) / (fabs(e_min) > 1 ? fabs(e_min) : 1);
+                        memcpy(occ, fl, plane * sizeof(float));
+                    }
                     free(d0); free(d1);
                     occ_pending = 0;
                 }

@@ -141,6 +141,11 @@ void orc_sor_coupled_readable(float *du, float *dv, const float *a11, const floa
 void orc_normalize(float **frames, int F, int w, int h, int stride, double avg[3], double std[3]);
 void orc_normalize_publish(const double avg[3], const double std[3], float avg_f[3], float std_f[3]);
 
+/* test hook: labels to use after the discrete step of alternation a (labels + a*h*stride), and the recorded relative energy excess of each
+ * over the run's own exact minimum -- a minimum cut is not unique, so parity of the flow is checked under the SAME labelling */
+void orc_force_labels(const float *labels, int n);
+double orc_forced_gap(int alter);
+
 /* variational_mt.cpp:293-320: occlusion / direction weighting of the 2*ref warp masks, in place */
 void orc_mask_weight(float *masks, const float *occ, int ref, float data_norm, int one_direction, int w, int h, int stride);
 

@@ -1,21 +1,28 @@
 // slow_flow.cpp -- the slow_flow driver of the drop-in: same cfg keys, command line and outputs as the reference's
-// slow_flow.cpp (usage :58-62, defaults :64-128, frame indexing :411-465, jet loop :706-1047, .flo outputs :908-911,
-// :1027-1030, resume :794,958, config.cfg :684-688) for the path this repository implements:
+// slow_flow.cpp (usage :58-62, defaults :64-128, adaptive frame rates :277-357, frame indexing :411-465, jet loop :706-1047,
+// .flo outputs :908-911, :1027-1030, resume :794,958, config.cfg :684-688) for the path this repository implements:
 //   frames -> normalize -> per jet: forward / backward Variational_MT::variational -> flow * steps -> .flo
-// The jets of a sequence are independent; they are sharded over the node's GPUs (one host thread per GPU) and each
-// GPU refines `gpu_batch` frame windows in lockstep.  Out of scope here (and rejected with a message): the third-party
-// demosaicers (raw_demosaicing 1, 2), DeepMatching/EpicFlow initialisation, adaptive frame rates -- they
-// live in third-party code (OpenCV, MATLAB SED, DeepMatching) outside the path.
+// The jets of a sequence are independent; they are sharded over the node's GPUs (shard.h: `gpu_streams` host threads per
+// GPU, each with its own context = HIP stream) and each worker refines `gpu_batch` frame windows in lockstep.  The driver is
+// a pipeline: frames are decoded by a pool of host threads, every worker keeps ONE resident job for all its batches
+// (upload / run / download), and results go to the output pool (.flo, colour PNG, occlusion images) while the worker
+// already refines its next batch; with two workers per GPU the uploads of one overlap the kernels of the other.
+// Out of scope here (and rejected with a message): the third-party demosaicers (raw_demosaicing 1, 2) and the
+// DeepMatching/EpicFlow initialisation -- third-party code (OpenCV, MATLAB SED, DeepMatching) outside the path.
 //
-// New, additive keys: gpus (default: all visible), gpu_batch (windows refined in lockstep per job, default 32), gpu_streams (default 2), gpu_device (first device, default 0).
+// New, additive keys: gpus (default: all visible), gpu_batch (windows refined in lockstep per job, default 32), gpu_streams
+// (default 2), gpu_device (first device, default 0), io_threads (decode / output pool, default min(16, cores)),
+// adaptive_fr_file (default: adaptiveFR.dat next to the executable, the reference's SOURCE_PATH).
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -26,6 +33,7 @@
 #include "ingest.h"
 #include "io.h"
 #include "parameter_list.h"
+#include "shard.h"
 #include "variational_mt.h"
 
 using std::string;
@@ -62,123 +70,140 @@ static void mkdirs(const string &path) {
 }
 static string fmt1(const string &format, int a) { char b[1024]; snprintf(b, sizeof b, format.c_str(), a); return b; }
 static string fmt2(const string &format, int a, int c) { char b[1024]; snprintf(b, sizeof b, format.c_str(), a, c); return b; }
+static string exe_dir() {
+    char buf[4096];
+    const ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1);
+    if (n <= 0) return ".";
+    buf[n] = 0;
+    string s(buf);
+    return s.substr(0, s.find_last_of('/'));
+}
 
 struct Window {
     unsigned jet; bool backward; string out; double seconds; int gpu; double epe, aae;   // epe/aae < 0: no ground truth
     Window(unsigned j, bool b, const string &o) : jet(j), backward(b), out(o), seconds(0), gpu(-1), epe(-1), aae(-1) {}
 };
 
-int main(int argc, char **argv) {
-    if (argc < 2) { usage(); return 1; }
-    ParameterList params;
-    setDefault(params);
-    if (argv[1][0] != '-' && file_exists(argv[1])) params.read(argv[1]);
-    else { std::cerr << "Couldn't find " << argv[1] << "!" << std::endl; return -1; }
+// the labels of optimizeOcc as an 8-bit image, (occ + 1) / 2 * 255 (variational_mt.cpp:277-279, slow_flow.cpp:895-896)
+static png_image occlusion_image(const image_t *occ) {
+    png_image im;
+    im.width = occ->width; im.height = occ->height; im.channels = 1; im.depth = 8;
+    im.samples.resize((size_t)occ->width * occ->height);
+    for (int y = 0; y < occ->height; y++)
+        for (int x = 0; x < occ->width; x++) {
+            const float v = (occ->data[(size_t)y * occ->stride + x] + 1) * 0.5f * 255.0f;
+            im.samples[(size_t)y * occ->width + x] = (uint16_t)std::max(0.0f, std::min(255.0f, std::nearbyint(v)));
+        }
+    return im;
+}
 
-    bool overwrite_output = false, resume_frame = false;
+struct RunOptions {
+    bool resume_frame = false;
     int selected_jet = -1;
-    for (int i = 1; i < argc; i++) {                                                 // slow_flow.cpp:168-193
-        const char *a = argv[i];
-        if (a[0] != '-') continue;
-        if (!strcmp(a, "-h") || !strcmp(a, "-help")) usage();
-        else if (!strcmp(a, "-overwrite")) overwrite_output = true;
-        else if (!strcmp(a, "-resume")) resume_frame = true;
-        else if (!strcmp(a, "-deep_settings") && i + 1 < argc) i++;
-        else if (!strcmp(a, "-threads") && i + 1 < argc) params.insert("threads", argv[++i], true);
-        else if (!strcmp(a, "-fr") && i + 1 < argc) i++;
-        else if (!strcmp(a, "-jet") && i + 1 < argc) { selected_jet = atoi(argv[++i]); resume_frame = true; }
-        else { fprintf(stderr, "unknown argument %s", a); usage(); }
+};
+
+// everything a finished window hands to the output pool
+struct WindowResult {
+    size_t index = 0;                            // into todo
+    image_t *wx = nullptr, *wy = nullptr, *occ = nullptr;
+    std::vector<image_t *> alt_occ;              // labels after alternation 1 .. niter_alter-1 (WRITE_FILES verbosity)
+    ~WindowResult() {
+        if (wx) image_delete(wx);
+        if (wy) image_delete(wy);
+        if (occ) image_delete(occ);
+        for (auto *o : alt_occ) image_delete(o);
     }
-    if (params.parameter<bool>("deep_matching")) { std::cerr << "deep_matching=1 needs the external DeepMatching/SED/EpicFlow stage: not part of this build (set deep_matching 0)" << std::endl; return 2; }
+};
+
+// One pass over the sequence at one frame rate: the body of the reference's adFR loop (slow_flow.cpp:367-1060).
+static int run_sequence(ParameterList &params, const string &sequence_path, const string &format, int skip, const RunOptions &opt) {
+    const auto t_begin = std::chrono::steady_clock::now();
     const bool raw = params.exists("raw") && params.parameter<bool>("raw");
-    if (raw && params.parameter<int>("raw_demosaicing", "0") != 0) {
-        std::cerr << "raw_demosaicing 1 (Hamilton-Adams, P. Getreuer) and 2 (OpenCV) are third-party code absent from the reference tree: use raw_demosaicing 0 "
-                     "(the reference's own bilinear / green-ratio routine) or provide demosaiced frames with raw 0" << std::endl;
-        return 2;
-    }
     const std::vector<int> red_loc = params.splitParameter<int>("raw_red_loc", "0,0");   // :439
     const float scale = params.parameter<float>("scale", "1.0");
-
     const int steps = params.parameter<int>("slow_flow_S") - 1, ref = steps;         // :208-209
-    const int max_fps = params.parameter<int>("max_fps", "1");
-    const int jet_fps = params.exists("jet_fps") ? params.parameter<int>("jet_fps") : max_fps;
-    const int skip = (int)((1.0f * max_fps) / jet_fps);                              // :220
-    const bool sintel = params.parameter<bool>("sintel", "0"), subframes = params.parameter<bool>("subframes", "0");
-    unsigned start = params.sequence_start;
-    const size_t cut = params.file.find_last_of('/') + 1;
-    string sequence_path = params.file.substr(0, cut), format = params.file.substr(cut);
-    if (sequence_path.empty() || params.output.empty()) { std::cerr << "cfg needs 'file' and 'output'" << std::endl; return -1; }
+    const bool sintel = params.parameter<bool>("sintel", "0");
+    const unsigned start = params.sequence_start;
     const string format_flow = format.substr(0, format.find_last_of('.'));
-    if (sintel && !subframes) start *= 1000;
-    params.sequence_start = start;
+    const int io_threads = std::max(1, std::min(64, params.parameter<int>("io_threads", std::to_string(std::max(1u, std::min(16u, std::thread::hardware_concurrency()))))));
 
-    if (!resume_frame && !overwrite_output) {                                        // never overwrite a results folder (:254-265)
-        string np = params.output;
-        if (np.back() == '/') np.pop_back();
-        const string base = np;
-        int num = 1;
-        while (file_exists(np)) { std::cerr << np << " already exists!" << std::endl; np = base + "_" + std::to_string(num++); }
-        params.output = np;
-    }
-    if (params.output.back() != '/') params.output += "/";
     mkdirs(params.output);
 
     const int frames = 1 + (params.Jets + 2) * steps;                                // :411
     unsigned start_f = 0, end_f = frames, start_j = 0, end_j = params.Jets;
-    if (resume_frame && selected_jet >= 0) {                                         // :418-424
-        start_f = selected_jet * steps;
-        end_f = std::min(frames, 1 + (selected_jet + 3) * steps);
-        start_j = selected_jet;
-        end_j = std::min((int)params.Jets, selected_jet + 1);
+    if (opt.resume_frame && opt.selected_jet >= 0) {                                 // :418-424
+        start_f = opt.selected_jet * steps;
+        end_f = std::min(frames, 1 + (opt.selected_jet + 3) * steps);
+        start_j = opt.selected_jet;
+        end_j = std::min((int)params.Jets, opt.selected_jet + 1);
     }
     if (start_f > end_f) return 0;
 
-    // ---- read the image sequence (:447-592, without OpenCV: PNG, binary PPM / PGM / PFM) ------------------------------
+    // ---- read the image sequence (:447-592, without OpenCV: PNG, binary PPM / PGM / PFM): decoded, demosaiced and cropped by the
+    //      io pool, one frame per task ----------------------------------------------------------------------------------------------
     std::vector<color_image_t *> seq(frames, nullptr), seq_back(frames, nullptr);
-    sfa_ctx *ingest_ctx = nullptr;
+    std::vector<string> names(frames);
     for (unsigned f = start_f; f < end_f; f++) {
-        string img_file;
-        if (!sintel) img_file = fmt1(sequence_path + format, (int)start - ref * skip + (int)f * skip);
+        if (!sintel) names[f] = fmt1(sequence_path + format, (int)start - ref * skip + (int)f * skip);
         else {
             int sintel_frame = start / 1000, hfr = (int)f * skip - ref * skip + (int)(start % 1000);
             while (hfr < 0) { sintel_frame--; hfr += 42; }
             while (hfr > 41) { sintel_frame++; hfr -= 42; }
-            img_file = fmt2(sequence_path + format, sintel_frame, hfr);
+            names[f] = fmt2(sequence_path + format, sintel_frame, hfr);
         }
-        std::cout << "Reading " << img_file << "..." << std::endl;
-        int maxval = 255;
-        seq[f] = color_image_load(img_file.c_str(), &maxval);
-        if (!seq[f]) { std::cerr << "cannot read frame " << img_file << " (PNG or binary PPM/PGM/PFM expected)" << std::endl; return 3; }
-        if (raw) {                                                                   // demosaicing (:482-527): the mosaic is the grey image
-            image_t mosaic = {seq[f]->width, seq[f]->height, seq[f]->stride, seq[f]->c1};
-            color_image_t *rgb = color_image_new(seq[f]->width, seq[f]->height);
-            color_image_erase(rgb);
-            bayer2rgbGR(&mosaic, rgb, red_loc.size() > 0 ? red_loc[0] : 0, red_loc.size() > 1 ? red_loc[1] : 0);
-            color_image_delete(seq[f]);
-            seq[f] = rgb;
-        }
-        if (!params.exists("raw") || params.parameter<float>("raw_weight", "1.0") == 1.0f) {   // :531
-            if (params.extent.x > 0 || params.extent.y > 0) {                        // use only a part of the images (:533-536)
-                color_image_t *part = color_image_crop(seq[f], params.center.x, params.center.y, params.extent.x, params.extent.y);
-                if (!part) { std::cerr << "center / extent do not fit the " << seq[f]->width << "x" << seq[f]->height << " frames" << std::endl; return 3; }
-                color_image_delete(seq[f]);
-                seq[f] = part;
-            }
-            if (scale != 1) {                                                        // blur + resize against aliasing (:550-553), on the GPU
-                if (!ingest_ctx && sfa_ctx_create(params.parameter<int>("gpu_device", "0"), &ingest_ctx) != SFA_OK) { std::cerr << sfa_last_error(nullptr) << std::endl; return 4; }
-                color_image_t *small = color_image_rescale(ingest_ctx, seq[f], scale);
-                if (!small) { std::cerr << "rescaling failed: " << sfa_last_error(ingest_ctx) << std::endl; return 4; }
-                color_image_delete(seq[f]);
-                seq[f] = small;
-            }
-        }
-        seq_back[frames - 1 - f] = seq[f];                                           // :590-591
+        std::cout << "Reading " << names[f] << "..." << std::endl;
     }
+    const bool preprocess = !params.exists("raw") || params.parameter<float>("raw_weight", "1.0") == 1.0f;   // :531
+    const Point center = params.center, extent = params.extent;
+    std::mutex err_mu;
+    string load_error;
+    {
+        TaskPool pool(io_threads);
+        for (unsigned f = start_f; f < end_f; f++)
+            pool.submit([&, f] {
+                int maxval = 255;
+                color_image_t *img = color_image_load(names[f].c_str(), &maxval);
+                if (!img) { std::lock_guard<std::mutex> l(err_mu); if (load_error.empty()) load_error = "cannot read frame " + names[f] + " (PNG or binary PPM/PGM/PFM expected)"; return; }
+                if (raw) {                                                           // demosaicing (:482-527): the mosaic is the grey image
+                    image_t mosaic = {img->width, img->height, img->stride, img->c1};
+                    color_image_t *rgb = color_image_new(img->width, img->height);
+                    color_image_erase(rgb);
+                    bayer2rgbGR(&mosaic, rgb, red_loc.size() > 0 ? red_loc[0] : 0, red_loc.size() > 1 ? red_loc[1] : 0);
+                    color_image_delete(img);
+                    img = rgb;
+                }
+                if (preprocess && (extent.x > 0 || extent.y > 0)) {                  // use only a part of the images (:533-536)
+                    color_image_t *part = color_image_crop(img, center.x, center.y, extent.x, extent.y);
+                    if (!part) {
+                        std::lock_guard<std::mutex> l(err_mu);
+                        if (load_error.empty()) load_error = "center / extent do not fit the " + std::to_string(img->width) + "x" + std::to_string(img->height) + " frames";
+                        color_image_delete(img);
+                        return;
+                    }
+                    color_image_delete(img);
+                    img = part;
+                }
+                seq[f] = img;
+            });
+        pool.wait_all();
+    }
+    if (!load_error.empty()) { std::cerr << load_error << std::endl; return 3; }
+    if (preprocess && scale != 1) {                                                  // blur + resize against aliasing (:550-553), on the GPU
+        sfa_ctx *ingest_ctx = nullptr;
+        if (sfa_ctx_create(params.parameter<int>("gpu_device", "0"), &ingest_ctx) != SFA_OK) { std::cerr << sfa_last_error(nullptr) << std::endl; return 4; }
+        for (unsigned f = start_f; f < end_f; f++) {
+            color_image_t *small = color_image_rescale(ingest_ctx, seq[f], scale);
+            if (!small) { std::cerr << "rescaling failed: " << sfa_last_error(ingest_ctx) << std::endl; sfa_ctx_destroy(ingest_ctx); return 4; }
+            color_image_delete(seq[f]);
+            seq[f] = small;
+        }
+        sfa_ctx_destroy(ingest_ctx);
+    }
+    for (unsigned f = start_f; f < end_f; f++) seq_back[frames - 1 - f] = seq[f];    // :590-591
     const int width = seq[start_f]->width, height = seq[start_f]->height;
     color_image_t *channel_weights = color_image_new(width, height);                 // :597-598 (all ones without raw weighting)
     for (size_t i = 0; i < (size_t)3 * channel_weights->stride * height; i++) channel_weights->c1[i] = 1.0f;
     if (raw) rawWeighting(channel_weights, red_loc.size() > 0 ? red_loc[0] : 0, red_loc.size() > 1 ? red_loc[1] : 0, params.parameter<float>("raw_weight", "1.0"));   // :599-600
-    if (ingest_ctx) { sfa_ctx_destroy(ingest_ctx); ingest_ctx = nullptr; }
 
     // ---- ground truth, if the cfg names it (:603-661): .flo -> crop -> nearest resize * scale -> gt/flow_%05i.{png,flo} --------
     std::vector<image_t **> gt(params.Jets, nullptr);
@@ -226,6 +251,7 @@ int main(int argc, char **argv) {
         std::ofstream infos((params.output + "config.cfg").c_str());                 // :684-688
         infos << "# SlowFlow variational estimation\n" << params;
     }
+    const double ingest_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 
     // ---- the windows to refine: forward and backward of every jet (:706-1047) --------------------------------------
     std::vector<Window> todo;
@@ -234,9 +260,9 @@ int main(int argc, char **argv) {
         const string fwd = sintel ? fmt2(params.output + format_flow + ".flo", start + f * skip, 0) : fmt1(params.output + format_flow + ".flo", start + f * skip);
         const string bwd = sintel ? fmt2(params.output + format_flow + "_back.flo", start + f * skip + steps * skip, 0)
                                   : fmt1(params.output + format_flow + "_back.flo", start + f * skip + steps * skip);
-        if (!resume_frame || !file_exists(fwd)) todo.push_back(Window(j, false, fwd));
+        if (!opt.resume_frame || !file_exists(fwd)) todo.push_back(Window(j, false, fwd));
         else std::cout << "Forward flow from frame " << start + f << " to " << start + f * skip + steps * skip << " already exist!" << std::endl;
-        if (!resume_frame || !file_exists(bwd)) todo.push_back(Window(j, true, bwd));
+        if (!opt.resume_frame || !file_exists(bwd)) todo.push_back(Window(j, true, bwd));
         else std::cout << "Backward flow from frame " << start + f * skip << " to " << start + f * skip + steps * skip << " already exist!" << std::endl;
     }
 
@@ -247,36 +273,78 @@ int main(int argc, char **argv) {
     const int batch = std::max(1, std::min(64, params.parameter<int>("gpu_batch", "32")));
     const int F = 2 * ref + 1;
     const bool backward_forward_only = params.exists("method") && params.parameter("method") == "forward";   // :1019-1020
+    const bool occ_on = params.parameter<bool>("slow_flow_occlusion_reasoning", "0");
+    const bool out_occ = params.parameter<bool>("slow_flow_output_occlusions", "0");                          // :892
+    // the per-alternation labels (:878-884: <output>tmp/frame_<n>_<alter>.png), with WRITE_FILES verbosity only
+    const bool out_alt_occ = out_occ && occ_on && params.verbosity(WRITE_FILES) && params.parameter<int>("slow_flow_niter_alter", "1") > 1;
+    if (out_occ) mkdirs(params.output + "occlusion/");                               // :676-677
+    if (out_alt_occ) mkdirs(params.output + "tmp/");
 
     std::mutex io_mu;
-    bool failed = false;
+    std::atomic<bool> failed(false);
     // `gpu_streams` workers per GPU (default 2), each with its own context = HIP stream: two lockstep groups fill each other's
     // ramp-up / drain phases (the reference runs its windows from `threads` OpenMP threads the same way, slow_flow.cpp:706)
     const int streams = std::max(1, std::min(4, params.parameter<int>("gpu_streams", "2")));
-    const int nworkers = ngpu * streams;
-    auto worker = [&](int wk) {
-        const int g = wk / streams;
-        // contiguous block of windows per worker: neighbouring jets share frames
-        const size_t lo = todo.size() * wk / nworkers, hi = todo.size() * (wk + 1) / nworkers;
-        if (lo >= hi) return;
+    const std::vector<WorkerPlan> plan = plan_workers(todo.size(), ngpu, streams);
+    TaskPool out_pool(io_threads);
+
+    // what happens to a finished window off the GPU worker's thread: flow * steps -> .flo, colour PNG, EPE / AAE, occlusion images
+    auto emit = [&](std::shared_ptr<WindowResult> r) {
+        Window &wd = todo[r->index];
+        image_mul_scalar(r->wx, (float)steps);                                       // :908-909
+        image_mul_scalar(r->wy, (float)steps);
+        bool ok = writeFlowFile(wd.out.c_str(), r->wx, r->wy) == 0;
+        const int fnum = (int)start + (int)wd.jet * steps * skip;
+        if (ok && !wd.backward) {                                                    // the flow as a colour image next to the .flo (:913-925)
+            ok = png_write((params.output + "frame_" + std::to_string(fnum) + ".png").c_str(), flowColorImg(r->wx, r->wy, 0));
+            image_t **g = gt[wd.jet];
+            if (g && g[0]->width == width && g[0]->height == height) {               // additive: error against the ground truth, reported in timings.json
+                wd.epe = computeEPE(r->wx, r->wy, g[0], g[1]);
+                wd.aae = computeAAE(r->wx, r->wy, g[0], g[1]);
+            }
+        }
+        // the occlusion estimate of the forward window (:892-905; the reference writes a binary PXM named .pbm through OpenCV, here the
+        // same 8-bit grey map as PGM) and, with WRITE_FILES verbosity, the labels after every alternation (:878-884 -> variational_mt.cpp:275-285)
+        if (ok && r->occ) ok = writePGM((params.output + "occlusion/frame_" + std::to_string(fnum) + ".pgm").c_str(), r->occ, 1.0f, 127.5f) == 0;
+        for (size_t a = 0; ok && a < r->alt_occ.size(); a++)
+            ok = png_write((params.output + "tmp/frame_" + std::to_string(fnum) + "_" + std::to_string(a + 1) + ".png").c_str(), occlusion_image(r->alt_occ[a]));
+        if (!ok) {
+            std::lock_guard<std::mutex> l(io_mu);
+            std::cerr << "cannot write the results of " << wd.out << std::endl;
+            failed = true;
+        }
+    };
+
+    auto worker = [&](const WorkerPlan &wp) {
+        if (wp.lo >= wp.hi) return;
+        const int device = dev0 + wp.gpu;
         sfa_ctx *ctx = nullptr;
-        if (sfa_ctx_create(dev0 + g, &ctx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; return; }
+        if (sfa_ctx_create(device, &ctx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; return; }
         ParameterList tp(params);                                                    // one copy per thread (:708)
-        for (size_t b0 = lo; b0 < hi && !failed; b0 += batch) {
-            const size_t nb = std::min((size_t)batch, hi - b0);
-            // forward and backward windows share one lockstep job (the channel weights are per window) unless the backward solver runs with
-            // different parameters ("method forward", :1019-1020): then one job per direction
-            for (int dirpass = 0; dirpass < (backward_forward_only ? 2 : 1); dirpass++) {
-                std::vector<size_t> idx;
-                for (size_t i = 0; i < nb; i++)
-                    if (!backward_forward_only || (int)todo[b0 + i].backward == dirpass) idx.push_back(b0 + i);
-                if (idx.empty()) continue;
-                sfa_params sp = sfa_params_from_cfg(tp, dirpass == 1 ? backward_forward_only : false);
-                sfa_job *job = nullptr;
+        // forward and backward windows share one lockstep job (the channel weights are per window) unless the backward solver runs with
+        // different parameters ("method forward", :1019-1020): then one pass per direction
+        for (int dirpass = 0; dirpass < (backward_forward_only ? 2 : 1) && !failed; dirpass++) {
+            std::vector<size_t> mine;
+            for (size_t i = wp.lo; i < wp.hi; i++)
+                if (!backward_forward_only || (int)todo[i].backward == dirpass) mine.push_back(i);
+            if (mine.empty()) continue;
+            sfa_params sp = sfa_params_from_cfg(tp, dirpass == 1 ? backward_forward_only : false);
+            // one resident job for every full batch of this worker; a shorter last batch gets its own
+            sfa_job *job = nullptr;
+            int job_nb = 0;
+            int rc = SFA_OK;
+            for (size_t b0 = 0; b0 < mine.size() && rc == SFA_OK && !failed; b0 += batch) {
+                const int nb = (int)std::min((size_t)batch, mine.size() - b0);
                 const auto t0 = std::chrono::steady_clock::now();
-                int rc = sfa_job_create(ctx, &sp, width, height, (int)idx.size(), &job);
-                for (size_t e = 0; e < idx.size() && rc == SFA_OK; e++) {
-                    const Window &wd = todo[idx[e]];
+                if (!job || job_nb != nb) {
+                    if (job) sfa_job_destroy(job);
+                    job = nullptr;
+                    rc = sfa_job_create(ctx, &sp, width, height, nb, &job);
+                    job_nb = nb;
+                    if (rc == SFA_OK && out_alt_occ) rc = sfa_job_keep_alternation_occlusions(job, 1);
+                }
+                for (int e = 0; e < nb && rc == SFA_OK; e++) {
+                    const Window &wd = todo[mine[b0 + e]];
                     const int f = wd.jet * steps;
                     color_image_t *const *im = wd.backward ? &seq_back[frames - 1 - f - 3 * steps] : &seq[f];   // :721-724
                     std::vector<const float *> fr(F);
@@ -284,64 +352,60 @@ int main(int argc, char **argv) {
                     const float *chw[3] = {channel_weights->c1, channel_weights->c2, channel_weights->c3};
                     // only the forward solver gets the channel weights (:876 vs :1018); without raw weighting they are all ones (:597-598), which is
                     // what a NULL pointer means to the library (x * 1.0f is exact: same bits, three planes less to read per pixel)
-                    rc = sfa_job_upload(job, (int)e, fr.data(), F, nullptr, nullptr, im[0]->stride, (wd.backward || !raw) ? nullptr : chw);
+                    rc = sfa_job_upload(job, e, fr.data(), F, nullptr, nullptr, im[0]->stride, (wd.backward || !raw) ? nullptr : chw);
                 }
                 if (rc == SFA_OK) rc = sfa_job_run(job);
-                for (size_t e = 0; e < idx.size() && rc == SFA_OK; e++) {
-                    Window &wd = todo[idx[e]];
-                    image_t *wx = image_new(width, height), *wy = image_new(width, height);
-                    image_erase(wx); image_erase(wy);
+                std::vector<std::shared_ptr<WindowResult>> results;
+                for (int e = 0; e < nb && rc == SFA_OK; e++) {
+                    const Window &wd = todo[mine[b0 + e]];
+                    std::shared_ptr<WindowResult> r(new WindowResult());
+                    r->index = mine[b0 + e];
+                    r->wx = image_new(width, height); r->wy = image_new(width, height);
+                    image_erase(r->wx); image_erase(r->wy);
                     float change[2];
-                    rc = sfa_job_download(job, (int)e, wx->data, wy->data, wx->stride, change);
-                    if (rc == SFA_OK) {
-                        image_mul_scalar(wx, (float)steps);                          // :908-909
-                        image_mul_scalar(wy, (float)steps);
-                        if (writeFlowFile(wd.out.c_str(), wx, wy) != 0) rc = SFA_ERR_ARG;
+                    rc = sfa_job_download(job, e, r->wx->data, r->wy->data, r->wx->stride, change);
+                    if (rc == SFA_OK && out_occ && !wd.backward) {                   // getOcclusions() of the forward solver (:893)
+                        r->occ = image_new(width, height);
+                        image_erase(r->occ);
+                        rc = sfa_job_download_occlusions(job, e, r->occ->data, r->occ->stride);
                     }
-                    if (rc == SFA_OK && !wd.backward) {                              // the flow as a colour image next to the .flo (:913-925)
-                        const int fnum = (int)start + (int)wd.jet * steps * skip;
-                        png_write((params.output + "frame_" + std::to_string(fnum) + ".png").c_str(), flowColorImg(wx, wy, 0));
-                        image_t **g = gt[wd.jet];
-                        if (g && g[0]->width == width && g[0]->height == height) {   // additive: error against the ground truth, reported in timings.json
-                            wd.epe = computeEPE(wx, wy, g[0], g[1]);
-                            wd.aae = computeAAE(wx, wy, g[0], g[1]);
-                        }
+                    for (int a = 1; a < sp.niter_alter && rc == SFA_OK && out_alt_occ && !wd.backward; a++) {
+                        image_t *o = image_new(width, height);
+                        image_erase(o);
+                        r->alt_occ.push_back(o);
+                        rc = sfa_job_download_alternation_occlusions(job, e, a, o->data, o->stride);
                     }
-                    if (rc == SFA_OK && sp.occlusion_reasoning && !wd.backward && tp.parameter<bool>("slow_flow_output_occlusions", "0")) {
-                        // the final occlusion labels of the forward window as an image, (occ + 1) / 2 * 255 like :276-279 (there: one PNG per
-                        // alternation; here the last one, as PGM)
-                        image_t *occ = image_new(width, height);
-                        rc = sfa_job_download_occlusions(job, (int)e, occ->data, occ->stride);
-                        if (rc == SFA_OK) {
-                            mkdirs(params.output + "occlusion/");                    // :676-677
-                            const string of = params.output + "occlusion/" + wd.out.substr(wd.out.find_last_of('/') + 1, wd.out.find_last_of('.') - wd.out.find_last_of('/') - 1) + "_occ.pgm";
-                            writePGM(of.c_str(), occ, 1.0f, 127.5f);
-                        }
-                        image_delete(occ);
-                    }
-                    image_delete(wx); image_delete(wy);
-                    wd.gpu = dev0 + g;
+                    results.push_back(r);
                 }
                 const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                for (size_t e = 0; e < idx.size(); e++) todo[idx[e]].seconds = secs / idx.size();
-                if (job) sfa_job_destroy(job);
+                if (rc == SFA_OK)
+                    for (auto &r : results) {
+                        todo[r->index].seconds = secs / nb;
+                        todo[r->index].gpu = device;
+                        out_pool.submit([&emit, r] { emit(r); });
+                    }
                 std::lock_guard<std::mutex> l(io_mu);
-                if (rc != SFA_OK) { std::cerr << "GPU " << dev0 + g << ": " << sfa_last_error(ctx) << std::endl; failed = true; }
-                else for (size_t e = 0; e < idx.size(); e++) {
-                    const Window &wd = todo[idx[e]];
+                if (rc != SFA_OK) { std::cerr << "GPU " << device << ": " << sfa_last_error(ctx) << std::endl; failed = true; }
+                else for (int e = 0; e < nb; e++) {
+                    const Window &wd = todo[mine[b0 + e]];
                     const int f = wd.jet * steps;
                     std::cout << (wd.backward ? "Backward" : "Forward") << " flow from frame " << start + f * skip << " to " << start + f * skip + steps * skip
-                              << " finished! (GPU " << dev0 + g << ", " << secs / idx.size() << " s per window in a batch of " << idx.size() << ")" << std::endl;
+                              << " finished! (GPU " << device << ", " << secs / nb << " s per window in a batch of " << nb << ")" << std::endl;
                 }
             }
+            if (job) sfa_job_destroy(job);
         }
         sfa_ctx_destroy(ctx);
     };
+    const auto t_compute = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
-    for (int wk = 0; wk < nworkers; wk++) th.emplace_back(worker, wk);
+    for (const WorkerPlan &wp : plan) th.emplace_back(worker, wp);
     for (auto &t : th) t.join();
+    const double compute_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_compute).count();
+    out_pool.wait_all();
+    const double total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 
-    // the gathered per-window timings (the only cross-GPU exchange of the path)
+    // the gathered per-window timings (the only cross-GPU exchange of the path) and where the wall time of the run went
     {
         std::ofstream tj((params.output + "timings.json").c_str());
         tj << "[";
@@ -350,10 +414,117 @@ int main(int argc, char **argv) {
                << ", \"seconds\": " << todo[i].seconds << ", \"flo\": \"" << todo[i].out << "\""
                << (todo[i].epe >= 0 ? ", \"epe\": " + std::to_string(todo[i].epe) + ", \"aae\": " + std::to_string(todo[i].aae) : string()) << "}";
         tj << "\n]\n";
+        std::ofstream rj((params.output + "run.json").c_str());
+        rj << "{\"windows\": " << todo.size() << ", \"gpus\": " << ngpu << ", \"streams\": " << streams << ", \"batch\": " << batch << ", \"io_threads\": " << io_threads
+           << ", \"ingest_seconds\": " << ingest_seconds << ", \"refine_seconds\": " << compute_seconds << ", \"total_seconds\": " << total_seconds << "}\n";
     }
     for (unsigned f = start_f; f < end_f; f++) color_image_delete(seq[f]);
     for (auto g : gt) if (g) { image_delete(g[0]); image_delete(g[1]); free(g); }
     color_image_delete(channel_weights);
-    std::cout << (failed ? "Failed!" : "Done!") << std::endl;
     return failed ? 5 : 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { usage(); return 1; }
+    ParameterList params;
+    setDefault(params);
+    if (argv[1][0] != '-' && file_exists(argv[1])) params.read(argv[1]);
+    else { std::cerr << "Couldn't find " << argv[1] << "!" << std::endl; return -1; }
+
+    bool overwrite_output = false;
+    RunOptions opt;
+    int selected_fr = -1;
+    for (int i = 1; i < argc; i++) {                                                 // slow_flow.cpp:168-193
+        const char *a = argv[i];
+        if (a[0] != '-') continue;
+        if (!strcmp(a, "-h") || !strcmp(a, "-help")) usage();
+        else if (!strcmp(a, "-overwrite")) overwrite_output = true;
+        else if (!strcmp(a, "-resume")) opt.resume_frame = true;
+        else if (!strcmp(a, "-deep_settings") && i + 1 < argc) i++;
+        else if (!strcmp(a, "-threads") && i + 1 < argc) params.insert("threads", argv[++i], true);
+        else if (!strcmp(a, "-fr") && i + 1 < argc) selected_fr = atoi(argv[++i]);
+        else if (!strcmp(a, "-jet") && i + 1 < argc) { opt.selected_jet = atoi(argv[++i]); opt.resume_frame = true; }
+        else { fprintf(stderr, "unknown argument %s", a); usage(); }
+    }
+    if (params.parameter<bool>("deep_matching")) { std::cerr << "deep_matching=1 needs the external DeepMatching/SED/EpicFlow stage: not part of this build (set deep_matching 0)" << std::endl; return 2; }
+    const bool raw = params.exists("raw") && params.parameter<bool>("raw");
+    if (raw && params.parameter<int>("raw_demosaicing", "0") != 0) {
+        std::cerr << "raw_demosaicing 1 (Hamilton-Adams, P. Getreuer) and 2 (OpenCV) are third-party code absent from the reference tree: use raw_demosaicing 0 "
+                     "(the reference's own bilinear / green-ratio routine) or provide demosaiced frames with raw 0" << std::endl;
+        return 2;
+    }
+
+    const int steps = params.parameter<int>("slow_flow_S") - 1;                      // :208
+    const int max_fps = params.parameter<int>("max_fps", "1");
+    const int jet_fps = params.exists("jet_fps") ? params.parameter<int>("jet_fps") : max_fps;
+    int skip = (int)((1.0f * max_fps) / jet_fps);                                    // :220
+    const bool sintel = params.parameter<bool>("sintel", "0"), subframes = params.parameter<bool>("subframes", "0");
+    unsigned start = params.sequence_start;
+    const size_t cut = params.file.find_last_of('/') + 1;
+    string sequence_path = params.file.substr(0, cut), format = params.file.substr(cut);
+    if (sequence_path.empty() || params.output.empty()) { std::cerr << "cfg needs 'file' and 'output'" << std::endl; return -1; }
+    if (sintel && !subframes) start *= 1000;
+    params.sequence_start = start;
+
+    if (!opt.resume_frame && !overwrite_output) {                                    // never overwrite a results folder (:254-265)
+        string np = params.output;
+        if (np.back() == '/') np.pop_back();
+        const string base = np;
+        int num = 1;
+        while (file_exists(np)) { std::cerr << np << " already exists!" << std::endl; np = base + "_" + std::to_string(num++); }
+        params.output = np;
+    }
+    if (params.output.back() != '/') params.output += "/";
+
+    // ---- adaptive frame rates (:277-357): adaptiveFR.dat (next to the program: the reference's SOURCE_PATH) names the target quantile and the
+    //      low-rate factor, <sequence>/quantil.dat (written by the adaptiveFR program) holds the sequence's flow-magnitude quantile ------------
+    bool adaptive = false;
+    double quantil = 1.0, hfr_quantil = 2.0;
+    int lfr_factor = 4;
+    AdaptiveRates rates = {1, 4};
+    const string adfr = params.exists("adaptive_fr_file") ? params.parameter("adaptive_fr_file") : exe_dir() + "/adaptiveFR.dat";
+    if (file_exists(adfr)) {
+        std::ifstream f(adfr.c_str());
+        string line;
+        while (std::getline(f, line)) {
+            const size_t tab = line.find('\t');
+            if (tab == string::npos) continue;
+            const string key = line.substr(0, tab), val = line.substr(tab + 1);
+            if (key == "opt_hfr_quantil") hfr_quantil = atof(val.c_str());
+            if (key == "opt_lfr_rate") lfr_factor = (int)atof(val.c_str());
+        }
+        adaptive = params.parameter<bool>("adaptive", "0");
+    }
+    const string qfstr = sequence_path + "/quantil.dat";
+    if (!params.exists("max_flow") && file_exists(qfstr)) {
+        std::ifstream f(qfstr.c_str());
+        string line;
+        std::getline(f, line);
+        quantil = atof(line.c_str());
+        if (adaptive) {
+            const int keyframes = (int)(params.parameter<float>("max_fps") / params.parameter<float>("ref_fps"));   // :324
+            rates = adaptive_rates(quantil, hfr_quantil, lfr_factor, keyframes, steps);
+            if (keyframes == 0) std::cout << rates.hfr_rate << " " << rates.lfr_rate << std::endl;
+            else std::cout << "hfr_rate " << rates.hfr_rate << std::endl << "lfr_rate " << rates.lfr_rate << std::endl;
+        }
+        // without `adaptive` the quantile only bounds DeepMatching's search radius (:353-355): outside this build
+    } else
+        adaptive = false;
+
+    int start_fr = 0, end_fr = adaptive ? 2 : 1;                                     // :359-364
+    if (selected_fr >= 0) { start_fr = selected_fr; end_fr = selected_fr + 1; }
+    int rc_all = 0;
+    for (int adFR = start_fr; adFR < end_fr; adFR++) {                               // :367-399
+        ParameterList adaptCfg(params);
+        if (adaptive) {
+            const int rate = adFR == 0 ? rates.hfr_rate : rates.lfr_rate;
+            adaptCfg.output += adFR == 0 ? "high_fr/" : "low_fr/";
+            adaptCfg.insert("jet_fps", std::to_string(max_fps / rate), true);        // jet estimation fps
+            skip = rate;
+        }
+        const int rc = run_sequence(adaptCfg, sequence_path, format, skip, opt);
+        if (rc != 0) rc_all = rc;
+    }
+    std::cout << (rc_all ? "Failed!" : "Done!") << std::endl;
+    return rc_all;
 }

@@ -1,6 +1,8 @@
 // variational_mt.cpp -- see variational_mt.h
 #include "variational_mt.h"
 
+#include "png.h"
+
 #include <cstdio>
 #include <cstdlib>
 #include <sstream>
@@ -116,10 +118,36 @@ Point2f Variational_MT::variational(image_t *wx, image_t *wy, color_image_t *con
     occlusions = image_new(wx->width, wx->height);
     image_erase(occlusions);
     float change[2] = {0, 0};
-    const int rc = sfa_variational(ctx, &p, wx->data, wy->data, wx->width, wx->height, wx->stride, frames.data(), F, channel_w ? chw : nullptr,
-                                   occlusions->data, change);
+    // the resident-job form of sfa_variational: the same calls, plus the labels of every alternation when the caller asks for them
+    const bool occ_files = p.occlusion_reasoning && params.exists("slow_flow_occlusions_output");       // variational_mt.cpp:275
+    sfa_job *job = nullptr;
+    int rc = sfa_job_create(ctx, &p, wx->width, wx->height, 1, &job);
+    if (rc == SFA_OK && occ_files) rc = sfa_job_keep_alternation_occlusions(job, 1);
+    if (rc == SFA_OK) rc = sfa_job_upload(job, 0, frames.data(), F, wx->data, wy->data, wx->stride, channel_w ? chw : nullptr);
+    if (rc == SFA_OK) rc = sfa_job_run(job);
+    if (rc == SFA_OK) rc = sfa_job_download(job, 0, wx->data, wy->data, wx->stride, change);
+    if (rc == SFA_OK) rc = sfa_job_download_occlusions(job, 0, occlusions->data, occlusions->stride);
+    for (int a = 1; a < p.niter_alter && rc == SFA_OK && occ_files; a++) {                              // :275-285: <prefix><alter>.png
+        image_t *o = image_new(wx->width, wx->height);
+        image_erase(o);
+        rc = sfa_job_download_alternation_occlusions(job, 0, a, o->data, o->stride);
+        if (rc == SFA_OK) {
+            png_image im;
+            im.width = o->width; im.height = o->height; im.channels = 1; im.depth = 8;
+            im.samples.resize((size_t)o->width * o->height);
+            for (int y = 0; y < o->height; y++)
+                for (int x = 0; x < o->width; x++)                                                      // (occ + 1) * 0.5 -> 8 bit, scale 255 (:277-279)
+                    im.samples[(size_t)y * o->width + x] = (uint16_t)((o->data[(size_t)y * o->stride + x] + 1) * 0.5f * 255.0f + 0.5f);
+            std::stringstream occF;
+            occF << params.parameter("slow_flow_occlusions_output") << a << ".png";
+            png_write(occF.str().c_str(), im);
+        }
+        image_delete(o);
+    }
+    const std::string err = rc == SFA_OK ? "" : sfa_last_error(ctx);
+    if (job) sfa_job_destroy(job);
     if (rc == SFA_ERR_REF_FRAME) throw std::logic_error("Frame compared to reference frame is the reference frame itself!");   // aux:419-421
-    if (rc != SFA_OK) throw std::runtime_error(std::string("slowflow_amd variational: ") + sfa_last_error(ctx));
+    if (rc != SFA_OK) throw std::runtime_error("slowflow_amd variational: " + err);
     params.setParameter<int>("final", 0);                                            // variational_mt.cpp:764
     return Point2f(change[0], change[1]);
 }

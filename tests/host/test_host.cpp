@@ -1,5 +1,6 @@
 // CPU-side checks of the host mirror (no GPU needed): ParameterList syntax and accessors, the cfg -> sfa_params
 // mapping of Variational_MT, the .flo wire format, the PPM/PGM/PFM/PNG loaders, ingest, flow colour coding and EPE/AAE.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 #include "io.h"
 #include "parameter_list.h"
 #include "png.h"
+#include "shard.h"
 #include "variational_mt.h"
 
 static int fails = 0;
@@ -257,6 +259,78 @@ int main(int argc, char **argv) {
         CHECK(same && same->width == 4 && same->data[1 * same->stride + 3] == 13.0f);
         image_delete(u); image_delete(v); image_delete(gu); image_delete(gv); image_delete(m); image_delete(other);
         image_delete(src); image_delete(halfsz); image_delete(dbl); image_delete(same);
+    }
+    // ---- shard.h: who refines which window (the reference's OpenMP loop over jets, slow_flow.cpp:706) -----------------------------------
+    {
+        // config 4 on a full node: 64 jets x 2 directions over 8 GPUs x 2 streams
+        const std::vector<WorkerPlan> plan = plan_workers(128, 8, 2);
+        CHECK(plan.size() == 16);
+        size_t next = 0;
+        for (size_t i = 0; i < plan.size(); i++) {
+            CHECK(plan[i].worker == (int)i && plan[i].gpu == (int)i / 2 && plan[i].stream == (int)i % 2);
+            CHECK(plan[i].lo == next && plan[i].hi - plan[i].lo == 8);              // contiguous, 8 windows = 4 jets (fwd + bwd) per worker
+            next = plan[i].hi;
+        }
+        CHECK(next == 128);
+        for (int ngpu = 1; ngpu <= 8; ngpu++)
+            for (int st = 1; st <= 4; st++)
+                for (size_t n : {(size_t)0, (size_t)1, (size_t)7, (size_t)128, (size_t)129}) {
+                    const std::vector<WorkerPlan> p = plan_workers(n, ngpu, st);
+                    size_t cover = 0, mn = n, mx = 0;
+                    for (const WorkerPlan &w : p) {
+                        CHECK(w.lo == cover && w.hi >= w.lo && w.gpu >= 0 && w.gpu < ngpu && w.gpu == w.worker / st);
+                        cover = w.hi;
+                        mn = std::min(mn, w.hi - w.lo); mx = std::max(mx, w.hi - w.lo);
+                    }
+                    CHECK(cover == n && (int)p.size() == ngpu * st && mx - mn <= 1);
+                    for (size_t i = 1; i < p.size(); i++) CHECK(p[i].gpu >= p[i - 1].gpu);   // a GPU's windows are contiguous
+                }
+        CHECK(plan_workers(5, 0, 0).size() == 1);
+    }
+    // ---- shard.h: adaptive frame rates (slow_flow.cpp:322-352), evaluated by hand from the reference's text -----------------------------
+    {
+        AdaptiveRates r = adaptive_rates(1.0, 2.0, 4, 10, 1);      // hfr = round(2/1) = 2 (10 % 2 == 0); lfr = min(10, 8) = 8 -> 9 -> 10; min(10/1, 10)
+        CHECK(r.hfr_rate == 2 && r.lfr_rate == 10);
+        r = adaptive_rates(0.5, 2.0, 4, 10, 2);                    // hfr = 4: 10 % 8 != 0 -> 5: 10 % 10 == 0; lfr = min(10, 20) = 10: 20 >= 10, 20 % 10 == 0; min(10/2, 10) = 5
+        CHECK(r.hfr_rate == 5 && r.lfr_rate == 5);
+        r = adaptive_rates(4.0, 2.0, 4, 10, 1);                    // slow sequence: hfr = max(1, round(.5)) = 1; lfr = min(10, 4) = 4 -> 5 (10 % 5 == 0, 5 % 1 == 0)
+        CHECK(r.hfr_rate == 1 && r.lfr_rate == 5);
+        r = adaptive_rates(0.7, 2.0, 4, 0, 1);                     // no keyframes: hfr = int(2.857) = 2; lfr = 2*4 = 8, then 2*8 = 16; m = round(16/2) = 8 -> 16
+        CHECK(r.hfr_rate == 2 && r.lfr_rate == 16);
+        r = adaptive_rates(5.0, 2.0, 4, 0, 1);                     // hfr = int(0.4) = 0 -> max(1, 0) = 1; lfr = 4, 4; m = 4
+        CHECK(r.hfr_rate == 1 && r.lfr_rate == 4);
+    }
+    // ---- shard.h: the task pool runs everything it was given, wait_all() waits for it ---------------------------------------------------
+    {
+        std::atomic<int> sum(0);
+        {
+            TaskPool pool(4);
+            for (int i = 1; i <= 200; i++) pool.submit([&sum, i] { sum += i; });
+            pool.wait_all();
+            CHECK(sum == 200 * 201 / 2);
+            for (int i = 0; i < 50; i++) pool.submit([&sum] { sum += 1; });
+        }                                                          // the destructor drains the queue
+        CHECK(sum == 200 * 201 / 2 + 50);
+    }
+    // ---- ingest on inputs written by tests/test_host.py (checked there against a numpy evaluation of utils.cpp:1241-1374) ---------------
+    {
+        std::ifstream m((tmp + "/bayer.txt").c_str());
+        int w = 0, h = 0, rx = 0, ry = 0;
+        float weight = 0;
+        if (m >> w >> h >> rx >> ry >> weight) {
+            image_t *mosaic = image_new(w, h);
+            std::ifstream f((tmp + "/bayer_in.bin").c_str(), std::ios::binary);
+            f.read(reinterpret_cast<char *>(mosaic->data), (std::streamsize)((size_t)mosaic->stride * h * sizeof(float)));
+            color_image_t *rgb = color_image_new(w, h), *cw = color_image_new(w, h);
+            color_image_erase(rgb);
+            bayer2rgbGR(mosaic, rgb, rx, ry);
+            for (size_t i = 0; i < (size_t)3 * cw->stride * h; i++) cw->c1[i] = 1.0f;
+            rawWeighting(cw, rx, ry, weight);
+            std::ofstream o1((tmp + "/bayer_rgb.bin").c_str(), std::ios::binary), o2((tmp + "/bayer_w.bin").c_str(), std::ios::binary);
+            o1.write(reinterpret_cast<const char *>(rgb->c1), (std::streamsize)((size_t)3 * rgb->stride * h * sizeof(float)));
+            o2.write(reinterpret_cast<const char *>(cw->c1), (std::streamsize)((size_t)3 * cw->stride * h * sizeof(float)));
+            image_delete(mosaic); color_image_delete(rgb); color_image_delete(cw);
+        }
     }
     printf(fails ? "host tests FAILED (%d)\n" : "host tests OK\n", fails);
     return fails ? 1 : 0;

@@ -688,21 +688,149 @@ def test_grid_cut_sparse_phase_runs_the_same_rounds(ctx, monkeypatch, kind, w, h
 
 @pytest.mark.parametrize("S,rho,omega", [(2, [1], [0]), (3, [1, 1], [0, 2])])
 def test_level_with_occlusion_reasoning(ctx, oracle, S, rho, omega):
-    """alternations with the discrete occlusion step (cfgs/slow_flow.cfg: occlusion reasoning on): same labels, same flow"""
+    """alternations with the discrete occlusion step (cfgs/slow_flow.cfg: occlusion reasoning on).  A minimum cut need not be unique, so
+    the comparison is made under ONE labelling: the GPU's labels of every alternation (sfa_job_keep_alternation_occlusions) are (a) checked
+    to be minimum-energy labellings of the oracle's own costs at that alternation and (b) forced on the oracle (orc_force_labels), whose
+    flow must then match the GPU's -- unconditionally."""
     w, h = 96, 64
+    A = 3
     frames, af, sf = normalized_frames(oracle, w, h, 2 * S - 1, seed=4)
-    po, ps = mk_params(oracle, S=S, rho=rho, omega=omega, norm_avg=af, norm_std=sf, niter_outer=2, niter_alter=3, occlusion_reasoning=1)
+    po, ps = mk_params(oracle, S=S, rho=rho, omega=omega, norm_avg=af, norm_std=sf, niter_outer=2, niter_alter=A, occlusion_reasoning=1, layers=1)
     stride = orc.stride_of(w)
+    job = sfa.Job(ctx, ps, w, h, 1)
+    job.keep_alternation_occlusions(True)
+    job.upload(0, [c_(f) for f in frames])
+    job.run()
+    wxg, wyg, _ = job.download(0)
+    occ_g = job.download_occlusions(0)
+    labels = orc.aligned_zeros((A, h, stride))
+    for a in range(1, A):
+        labels[a] = job.download_alternation_occlusions(0, a)
+        assert set(np.unique(valid(labels[a], w))) <= {-1.0, 1.0}
+    job.close()
+    assert np.array_equal(occ_g, labels[A - 1])                                             # getOcclusions() = the last alternation's labels
+    assert (valid(occ_g, w) > 0).any() and (valid(occ_g, w) < 0).any()                      # the cut did label something "future"
+    # the oracle on its own: its labels may differ from the GPU's only where the minimum is not unique
     wxo, wyo = orc.plane(h, stride), orc.plane(h, stride)
-    wxg, wyg = c_(wxo).copy(), c_(wyo).copy()
-    rc, cho, occ_o = oracle.compute_one_level(po, wxo, wyo, frames, w, None, want_occ=True)
-    chg, occ_g = ctx.compute_one_level(ps, wxg, wyg, [c_(f) for f in frames], w, None, want_occ=True)
-    assert rc == 0
-    assert set(np.unique(valid(occ_g, w))) <= {-1.0, 1.0} and (valid(occ_g, w) > 0).any()    # the cut did label something "future"
-    assert (valid(occ_o, w) != valid(occ_g, w)).mean() < 0.002
-    d = max(np.abs(valid(wxo, w) - valid(wxg, w)).max(), np.abs(valid(wyo, w) - valid(wyg, w)).max())
-    if np.array_equal(valid(occ_o, w), valid(occ_g, w)):
-        assert d <= max(TOL_LEVEL, 3 * oracle_sensitivity(oracle, po, frames, w, h)), d
+    rc, _, occ_o = oracle.compute_one_level(po, wxo, wyo, frames, w, None, want_occ=True)
+    assert rc == 0 and (valid(occ_o, w) != valid(occ_g, w)).mean() < 0.002
+    # the oracle under the GPU's labels
+    oracle.force_labels(labels)
+    try:
+        wxf, wyf = orc.plane(h, stride), orc.plane(h, stride)
+        rc, _, occ_f = oracle.compute_one_level(po, wxf, wyf, frames, w, None, want_occ=True)
+        gaps = [oracle.forced_gap(a) for a in range(1, A)]
+    finally:
+        oracle.force_labels(None)
+    assert rc == 0 and np.array_equal(valid(occ_f, w), valid(occ_g, w))
+    assert max(abs(g) for g in gaps) <= 1e-5, gaps                                          # each GPU labelling is a minimum of the oracle's energy
+    d = max(np.abs(valid(wxf, w) - valid(wxg, w)).max(), np.abs(valid(wyf, w) - valid(wyg, w)).max())
+    assert d <= max(TOL_LEVEL, 3 * oracle_sensitivity(oracle, po, frames, w, h)), d
+
+
+def test_config3_full_schedule_2560x1440(ctx, oracle):
+    """BASELINE config 3 (stand-in for the `sheeps` teaser, SURVEY.md 8d: 2560x1440 synthetic) under the FULL cfgs/slow_flow.cfg schedule:
+    S=3, rho 1/1, omega 0/2, modified L1, 5 levels, 10 alternations x 10 outer x 30 sweeps, occlusion reasoning on, thresholds 1e-5.
+    The oracle needs hours at this size, so the checks are properties: the known (2,1) px/frame translation is recovered, the labels are
+    labels, a second run of the same job gives the same bits, and a lockstep batch of two windows gives each window's own result."""
+    w, h = 2560, 1440
+    frames, af, sf = normalized_frames(oracle, w, h, 5, seed=23)
+    _, ps = mk_params(oracle, S=3, rho=[1, 1], omega=[0, 2], norm_avg=af, norm_std=sf, niter_alter=10, niter_outer=10, layers=5, occlusion_reasoning=1,
+                      thres_outer=1e-5, thres_inner=1e-5, occlusion_penalty=0.1, occlusion_alpha=0.1)
+    fr = [c_(f) for f in frames]
+    job = sfa.Job(ctx, ps, w, h, 1)
+    job.upload(0, fr[0:5])
+    job.run()
+    wx, wy, chg = job.download(0)
+    occ = job.download_occlusions(0)
+    job.run()
+    wx2, wy2, _ = job.download(0)
+    job.close()
+    assert np.isfinite(wx).all() and np.isfinite(wy).all()
+    assert abs(np.median(valid(wx, w)) - 2.0) < 0.1 and abs(np.median(valid(wy, w)) - 1.0) < 0.1
+    inner = (slice(40, h - 40), slice(40, w - 40))
+    assert np.abs(wx[inner] - 2.0).mean() < 0.1 and np.abs(wy[inner] - 1.0).mean() < 0.1
+    assert set(np.unique(valid(occ, w))) <= {-1.0, 1.0}
+    assert np.array_equal(wx, wx2) and np.array_equal(wy, wy2)
+    assert 0 <= chg[0] < 1e-2 and 0 <= chg[1] < 1e-2                                        # the last outer iteration barely moves the flow
+    job2 = sfa.Job(ctx, ps, w, h, 2)
+    job2.upload(0, fr[::-1]); job2.upload(1, fr[0:5])                                       # the backward window rides along
+    job2.run()
+    bx, by, _ = job2.download(1)
+    job2.close()
+    assert np.array_equal(bx, wx) and np.array_equal(by, wy)
+
+
+def test_batch_with_thresholds_keeps_every_window_exact(ctx, oracle):
+    """cfg thresholds on: windows of a lockstep batch meet them at different outer iterations and ride along as passengers of the batched
+    launches; each must end with exactly the result it gets alone (which test_thresholds_break_like_the_oracle ties to the oracle)"""
+    w, h = 130, 98
+    sets = [normalized_frames(oracle, w, h, 3, seed=s)[0] for s in (1, 2)]
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=3)
+    still = [frames[1], frames[1], frames[1]]                                               # no motion: converges at once
+    wins = [sets[0], still, sets[1], still, frames, sets[0], still, frames, sets[1]]        # 9 windows: the band kernel's batch path
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=8, niter_inner=2, layers=2, thres_outer=2e-3, thres_inner=1e-3)
+    alone = []
+    for f in wins[:5]:
+        j1 = sfa.Job(ctx, ps, w, h, 1)
+        j1.upload(0, [c_(x) for x in f]); j1.run()
+        alone.append(j1.download(0))
+        j1.close()
+    job = sfa.Job(ctx, ps, w, h, len(wins))
+    for b, f in enumerate(wins):
+        job.upload(b, [c_(x) for x in f])
+    job.run()
+    for b in range(len(wins)):
+        gx, gy, chg = job.download(b)
+        ref = alone[[0, 1, 2, 1, 4, 0, 1, 4, 2][b]]
+        assert np.array_equal(gx, ref[0]) and np.array_equal(gy, ref[1]) and chg == ref[2], b
+    job.close()
+    assert np.abs(alone[1][0]).max() < 1e-3                                                 # the still window did stop early (and stayed put)
+
+
+def test_job_can_be_run_again_and_slots_reused(ctx, oracle):
+    """a resident job is reused: run(); run() gives run() -- also with presmoothing (cfg sigma > 0), which replaces the uploaded frames once
+    per upload -- and a slot that held channel weights forgets them when the next window comes without"""
+    w, h = 130, 98
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=13)
+    other, _, _ = normalized_frames(oracle, w, h, 3, seed=14)
+    rng = np.random.default_rng(0)
+    chw = [c_(noise_plane(rng, w, h, 0.5, 1.5)) for _ in range(3)]
+    for sigma in (0.0, 0.8):
+        _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, layers=2, niter_outer=2, presmooth_sigma=sigma)
+        fresh = sfa.Job(ctx, ps, w, h, 2)
+        fresh.upload(0, [c_(f) for f in frames]); fresh.upload(1, [c_(f) for f in other])
+        fresh.run()
+        want = [fresh.download(b) for b in (0, 1)]
+        fresh.run()
+        for b in (0, 1):
+            again = fresh.download(b)
+            assert np.array_equal(again[0], want[b][0]) and np.array_equal(again[1], want[b][1]), (sigma, b)
+        fresh.close()
+        job = sfa.Job(ctx, ps, w, h, 2)
+        job.upload(0, [c_(f) for f in other], chw=chw); job.upload(1, [c_(f) for f in frames], chw=chw)
+        job.run()
+        weighted = job.download(0)
+        job.upload(0, [c_(f) for f in frames]); job.upload(1, [c_(f) for f in other])    # new windows into used slots, no weights
+        job.run()
+        for b in (0, 1):
+            got = job.download(b)
+            assert np.array_equal(got[0], want[b][0]) and np.array_equal(got[1], want[b][1]), (sigma, b)
+        assert not np.array_equal(weighted[0], want[1][0])                                  # the weights did matter
+        job.close()
+
+
+@pytest.mark.parametrize("sw,sh,fx,fy", [(130, 98, 0.5, 0.5), (131, 97, 0.5, 0.5), (200, 150, 0.3, 0.3), (67, 45, 0.75, 0.6), (64, 48, 1.5, 1.25), (1024, 436, 0.4, 0.4)])
+def test_resize_linear_fx(ctx, oracle, sw, sh, fx, fy):
+    """the driver's input rescaling (slow_flow.cpp:552: cv::resize(Size(0,0), fx, fy, INTER_LINEAR)): source coordinate (dst + .5) / f - .5,
+    which is NOT the explicit-dsize form when sw * fx is not an integer"""
+    rng = np.random.default_rng(sw + sh)
+    src = noise_plane(rng, sw, sh, 0, 255)
+    a, dwa = oracle.resize_linear_fx(src, sw, fx, fy)
+    b, dwb = ctx.resize_linear_fx(c_(src), sw, fx, fy)
+    assert dwa == dwb and a.shape == b.shape and np.array_equal(valid(a, dwa), valid(b, dwb))
+    if (sw * fx) % 1:
+        assert not np.array_equal(valid(a, dwa), valid(oracle.resize_linear_cv(src, sw, dwa, a.shape[0]), dwa))
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -93,6 +93,66 @@ def write_png_cases(tmp_path):
     (tmp_path / "png_cases.txt").write_text("\n".join(lines) + "\n")
 
 
+def bayer_numpy(src, rx, ry):
+    """utils.cpp:1241-1334 evaluated with numpy: green by the mean of the 4 neighbours at red / blue sites (mirrored borders), red and blue
+    through the local green ratio; float operands, double products where the C expression promotes (0.25 * float, float * 0.5 * float)"""
+    h, w = src.shape
+    xm1 = np.where(np.arange(w) > 0, np.arange(w) - 1, np.arange(w) + 1); xp1 = np.where(np.arange(w) < w - 1, np.arange(w) + 1, np.arange(w) - 1)
+    ym1 = np.where(np.arange(h) > 0, np.arange(h) - 1, np.arange(h) + 1); yp1 = np.where(np.arange(h) < h - 1, np.arange(h) + 1, np.arange(h) - 1)
+    Y, X = np.mgrid[0:h, 0:w]
+    blue_row = (Y + (1 - ry)) % 2 == 0
+    green = np.where(blue_row, (X + rx) % 2 == 0, (X + (1 - rx)) % 2 == 0)
+    f32 = np.float32
+    nb4 = ((src[ym1][:, :] + src[yp1][:, :]).astype(f32) + src[:, xm1]).astype(f32) + src[:, xp1]           # left to right, float
+    G = np.where(green, src, (0.25 * nb4.astype(np.float64)).astype(f32)).astype(f32)
+
+    def ratio(ys, xs):
+        return (src[np.ix_(ys, xs)] / G[np.ix_(ys, xs)]).astype(f32)
+    ar = np.arange
+    vert = (ratio(ym1, ar(w)) + ratio(yp1, ar(w))).astype(f32)
+    horz = (ratio(ar(h), xm1) + ratio(ar(h), xp1)).astype(f32)
+    diag = (((ratio(ym1, xm1) + ratio(ym1, xp1)).astype(f32) + ratio(yp1, xm1)).astype(f32) + ratio(yp1, xp1)).astype(f32)
+    g64 = G.astype(np.float64)
+    half_v, half_h, quarter_d = (g64 * 0.5 * vert).astype(f32), (g64 * 0.5 * horz).astype(f32), (g64 * 0.25 * diag).astype(f32)
+    R = np.where(blue_row, np.where(green, half_v, quarter_d), np.where(green, half_h, src))
+    B = np.where(blue_row, np.where(green, half_h, src), np.where(green, half_v, quarter_d))
+    return np.stack([R, G, B]).astype(f32)
+
+
+def raw_weights_numpy(w, h, rx, ry, weight):
+    """utils.cpp:1336-1374"""
+    weight = min(max(weight, 0.0), 3.0)
+    other = np.float32(0.5 * (3 - np.float64(np.float32(weight))))
+    Y, X = np.mgrid[0:h, 0:w]
+    blue_row = (Y + (1 - ry)) % 2 == 0
+    green = np.where(blue_row, ((X + (1 - rx)) % 2 == 0) if ry == 1 else ((X + rx) % 2 == 0), ((X + (1 - rx)) % 2 == 0) if ry == 0 else ((X + rx) % 2 == 0))
+    W = np.full((3, h, w), other, np.float32)
+    W[1][green] = weight
+    W[2][blue_row & ~green] = weight
+    W[0][~blue_row & ~green] = weight
+    return W
+
+
+@pytest.mark.parametrize("rx,ry,weight", [(1, 0, 2.0), (0, 0, 1.0), (0, 1, 5.0), (1, 1, 0.5)])
+def test_demosaic_and_raw_weights_against_numpy(host_build, tmp_path, rx, ry, weight):
+    """the host ingest routines (restated from utils.cpp:1241-1374, which needs OpenCV to build) against a direct numpy evaluation"""
+    w, h = 37, 22
+    st = ((w + 3) // 4) * 4
+    rng = np.random.default_rng(rx + 2 * ry)
+    mosaic = np.zeros((h, st), np.float32)
+    mosaic[:, :w] = rng.uniform(20, 4000, (h, w)).astype(np.float32)
+    mosaic.tofile(str(tmp_path / "bayer_in.bin"))
+    (tmp_path / "bayer.txt").write_text("%d %d %d %d %g\n" % (w, h, rx, ry, weight))
+    write_png_cases(tmp_path)
+    exe = _link_host_test(tmp_path, ["test_host.cpp"], "test_host")
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "host tests OK" in r.stdout, r.stdout + r.stderr
+    rgb = np.fromfile(str(tmp_path / "bayer_rgb.bin"), dtype=np.float32).reshape(3, h, st)[:, :, :w]
+    cw = np.fromfile(str(tmp_path / "bayer_w.bin"), dtype=np.float32).reshape(3, h, st)[:, :, :w]
+    assert np.array_equal(rgb, bayer_numpy(mosaic[:, :w], rx, ry))
+    assert np.array_equal(cw, raw_weights_numpy(w, h, rx, ry, weight))
+
+
 def test_host_mirror_cpu(host_build, tmp_path):
     write_png_cases(tmp_path)
     exe = str(tmp_path / "test_host")
@@ -191,7 +251,7 @@ def test_slow_flow_driver_end_to_end(host_build, tmp_path, alter, occ):
     assert abs(np.median(u) - 1.5) < 0.1 and abs(np.median(v) + 0.75) < 0.1
     if occ:                                                       # the occlusion labels of every forward window were written
         for j in range(jets):
-            with open(str(out / "occlusion" / ("f_%03d_occ.pgm" % (10 + j * steps))), "rb") as f:
+            with open(str(out / "occlusion" / ("frame_%d.pgm" % (10 + j * steps))), "rb") as f:
                 assert f.readline() == b"P5\n" and f.readline().split() == [b"%d" % w, b"%d" % h]
     for j in range(jets):                                         # the colour-coded forward flows: a constant translation = one colour
         with open(str(out / ("frame_%d.png" % (10 + j * steps))), "rb") as f:
@@ -282,3 +342,240 @@ def test_driver_ingest_scale_and_raw(host_build, tmp_path):
     cfg.write_text("file\t%s/m_%%03i.pgm\noutput\t%s/out_raw2\nraw\t1\nraw_demosaicing\t1\n" % (tmp_path, tmp_path) + common)
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "raw_demosaicing" in r.stderr
+
+
+def _link_host_test(tmp_path, sources, name):
+    exe = str(tmp_path / name)
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-pthread", "-I", HOST] + [os.path.join(ROOT, "tests", "host", x) for x in sources] +
+                       [os.path.join(HOST, "libslowflow_host.a"), "-L", os.path.join(ROOT, "slowflow_amd"), "-lslowflow_amd", "-lz",
+                        "-Wl,-rpath," + os.path.join(ROOT, "slowflow_amd"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_entry_point_tests_compile_and_link(host_build, tmp_path):
+    """the GPU tests of the C++ entry points build against the host library and the C-ABI .so here (they run on the GPU box)"""
+    _link_host_test(tmp_path, ["test_entry_points.cpp", "test_entry_symbols.cpp"], "test_entry_points")
+
+
+@pytest.mark.gpu
+def test_cpp_entry_points(host_build, tmp_path):
+    """north_star's entry points, called as the reference's own caller calls them (slow_flow.cpp:673, :865-888, :1018-1023): C++
+    normalize() + Variational_MT::variational (forward with setChannelWeights, backward without) against the same windows through the
+    C-ABI binding, bit for bit; the literal symbols sor_coupled (solver.h:11) and variational (variational.h:34) on the golden systems
+    against the outputs of the compiled reference (tests/golden) and the oracle."""
+    import slowflow_amd as sfa
+    from synth import texture_frame
+    exe = _link_host_test(tmp_path, ["test_entry_points.cpp", "test_entry_symbols.cpp"], "test_entry_points")
+    w, h, S, n = 96, 64, 3, 7
+    F = 2 * (S - 1) + 1
+    stride = sfa.stride_of(w)
+    rng = np.random.default_rng(0)
+    frames = []
+    for k in range(n):
+        a = np.zeros((3, h, stride), np.float32)
+        a[:, :, :w] = np.clip(np.round(texture_frame(w, h, k)[:, :, :w]), 0, 255)
+        a.tofile(str(tmp_path / ("ep_frame_%d.bin" % k)))
+        frames.append(a)
+    chw = np.ones((3, h, stride), np.float32)
+    chw[:, :, :w] = rng.uniform(0.5, 1.5, (3, h, w)).astype(np.float32)
+    chw.tofile(str(tmp_path / "ep_chw.bin"))
+    (tmp_path / "ep.cfg").write_text(
+        "slow_flow_S\t3\nslow_flow_layers\t3\nslow_flow_p_scale\t0.9\nslow_flow_niter_alter\t2\nslow_flow_niter_outer\t3\nslow_flow_niter_inner\t1\n"
+        "slow_flow_niter_solver\t30\nslow_flow_sor_omega\t1.9\nslow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_occlusion_reasoning\t1\n"
+        "slow_flow_occlusion_penalty\t0.1\nslow_flow_occlusion_alpha\t0.1\nslow_flow_rho_0\t1\nslow_flow_rho_1\t1\nslow_flow_omega_0\t0\nslow_flow_omega_1\t2\n"
+        "slow_flow_alpha\t4.0\nslow_flow_gamma\t6.0\nslow_flow_delta\t1.0\nslow_flow_smoothing\t1\nslow_flow_dataterm\t1\n16bit\t0\n"
+        "slow_flow_robust_color\t1\nslow_flow_robust_color_eps\t0.001\nslow_flow_robust_color_truncation\t0.5\n"
+        "slow_flow_robust_reg\t1\nslow_flow_robust_reg_eps\t0.001\nslow_flow_robust_reg_truncation\t0.5\n")
+    # the literal symbols' inputs: the golden SOR system and the golden two-frame case (outputs of the compiled reference are committed)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "ref_vectors.npz"))
+    T = np.load(os.path.join(ROOT, "tests", "golden", "ref_two_frame.npz"))
+    sw, sh_ = 67, 45
+    names = ["du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv"]
+    sysm = {nm: np.ascontiguousarray(G["sor_%dx%d_in_%s" % (sw, sh_, nm)], dtype=np.float32) for nm in names}
+    for nm in names:
+        sysm[nm].tofile(str(tmp_path / ("sym_sor_%s.bin" % nm)))
+    (tmp_path / "sym_sor.txt").write_text("%d %d 30 1.9\n" % (sw, sh_))
+    tw, th = (int(v) for v in T["size"])
+    for nm, key in (("im1", "im1"), ("im2", "im2"), ("wx", "wx0"), ("wy", "wy0")):
+        np.ascontiguousarray(T[key], dtype=np.float32).tofile(str(tmp_path / ("sym_var_%s.bin" % nm)))
+    (tmp_path / "sym_var.txt").write_text("%d %d 3.0 0.2 0.0 1.0 5 1 7 1.5\n" % (tw, th))        # the "weights" case of make_golden_2frame.py
+    r = subprocess.run([exe, str(tmp_path), str(w), str(h), str(n)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "entry points OK" in r.stdout, r.stdout + r.stderr
+
+    def rd(name, hh=h, st=stride):
+        return np.fromfile(str(tmp_path / name), dtype=np.float32).reshape(hh, st)
+    # ---- Variational_MT against the binding ---------------------------------------------------------------------------
+    ctx = sfa.Context(0)
+    fr = [f.copy() for f in frames]
+    avg, std = ctx.normalize(fr, w)
+    cfg = (tmp_path / "ep_after_normalize.cfg").read_text()
+    for k in range(3):
+        assert ("slow_flow_img_norm_avg_%d\t%g" % (k + 1, avg[k])) in cfg and ("slow_flow_img_norm_std_%d\t%g" % (k + 1, std[k])) in cfg
+    p = sfa.default_params()
+    p.S = 3; p.layers = 3; p.niter_alter = 2; p.niter_outer = 3; p.occlusion_reasoning = 1; p.thres_outer = 0; p.thres_inner = 0; p.hbit = 0
+    p.rho[0] = 1; p.rho[1] = 1; p.omega[0] = 0; p.omega[1] = 2; p.occlusion_penalty = 0.1; p.occlusion_alpha = 0.1
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    for tag, win, cw in (("fwd", fr[0:F], [np.ascontiguousarray(chw[k]) for k in range(3)]), ("bwd", [fr[n - 1 - i] for i in range(n - F, n)], None)):
+        wx, wy = np.zeros((h, stride), np.float32), np.zeros((h, stride), np.float32)
+        chg, occ = ctx.variational(p, wx, wy, win, w, cw, want_occ=True)
+        assert np.array_equal(rd("ep_%s_wx.bin" % tag)[:, :w], wx[:, :w]) and np.array_equal(rd("ep_%s_wy.bin" % tag)[:, :w], wy[:, :w]), tag
+        assert np.array_equal(rd("ep_%s_occ.bin" % tag)[:, :w], occ[:, :w]), tag
+        c = [float(v) for v in (tmp_path / ("ep_%s_change.txt" % tag)).read_text().split()]
+        assert abs(c[0] - chg[0]) <= 1e-7 and abs(c[1] - chg[1]) <= 1e-7
+    fx = rd("ep_fwd_wx.bin")[:, :w]
+    assert abs(np.median(fx) - 1.5) < 0.15                                     # and it is a flow: the texture moves by (1.5, -0.75) px / frame
+    assert not np.array_equal(fx, -rd("ep_bwd_wx.bin")[:, :w])
+    ctx.close()
+    # ---- sor_coupled (solver.h:11): the committed outputs of the compiled reference's own sor_coupled (tests/golden/make_golden.py), a11 / a12 /
+    #      a22 overwritten with the inverted blocks as solver.c:183-188 does ----------------------------------------------------------------
+    sst = sysm["du"].shape[1]
+    for nm, key in (("du", "K30_du"), ("dv", "K30_dv"), ("a11", "inv_a11"), ("a12", "inv_a12"), ("a22", "inv_a22")):
+        assert np.array_equal(rd("sym_sor_out_%s.bin" % nm, sh_, sst)[:, :sw], G["sor_%dx%d_%s" % (sw, sh_, key)][:, :sw]), nm
+    # ---- variational (variational.h:34): the committed output of the compiled reference -----------------------------------------
+    tst = T["wx0"].shape[1]
+    assert np.array_equal(rd("sym_var_out_wx.bin", th, tst)[:, :tw], T["weights_wx"]) and np.array_equal(rd("sym_var_out_wy.bin", th, tst)[:, :tw], T["weights_wy"])
+
+
+def _write_sequence(out, nframes, first, W, H, seed=0, amp=0.5):
+    """synthetic high-speed sequence as PPM files f_%04d.ppm: band-limited texture moving by a smooth sub-pixel flow per frame"""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    pad = 96
+    base = gaussian_filter(rng.uniform(0, 1, size=(3, H + 2 * pad, W + 2 * pad)), sigma=(0, 2.0, 2.0), mode="nearest")
+    base = (base - base.min()) / (base.max() - base.min()) * 255.0
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    fu = amp + 0.3 * amp * np.sin(2 * np.pi * yy / H)
+    fv = 0.3 * amp * np.cos(2 * np.pi * xx / W)
+    frames = []
+    for t in range(nframes):
+        sx, sy = xx - t * fu + pad, yy - t * fv + pad
+        x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+        ax, ay = sx - x0, sy - y0
+        img = np.empty((3, H, W), np.float64)
+        for c in range(3):
+            b = base[c]
+            img[c] = b[y0, x0] * (1 - ax) * (1 - ay) + b[y0, x0 + 1] * ax * (1 - ay) + b[y0 + 1, x0] * (1 - ax) * ay + b[y0 + 1, x0 + 1] * ax * ay
+        write_ppm(os.path.join(out, "f_%04d.ppm" % (first + t)), img)
+        frames.append(np.clip(np.round(img), 0, 255).astype(np.float32))
+    return frames, fu, fv
+
+
+CFG4_SOLVER = ("slow_flow_S\t3\nslow_flow_layers\t5\nslow_flow_p_scale\t0.9\nslow_flow_niter_alter\t10\nslow_flow_niter_outer\t10\nslow_flow_niter_inner\t1\n"
+               "slow_flow_niter_solver\t30\nslow_flow_sor_omega\t1.9\nslow_flow_occlusion_reasoning\t1\nslow_flow_occlusion_penalty\t0.1\nslow_flow_occlusion_alpha\t0.1\n"
+               "slow_flow_rho_0\t1\nslow_flow_rho_1\t1\nslow_flow_omega_0\t0\nslow_flow_omega_1\t2\nslow_flow_alpha\t4.0\nslow_flow_gamma\t6.0\nslow_flow_delta\t1.0\n"
+               "slow_flow_thres_outer\t1e-5\nslow_flow_thres_inner\t1e-5\n")
+
+
+@pytest.mark.gpu
+def test_config4_cfg_over_64_jets_1024x436(host_build, tmp_path):
+    """BASELINE config 4 on this box's GPU: the reference's cfgs/slow_flow.cfg solver section (S=3, 5 layers, 10 alternations x 10 outer x 30
+    sweeps, occlusion reasoning, thresholds 1e-5) over 64 consecutive jets of a 1024x436 sequence, forward and backward, through the
+    slow_flow driver (133 PPM frames in; 128 .flo, 64 colour PNG, 64 occlusion maps out).  A sample of the .flo files equals the same
+    windows refined one by one through the C-ABI binding bit for bit (windows batched 32 at a time in the driver: lockstep, passengers and
+    job reuse included), the sub-pixel motion is recovered, and timings.json accounts for all 128 windows.  run.json shows where the wall
+    time went: the refinement (GPU-bound) must be the bulk, ingest and output overlapped around it."""
+    import json
+    import slowflow_amd as sfa
+    W, H, S, JETS = 1024, 436, 3, 64
+    steps = S - 1
+    nframes = 1 + (JETS + 2) * steps
+    seqdir = str(tmp_path)
+    frames, fu, fv = _write_sequence(seqdir, nframes, 100 - steps, W, H)
+    cfg = tmp_path / "run.cfg"
+    cfg.write_text("file\t%s/f_%%04i.ppm\noutput\t%s/out\nJets\t%d\nstart\t100\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\ngpus\t1\n"
+                   "slow_flow_output_occlusions\t1\n" % (seqdir, seqdir, JETS) + CFG4_SOLVER)
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "Done!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    out = tmp_path / "out"
+    tj = json.load(open(str(out / "timings.json")))
+    assert len(tj) == 2 * JETS and all(t["gpu"] == 0 and t["seconds"] > 0 for t in tj)
+    assert sorted((t["jet"], t["direction"]) for t in tj) == sorted((j, d) for j in range(JETS) for d in ("forward", "backward"))
+    for j in range(JETS):
+        assert (out / ("f_%04d.flo" % (100 + j * steps))).exists() and (out / ("f_%04d_back.flo" % (100 + j * steps + steps))).exists()
+        assert (out / ("frame_%d.png" % (100 + j * steps))).exists() and (out / "occlusion" / ("frame_%d.pgm" % (100 + j * steps))).exists()
+    run = json.load(open(str(out / "run.json")))
+    assert run["windows"] == 128 and run["refine_seconds"] <= run["total_seconds"]
+    print("config 4 through the driver on one GPU: %s" % run)
+    # the pipeline hides ingest and output: beyond the refinement itself the run may spend 15 % + 1.5 s (133 frames decoded, normalize, config echo)
+    assert run["total_seconds"] <= 1.15 * run["refine_seconds"] + 1.5, run
+    # ---- a sample of windows through the binding ------------------------------------------------------------------------------
+    ctx = sfa.Context(0)
+    stride = sfa.stride_of(W)
+    fr = []
+    for f in frames:
+        a = np.zeros((3, H, stride), np.float32)
+        a[:, :, :W] = f
+        fr.append(a)
+    avg, std = ctx.normalize(fr, W)
+    p = sfa.default_params()
+    p.S = S; p.layers = 5; p.niter_alter = 10; p.niter_outer = 10; p.occlusion_reasoning = 1; p.thres_outer = 1e-5; p.thres_inner = 1e-5
+    p.hbit = 0; p.smoothing = 1; p.rho[0] = 1; p.rho[1] = 1; p.omega[0] = 0; p.omega[1] = 2; p.occlusion_penalty = 0.1; p.occlusion_alpha = 0.1
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    for j, back in ((0, False), (0, True), (15, True), (16, False), (31, True), (47, False), (63, False), (63, True)):
+        f0 = j * steps
+        win = fr[f0:f0 + 2 * steps + 1] if not back else [fr[nframes - 1 - i] for i in range(nframes - 1 - f0 - 3 * steps, nframes - 1 - f0 - 3 * steps + 2 * steps + 1)]
+        wx, wy = np.zeros((H, stride), np.float32), np.zeros((H, stride), np.float32)
+        ctx.variational(p, wx, wy, win, W)
+        name = "f_%04d%s.flo" % ((100 + f0) if not back else (100 + f0 + steps), "_back" if back else "")
+        u, v = read_flo(str(out / name))
+        assert np.array_equal(u, wx[:, :W] * steps) and np.array_equal(v, wy[:, :W] * steps), name
+    ctx.close()
+    # the flow of the reference frame over `steps` frames: the synthetic sub-pixel motion, forward and (negated) backward
+    u, v = read_flo(str(out / "f_0100.flo"))
+    inner = (slice(20, H - 20), slice(20, W - 20))
+    assert np.abs(u[inner] - steps * fu[inner]).mean() < 0.05 and np.abs(v[inner] - steps * fv[inner]).mean() < 0.05
+    ub, vb = read_flo(str(out / "f_0102_back.flo"))
+    assert np.abs(ub[inner] + steps * fu[inner]).mean() < 0.05 and np.abs(vb[inner] + steps * fv[inner]).mean() < 0.05
+
+
+@pytest.mark.gpu
+def test_driver_adaptive_frame_rates_and_alternation_outputs(host_build, tmp_path):
+    """the rest of the driver surface (slow_flow.cpp:277-399, :878-884): with adaptiveFR.dat and <sequence>/quantil.dat the run is done twice,
+    at the high and the low frame rate, into high_fr/ and low_fr/ (`-fr k` selects one), reading every skip-th frame; with WRITE_FILES
+    verbosity the occlusion labels of every alternation are written as tmp/frame_<n>_<alter>.png, the last one being the final estimate."""
+    import json
+    import slowflow_amd as sfa
+    W, H, S, JETS = 96, 64, 2, 2
+    steps = S - 1
+    seqdir = tmp_path / "seq"
+    seqdir.mkdir()
+    # hfr_quantil 2 / quantil 1.0 -> hfr_rate 2; keyframes = 200 / 20 = 10 -> while 10 % 2: ok; lfr = min(10, 2 * 4) = 8 -> 8 does not divide 10 -> 10 -> min(10 / 1, 10)
+    frames, fu, fv = _write_sequence(str(seqdir), 1 + (JETS + 2) * steps * 10 + 10, 0, W, H, seed=1, amp=0.25)
+    (seqdir / "quantil.dat").write_text("1.0\n")
+    (tmp_path / "adaptiveFR.dat").write_text("opt_hfr_quantil\t2\nopt_lfr_quantil\t8\nopt_lfr_rate\t4\n")
+    cfg = tmp_path / "run.cfg"
+    cfg.write_text("file\t%s/f_%%04i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\nref_fps\t20\nadaptive\t1\nadaptive_fr_file\t%s/adaptiveFR.dat\n"
+                   "16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\ngpus\t1\nverbose\t00001\nslow_flow_S\t2\nslow_flow_layers\t2\nslow_flow_niter_alter\t3\n"
+                   "slow_flow_niter_outer\t3\nslow_flow_occlusion_reasoning\t1\nslow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\n"
+                   % (seqdir, tmp_path, JETS, tmp_path))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "hfr_rate 2" in r.stdout and "lfr_rate 10" in r.stdout, r.stdout + r.stderr
+    hi, lo = tmp_path / "out" / "high_fr", tmp_path / "out" / "low_fr"
+    assert "jet_fps\t100" in (hi / "config.cfg").read_text() and "jet_fps\t20" in (lo / "config.cfg").read_text()
+    for d, skip in ((hi, 2), (lo, 10)):
+        assert len(json.load(open(str(d / "timings.json")))) == 2 * JETS
+        u, v = read_flo(str(d / "f_0010.flo"))                                              # frames 10 -> 10 + skip
+        inner = (slice(12, H - 12), slice(12, W - 12))
+        assert np.abs(u[inner] - skip * fu[inner]).mean() < 0.1 * skip and np.abs(v[inner] - skip * fv[inner]).mean() < 0.1 * skip, (skip, np.abs(u[inner] - skip * fu[inner]).mean())
+        for a in (1, 2):
+            assert open(str(d / "tmp" / ("frame_10_%d.png" % a)), "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    # `-fr 1` alone redoes only the low frame rate
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite", "-fr", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("Reading") == 1 + (JETS + 2) * steps
+    # the last alternation's labels are the occlusion estimate that is written next to the flow
+    import zlib
+    png = open(str(hi / "tmp" / "frame_10_2.png"), "rb").read()
+    i, idat = 8, b""
+    while i < len(png):
+        n, t = struct.unpack(">I4s", png[i:i + 8])
+        if t == b"IDAT":
+            idat += png[i + 8:i + 8 + n]
+        i += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(H, W + 1)
+    assert np.all(rows[:, 0] == 0)
+    pgm = open(str(hi / "occlusion" / "frame_10.pgm"), "rb").read()
+    assert np.array_equal(rows[:, 1:], np.frombuffer(pgm[-W * H:], dtype=np.uint8).reshape(H, W))
+    assert set(np.unique(rows[:, 1:])) <= {0, 255}
