@@ -850,6 +850,12 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     static_assert(TY * 65 * 10 <= 12 * NM + 6 * N1, "operand tile must fit the staging block");
     static_assert(DT_W % 4 == 0 && AT_W1 % 4 == 0 && NM % 4 == 0 && N1 % 4 == 0, "16-byte LDS rows");
     const int b = blockIdx.z;
+    // reset the solver's progress words and ticket -- for EVERY window of the launch: the solver that follows runs all of them, also the
+    // passengers whose operands this launch leaves alone (Geo::active), and draws its tickets from window 0's block whoever is active
+    if (a.op.sa && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int i = threadIdx.x; i < a.op.ntasks; i += NT) a.op.flags[(size_t)b * a.op.ntasks + i] = 0;
+        if (b == 0 && threadIdx.x == 0) a.op.flags[(size_t)a.op.nb * a.op.ntasks] = 0;
+    }
     if (!elem_active(g.active, b)) return;
     const int x0 = blockIdx.x * DT_X - DT_H, y0 = blockIdx.y * TY - DT_H;       // origin of the halo-4 tile
     const long eb = b * g.es;
@@ -1026,10 +1032,6 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         tX[yl][tx] = make_float2(u[k], v[k]);
     }
     if (!a.op.sa) return;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {                        // reset the solver's progress words and ticket
-        for (int i = threadIdx.x; i < a.op.ntasks; i += NT) a.op.flags[(size_t)b * a.op.ntasks + i] = 0;
-        if (b == 0 && threadIdx.x == 0) a.op.flags[(size_t)a.op.nb * a.op.ntasks] = 0;
-    }
     __syncthreads();
     // the tile's anti-diagonals: TY consecutive entries of the diagonal-major operand planes each
     const int c0 = x0 + DT_H, r0 = y0 + DT_H;
