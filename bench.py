@@ -166,18 +166,47 @@ def hbm_triad_gbs(torch):
 
 
 def measured_traffic(batch):
-    """HBM-side bytes per SOR launch from the PMC passes of profiles/collect_traffic.sh (FETCH_SIZE x2 on gfx950 for wide
+    """HBM-side bytes per SOR launch from the PMC passes of profiles/collect.sh (FETCH_SIZE x2 on gfx950 for wide
     reads + WRITE_SIZE, separate passes; MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process,
-    so the committed measurement of the same command is reported, and only when it was taken at this batch size."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if int(t["batch"]) == int(batch):
-            return t["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, python bench.py --path-only)"
-    except (OSError, KeyError, ValueError):
-        pass
-    return None, None
+    so the committed measurement of the same command is reported, and only when it was taken at this batch size.
+    Returns (bytes per launch, source, valu_busy) -- valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (SIMDs x kernel cycles) of the SOR kernel
+    when the SQ pass of the same round is there (profiles/<tag>_sq.json), else None."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", tag + "_traffic.json")
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if int(t["batch"]) != int(batch):
+                continue
+            valu = None
+            try:
+                with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
+                    valu = json.load(f).get("valu_busy_frac")
+            except (OSError, ValueError):
+                pass
+            return t["traffic_bytes_per_launch"], "profiles/%s_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, python bench.py --path-only)" % tag, valu
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None
+
+
+def one_window_latency(ctx, reps=3):
+    """the whole path for ONE frame window on one stream, inputs resident: what a single pair (BASELINE config 2 is literally one) costs"""
+    p = bench_params()
+    win = synth_window(1)
+    avg, std = ctx.normalize(win, W)
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    job = sfa.Job(ctx, p, W, H, 1)
+    job.upload(0, win)
+    job.run(); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        job.run()
+    ctx.sync()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    job.close()
+    return ms
 
 
 def sor_only(ctx, B, rank):
@@ -371,7 +400,10 @@ def main():
         total = mpix_iters * args.steps * world
         value = total / elapsed_max
         achieved = sor_bytes / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(BL)
+        traffic, traffic_src, valu_busy = measured_traffic(BL)
+        avg_launch_s = sor_ms / max(n_sor, 1) * 1e-3
+        # what one launch must move at least: every operand entry read once (SA 16 B + SB 16 B + x 8 B), x written once (8 B)
+        compulsory = 48.0 * (sor_bytes / (44.0 * SWEEPS + 12.0)) / max(n_sor, 1)
         out = {
             "metric": "Mpix*solver-iters/s at 1024x436 (whole coarse-to-fine path)", "value": round(value, 1), "unit": "Mpix*solver-iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
@@ -380,11 +412,18 @@ def main():
                                    "symmetric window, modified-L1 penalties, thresholds off",
                        "frame_windows_per_gpu": B, "streams": S, "windows_per_launch": BL, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
                        "parallelism": f"frame-window data parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_sor_band<3,10,3,12,16> (batched lockstep solves; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_sor_band<3,10,4,12,16> (batched lockstep solves; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
                          "algorithmic_bytes_per_launch": round(sor_bytes / max(n_sor, 1)),
                          "traffic_source": traffic_src,
+                         # the physical picture beside the algorithmic one: counter bytes / launch time against the HBM peak, the bytes a launch cannot avoid,
+                         # and how busy the vector ALUs are (PMC of the same round) -- the kernel fuses K sweeps, so neither HBM nor VALU issue is its roof:
+                         # it is bound by the latency chain of the K-stage pipeline
+                         "hbm_physical": (round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_s > 0 else None),
+                         "compulsory_bytes_per_launch": round(compulsory),
+                         "traffic_over_compulsory": (round(traffic / compulsory, 2) if traffic and compulsory > 0 else None),
+                         "valu_issue_frac": valu_busy,
                          "note": "over the timed region (launches of all streams; with streams > 1 a launch shares the GPU with the other groups' kernels, so its duration is longer than alone): sum of (44*K+12)*w*h*batch ALGORITHMIC bytes of every SOR launch (all 5 levels) / sum of HIP-event durations; the kernel fuses all K sweeps of a 64-row band in one workgroup (x stays in registers/LDS), so its real HBM traffic is far below the algorithmic bytes and frac can exceed 1",
                          },
             "sor_share_of_step": round(sor_ms / S / (elapsed * 1e3), 4),
@@ -397,6 +436,10 @@ def main():
             out["roofline"]["sor_1024x436_single"] = {"batch": 1, "avg_launch_ms": round(ms2 / n2, 4), "achieved": round(by2 / (ms2 * 1e-3) / 1e9, 1),
                                                       "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                       "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}
+        try:
+            out["latency_one_window_ms"] = round(one_window_latency(ctx), 3)
+        except Exception as e:                                    # a reported extra
+            out["latency_one_window_ms"] = None
         try:
             out["roofline"]["measured_triad_gbs"] = round(hbm_triad_gbs(torch), 1)
         except Exception as e:                                    # a measurement aid only

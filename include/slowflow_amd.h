@@ -64,6 +64,10 @@ typedef struct sfa_params {
     float occlusion_penalty;    /* slow_flow_occlusion_penalty ("1.0"): cost of the label "occluded in the future" */
     float occlusion_alpha;      /* slow_flow_occlusion_alpha ("0.5"): Potts weight between 4-neighbours */
     int   niter_graphc;         /* slow_flow_niter_graphc ("10"): expansion iterations; a two-label cut is exact after one */
+    /* ADDITIVE key slow_flow_sor_order: 0 = "lexicographic" (default; the reference's raster order, results identical to sor_coupled), 1 = "red_black":
+     * a DIFFERENT ALGORITHM (two-colour sweeps of the same point update) that does not reproduce the reference -- after 30 sweeps its increment is 1e-2..1e-1
+     * away -- kept as a labelled low-latency mode for a single frame pair; every result produced with it is to be labelled as such */
+    int   sor_order;
 } sfa_params;
 
 /* variational_params_t (epic_flow_extended/variational.h:16-25), same layout */
@@ -119,6 +123,10 @@ int sfa_normalize(sfa_ctx *ctx, float *const *frames, int n_frames, int w, int h
 int sfa_sor_coupled(sfa_ctx *ctx, sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, sfa_image *a22,
                     sfa_image *b1, sfa_image *b2, sfa_image *dpsis_horiz, sfa_image *dpsis_vert,
                     int iterations, float omega);
+/* LABELLED MODE, not a replacement of anything in the reference: K red-black sweeps of the same per-point update on host planes (a11/a12/a22 are overwritten
+ * with the inverted blocks).  Bit-identical to the test checker's red-black restatement, NOT to sor_coupled. */
+int sfa_sor_red_black(sfa_ctx *ctx, sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, sfa_image *a22,
+                      sfa_image *b1, sfa_image *b2, sfa_image *dpsis_horiz, sfa_image *dpsis_vert, int iterations, float omega);
 /* the reference's own symbol and signature (solver.h:11); uses a process-wide default context on device 0 and
  * aborts with a message if no GPU is usable (the reference's error style, solver.c:75-78) */
 void sor_coupled(sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, sfa_image *a22, sfa_image *b1,

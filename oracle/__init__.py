@@ -68,7 +68,7 @@ class Params(C.Structure):
         ("rho", C.c_float * MAX_REF), ("omega", C.c_float * MAX_REF),
         ("hbit", C.c_int), ("norm_avg", C.c_float * 3), ("norm_std", C.c_float * 3),
         ("occlusion_reasoning", C.c_int), ("layers", C.c_int), ("p_scale", C.c_float), ("presmooth_sigma", C.c_float),
-        ("occlusion_penalty", C.c_float), ("occlusion_alpha", C.c_float), ("niter_graphc", C.c_int),
+        ("occlusion_penalty", C.c_float), ("occlusion_alpha", C.c_float), ("niter_graphc", C.c_int), ("sor_order", C.c_int),
     ]
 
 
@@ -181,9 +181,9 @@ class Oracle:
         return fn(fptr(a11), fptr(a12), fptr(a22), fptr(b1), fptr(b2), fptr(mask), fptr(du), fptr(dv), fptr(D), cw,
                   w, h, stride, C.c_float(hd), C.c_float(hg), C.c_float(s), int(dt_norm), C.byref(color), C.byref(grad))
 
-    def sor(self, du, dv, a11, a12, a22, b1, b2, sh, sv, w, iterations, omega, readable=False):
+    def sor(self, du, dv, a11, a12, a22, b1, b2, sh, sv, w, iterations, omega, readable=False, red_black=False):
         h, stride = du.shape
-        fn = self.lib.orc_sor_coupled_readable if readable else self.lib.orc_sor_coupled
+        fn = self.lib.orc_sor_red_black if red_black else (self.lib.orc_sor_coupled_readable if readable else self.lib.orc_sor_coupled)
         fn(fptr(du), fptr(dv), fptr(a11), fptr(a12), fptr(a22), fptr(b1), fptr(b2), fptr(sh), fptr(sv), w, h, stride, iterations, C.c_float(omega))
 
     def normalize(self, frames, w):

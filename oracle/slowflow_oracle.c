@@ -36,6 +36,7 @@ void orc_params_default(orc_params *p) {
     p->occlusion_reasoning = 1;
     p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;
     p->occlusion_penalty = 0.1f; p->occlusion_alpha = 0.1f; p->niter_graphc = 10;   /* slow_flow.cpp:117-118 */
+    p->sor_order = 0;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -680,6 +681,45 @@ void orc_sor_coupled(float *du, float *dv, float *a11, float *a12, float *a22, c
             }
 }
 
+/* RED-BLACK ordering of the same point update -- NOT the reference's algorithm (solver.c sweeps in raster order; SURVEY.md 0.1: after 30 sweeps a
+ * red-black result is 1e-2 .. 1e-1 away from it).  It restates the labelled throughput / latency mode `slow_flow_sor_order red_black` of the
+ * product so that the GPU kernels of that mode have a CPU twin: per sweep first every point with (x + y) even from the current values, then every
+ * point with (x + y) odd; per point the fast solver's operations in the fast solver's order (as orc_sor_coupled), the 2x2 blocks inverted first. */
+void orc_sor_red_black(float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
+                       const float *sh, const float *sv, int w, int h, int stride, int iterations, float omega) {
+    if (iterations < 1) return;
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            const size_t o = (size_t)j * stride + i;
+            const float hl = i > 0 ? sh[o - 1] : 0.0f, hp = sh[o];
+            float dpsis = hl + hp;
+            if (j > 0) dpsis = dpsis + sv[o - stride];
+            if (j < h - 1) dpsis = dpsis + sv[o];
+            const float A11 = a22[o] + dpsis, A22 = a11[o] + dpsis;
+            const float det = A11 * A22 - a12[o] * a12[o];
+            a11[o] = A11 / det;
+            a22[o] = A22 / det;
+            a12[o] = a12[o] / -det;
+        }
+    for (int iter = 0; iter < iterations; iter++)
+        for (int color = 0; color < 2; color++)
+            for (int j = 0; j < h; j++)
+                for (int i = (j + color) & 1; i < w; i += 2) {
+                    const size_t o = (size_t)j * stride + i;
+                    const float hl = i > 0 ? sh[o - 1] : 0.0f, hp = sh[o];
+                    const float dur = i < w - 1 ? du[o + 1] : 0.0f, dvr = i < w - 1 ? dv[o + 1] : 0.0f;
+                    float s1 = hp * dur, s2 = hp * dvr;
+                    if (j > 0) { s1 = s1 + sv[o - stride] * du[o - stride]; s2 = s2 + sv[o - stride] * dv[o - stride]; }
+                    if (j < h - 1) { s1 = s1 + sv[o] * du[o + stride]; s2 = s2 + sv[o] * dv[o + stride]; }
+                    s1 = s1 + b1[o];
+                    s2 = s2 + b2[o];
+                    float B1 = s1, B2 = s2;
+                    if (i > 0) { B1 = hl * du[o - 1] + s1; B2 = hl * dv[o - 1] + s2; }
+                    du[o] += omega * (a11[o] * B1 + a12[o] * B2 - du[o]);
+                    dv[o] += omega * (a12[o] * B1 + a22[o] * B2 - dv[o]);
+                }
+}
+
 /* ------------------------------------------------------------------------------------------
  * variational_mt.cpp:17-85 -- normalize
  * ---------------------------------------------------------------------------------------- */
@@ -987,7 +1027,8 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
                 if (rc) break;
                 orc_sub_laplacian(b1, uu, sh, sv, w, h, stride);                /* :364-365 */
                 orc_sub_laplacian(b2, vv, sh, sv, w, h, stride);
-                orc_sor_coupled(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, stride, p->niter_solver, p->sor_omega);   /* :368 */
+                if (p->sor_order == 1) orc_sor_red_black(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, stride, p->niter_solver, p->sor_omega);   /* labelled mode, not the reference */
+                else orc_sor_coupled(du, dv, a11, a12, a22, b1, b2, sh, sv, w, h, stride, p->niter_solver, p->sor_omega);   /* :368 */
 
                 /* :371-402: padding lanes of du,dv are zeroed; the L1 change norms are fp32 running sums
                  * in raster order, four lanes of a block added left to right first.  The oracle sums the

@@ -66,6 +66,7 @@ typedef struct {
     float occlusion_penalty;  /* slow_flow_occlusion_penalty */
     float occlusion_alpha;    /* slow_flow_occlusion_alpha */
     int   niter_graphc;       /* slow_flow_niter_graphc */
+    int   sor_order;          /* additive key slow_flow_sor_order: 0 lexicographic (the reference), 1 red_black (labelled mode, a different algorithm) */
 } orc_params;
 
 void orc_params_default(orc_params *p);
@@ -132,6 +133,9 @@ int orc_add_data_and_match_ref(float *a11, float *a12, float *a22, float *b1, fl
  * inverted 2x2 blocks) and solver.c:17-57 (readable) */
 void orc_sor_coupled(float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
                      const float *sh, const float *sv, int w, int h, int stride, int iterations, float omega);
+/* red-black ordering of the same point update: the CPU twin of the product's labelled `slow_flow_sor_order red_black` mode -- NOT the reference */
+void orc_sor_red_black(float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
+                       const float *sh, const float *sv, int w, int h, int stride, int iterations, float omega);
 void orc_sor_coupled_readable(float *du, float *dv, const float *a11, const float *a12, const float *a22,
                               const float *b1, const float *b2, const float *sh, const float *sv,
                               int w, int h, int stride, int iterations, float omega);

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslowflow_amd.so")
+LIB_PATH = os.environ.get("SFA_LIB") or os.path.join(_HERE, "libslowflow_amd.so")     # SFA_LIB: an experimental build of the same C-ABI (tuning only)
 MAX_REF = 4
 
 _f = C.POINTER(C.c_float)
@@ -46,7 +46,7 @@ class Params(C.Structure):
         ("rho", C.c_float * MAX_REF), ("omega", C.c_float * MAX_REF),
         ("hbit", C.c_int), ("norm_avg", C.c_float * 3), ("norm_std", C.c_float * 3),
         ("occlusion_reasoning", C.c_int), ("layers", C.c_int), ("p_scale", C.c_float), ("presmooth_sigma", C.c_float),
-        ("occlusion_penalty", C.c_float), ("occlusion_alpha", C.c_float), ("niter_graphc", C.c_int),
+        ("occlusion_penalty", C.c_float), ("occlusion_alpha", C.c_float), ("niter_graphc", C.c_int), ("sor_order", C.c_int),
     ]
 
 
@@ -63,7 +63,7 @@ class Params2f(C.Structure):
 
 EXPORTS = [
     "sfa_device_count", "sfa_ctx_create", "sfa_ctx_destroy", "sfa_last_error", "sfa_ctx_sync", "sfa_params_default",
-    "sfa_variational", "sfa_variational_2frame", "sfa_params_2frame_default", "variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sor_coupled",
+    "sfa_variational", "sfa_variational_2frame", "sfa_params_2frame_default", "variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sfa_sor_red_black", "sor_coupled",
     "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
     "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_resize_linear_fx", "sfa_gaussian_presmooth", "sfa_pyramid_sizes",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters",
@@ -209,11 +209,12 @@ class Context:
                                           C.byref(color), C.byref(grad))
         return rc
 
-    def sor_coupled(self, du, dv, a11, a12, a22, b1, b2, sh, sv, w, iterations, omega):
-        """drop-in for sor_coupled (solver.h:11) on host planes"""
+    def sor_coupled(self, du, dv, a11, a12, a22, b1, b2, sh, sv, w, iterations, omega, red_black=False):
+        """drop-in for sor_coupled (solver.h:11) on host planes; red_black=True: the labelled two-colour mode (a different algorithm)"""
         h, stride = du.shape
         imgs = [Image(w, h, stride, fptr(a)) for a in (du, dv, a11, a12, a22, b1, b2, sh, sv)]
-        self._ck(lib().sfa_sor_coupled(self.h, *[C.byref(i) for i in imgs], int(iterations), C.c_float(omega)), "sfa_sor_coupled")
+        fn, name = (lib().sfa_sor_red_black, "sfa_sor_red_black") if red_black else (lib().sfa_sor_coupled, "sfa_sor_coupled")
+        self._ck(fn(self.h, *[C.byref(i) for i in imgs], int(iterations), C.c_float(omega)), name)
 
     def gaussian_blur(self, src, w, sigma):
         h, stride = src.shape

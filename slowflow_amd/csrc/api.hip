@@ -231,7 +231,8 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             // Windows that already met a threshold stay in the lockstep launches as passengers: every kernel but the solver skips them
             // (Geo::active), the solver re-solves their stale operands into its own x plane, which nobody reads -- cheaper than leaving
             // the batched path for single solves (one window costs 0.87 ms alone, a batch of 32 costs 1.5 ms).
-            const bool direct_outer = L.fused && !getenv("SFA_NO_DIRECT_OPERANDS");
+            const bool red_black = p.sor_order == 1;           // labelled mode: works on the row-major planes, never on the diagonal-major operands
+            const bool direct_outer = L.fused && !red_black && !getenv("SFA_NO_DIRECT_OPERANDS");
             if (!direct_outer) launch_zero_planes(c, g, L.plane(P_DU), 2);                                   // :323-324 (du, dv adjacent)
             unsigned long long in_active = active, outer_done = 0;
             for (int inner = 0; inner < p.niter_inner; inner++) {
@@ -257,6 +258,9 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                                     L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV));   // :336-365
                 if (direct) {
                     SFA_TRY(sor_run_prepared(c, sorws, gi, nullptr, nullptr, p.niter_solver, p.sor_omega));             // :368
+                } else if (red_black) {
+                    SFA_TRY(sor_rb_run(c, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2),
+                                       L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega));
                 } else if (in_active == all) {
                     SFA_TRY(sor_run(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1),
                                     L.plane(P_B2), L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega, false));   // :368
@@ -458,6 +462,7 @@ void sfa_params_default(sfa_params *p) {           // slow_flow.cpp:64-128
     p->hbit = 1;
     for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
     p->occlusion_reasoning = 1; p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;
+    p->sor_order = 0;                                                                  // the reference's raster order
     p->occlusion_penalty = 0.1f; p->occlusion_alpha = 0.1f; p->niter_graphc = 10;     // slow_flow.cpp:117-118 (the class itself falls back to 1.0 / 0.5, variational_mt.cpp:189-190)
 }
 
@@ -781,6 +786,21 @@ int sfa_sor_coupled(sfa_ctx *ctx, sfa_image *du, sfa_image *dv, sfa_image *a11, 
     SFA_TRY(s.down(du->data, stride, 0)); SFA_TRY(s.down(dv->data, stride, 1));
     if (!(w < 2 || h < 2 || iterations < 1))                                          // the fast path inverts the blocks in place (solver.c:104-106)
         for (int i = 2; i < 5; i++) SFA_TRY(s.down(im[i]->data, stride, i));
+    return sfa_ctx_sync(ctx);
+}
+
+int sfa_sor_red_black(sfa_ctx *ctx, sfa_image *du, sfa_image *dv, sfa_image *a11, sfa_image *a12, sfa_image *a22, sfa_image *b1, sfa_image *b2,
+                      sfa_image *dpsis_horiz, sfa_image *dpsis_vert, int iterations, float omega) {
+    CHECK_ARGS(ctx && du && dv && a11 && a12 && a22 && b1 && b2 && dpsis_horiz && dpsis_vert, "null image");
+    const int w = du->width, h = du->height, stride = du->stride;
+    CHECK_ARGS(w > 0 && h > 0 && stride >= w, "bad image geometry");
+    sfa_image *im[9] = {du, dv, a11, a12, a22, b1, b2, dpsis_horiz, dpsis_vert};
+    for (auto *i : im) CHECK_ARGS(i->data && i->width == w && i->height == h && i->stride == stride, "images must share one geometry");
+    Staging s;
+    SFA_TRY(s.init(ctx, w, h, 9));
+    for (int i = 0; i < 9; i++) SFA_TRY(s.up(i, im[i]->data, stride));
+    SFA_TRY(sor_rb_run(ctx, s.geo(), s.plane(0), s.plane(1), s.plane(2), s.plane(3), s.plane(4), s.plane(5), s.plane(6), s.plane(7), s.plane(8), iterations, omega));
+    for (int i = 0; i < 5; i++) SFA_TRY(s.down(im[i]->data, stride, i));
     return sfa_ctx_sync(ctx);
 }
 

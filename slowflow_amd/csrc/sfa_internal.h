@@ -206,6 +206,9 @@ struct SorWorkspace {
 int sor_operand_target(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, SorOperandOut *out);
 // du == nullptr: leave the result in the workspace's x plane (read it with launch_update_inner_x)
 int sor_run_prepared(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, int K, float omega);
+// labelled mode slow_flow_sor_order red_black (a different algorithm; sor.hip): K two-colour sweeps on row-major planes, blocks inverted in place
+int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2, const float *sh,
+               const float *sv, int K, float omega);
 int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
             const float *sh, const float *sv, int K, float omega, bool inv_out);
 

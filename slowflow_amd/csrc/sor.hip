@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "sfa_internal.h"
+#include "sfa_device.h"
 
 #pragma clang fp contract(off)
 
@@ -64,6 +65,9 @@ __device__ __forceinline__ v2f sor_point(v2f self, v2f right, v2f top, v2f botto
     // written on the register pairs the loads deliver, with explicit broadcasts: the packed ops then select their halves
     // (op_sel) instead of copying scalars into fresh pairs -- 8 VALU instructions less per step of the band kernel
     const v2f SAxy = {SA.x, SA.y}, SAzw = {SA.z, SA.w}, SBxy = {SB.x, SB.y}, SBzw = {SB.z, SB.w};
+#ifdef SFA_X_NOARITH      // timing experiment only: one dependent operation instead of fourteen
+    return self + right * SAxy + top * SBxy + bottom * SAzw + left * hl;
+#endif
     v2f s = __builtin_shufflevector(SBzw, SBzw, 0, 0) * right;
     s = s + __builtin_shufflevector(SAzw, SAzw, 1, 1) * top;
     s = s + __builtin_shufflevector(SBzw, SBzw, 1, 1) * bottom;
@@ -105,6 +109,35 @@ __device__ __forceinline__ void st_x(unsigned long long *p, unsigned long long v
 }
 __device__ __forceinline__ unsigned ld_flag(const unsigned *p) {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Buffer addressing for the band kernel's streams: a wave-uniform descriptor per plane, the lane part of the address in one CONSTANT 32-bit
+// voffset and the per-step advance in the scalar soffset -- no per-step 64-bit vector address arithmetic (flat loads cost a v_lshl_add_u64 each).
+// Lanes that must not take part in an access get an out-of-range voffset: the range check drops their load (returns 0) or store, no exec mask.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr unsigned kOobOffset = 0xfffffff0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *base, unsigned long long bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    const unsigned n = __builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xffffff00ull ? 0xffffff00ull : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ unsigned long long bload8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+}
+__device__ __forceinline__ float2 bload8f(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ void bstore8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b) {
+    v2u v = {__float_as_uint(a), __float_as_uint(b)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
 // bounded relaxed poll of one progress word (wave-uniform); returns the value seen (>= target) or 0xffffffff on give-up
@@ -344,9 +377,18 @@ namespace sfa {
 // 3 the only stage (K == F).  The role is a template parameter so that the per-step code carries no role branches.
 // Two granularities: operands are refilled and the LDS hand-over to the next stage happens every CH steps; the
 // (slower) HBM hand-over to the band below -- progress words, lane-0 values -- every MC steps.
+//
+// Instruction diet of the step (the kernel is issue bound: PMC of round 2 showed ~195 instructions per wave-step, 42 of them the packed
+// arithmetic of the three point updates, and the slowest SIMD -- three waves -- busy issuing for the whole step):
+//   * all global streams go through buffer descriptors with a constant per-lane voffset and the step in the scalar soffset (no 64-bit
+//     vector address arithmetic); lanes that sit out get an out-of-range voffset instead of an exec mask;
+//   * lane 0's "lane -1" values (the band above's lane 63) reach the DPP shifts as their `old` operand straight from a broadcast LDS read
+//     (BC shapes) instead of one row-shift DPP per value and step;
+//   * the only lane-masked regions left in a step (lane 63's edge staging, the window's extra positions) sit behind the arithmetic and in
+//     front of plain LDS / memory instructions, so no hazard nops are needed between an exec write and the next step's DPP block.
 template <int F, int CH, int MC, int RING, int ROLE>
-__device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long (*ring)[RING][64], unsigned *lprog, unsigned char *win, unsigned long long (*estage)[MC], int job, int b,
-                                          int wave, int lane) {
+__device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long (*ring)[RING][64], unsigned *lprog, unsigned char *win, unsigned long long (*estage)[MC],
+                                          unsigned long long *tvbuf, int job, int b, int wave, int lane) {
     constexpr bool FIRST = ROLE == 0 || ROLE == 3, LASTW = ROLE == 2 || ROLE == 3;
     constexpr int NQ = MC / CH;
     const int k0 = wave * F;
@@ -355,19 +397,24 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     const int r0 = 64 * b - k0;
     const long FOFF = 2L * RP + 1;
     const long U0 = (long)(r0 + a.G) * RP + (r0 + a.G);
-    // wave-uniform byte bases (SGPR pairs); the per-step advance lives in ONE 32-bit lane offset per element size.
     // Only sweep f = 0 reads its operands from HBM.  Sweep f at step s works on what f = 0 worked on at step s - 2f, one
     // row up per sweep (FOFF): the wave keeps its last 2(F-1) operand rows in LDS and sweeps f >= 1 read them back at
-    // lane offset -f.  Rows r0-(F-1) .. r0-1 (positions 0 .. F-2 of a window row) come through a third, 8-lane load.
+    // lane offset -f.  Rows r0-(F-1) .. r0-1 (positions 0 .. F-2 of a window row) come through a second, (F-1)-lane load per plane.
     constexpr int NSLOT = F > 1 ? 2 * (F - 1) : 1, WP = 64 + F - 1;      // window rows (steps) / positions per row
-    const char *ba0 = reinterpret_cast<const char *>(a.sa + (size_t)job * a.ent + U0);
-    const char *bb0 = reinterpret_cast<const char *>(a.sb + (size_t)job * a.ent + U0);
+#ifdef SFA_X_NOLOAD       // timing experiment only: zero records, the range check drops every operand load
+    const __amdgpu_buffer_rsrc_t rA = plane_rsrc(a.sa + (size_t)job * a.ent, 0);
+    const __amdgpu_buffer_rsrc_t rB = plane_rsrc(a.sb + (size_t)job * a.ent, 0);
+#else
+    const __amdgpu_buffer_rsrc_t rA = plane_rsrc(a.sa + (size_t)job * a.ent, (unsigned long long)a.ent * 16);
+    const __amdgpu_buffer_rsrc_t rB = plane_rsrc(a.sb + (size_t)job * a.ent, (unsigned long long)a.ent * 16);
+#endif
+    const __amdgpu_buffer_rsrc_t rX = plane_rsrc(a.x + (size_t)job * a.ent, (unsigned long long)a.ent * 8);
     float4 *winA = reinterpret_cast<float4 *>(win), *winB = winA + NSLOT * WP;   // [NSLOT][WP] each
-    // extras: lanes [0, 2(F-1)) fetch 8 B each of SA's entries U0-(F-1) .. U0-1, lanes [2(F-1), 4(F-1)) the same of SB
-    const bool ex_lane = F > 1 && lane < 4 * (F - 1);
-    const bool ex_b = lane >= 2 * (F - 1);
-    const char *bex = (ex_b ? bb0 : ba0) - (F - 1) * 16 + (lane - (ex_b ? 2 * (F - 1) : 0)) * 8 - lane * 16;   // + vo16
-    float2 *wex = reinterpret_cast<float2 *>(ex_b ? winB : winA) + (lane - (ex_b ? 2 * (F - 1) : 0));         // + slot * WP * 2
+    const unsigned vA = lane * 16u, vX = lane * 8u;                 // constant lane parts of every stream
+    const bool ex_lane = F > 1 && lane < F - 1;                     // lanes that also fetch the extra positions (entries U0-(F-1) .. U0-1)
+    const unsigned vE = ex_lane ? lane * 16u : kOobOffset;
+    const unsigned st16 = RP * 16u, st8 = RP * 8u;
+    unsigned so16 = __builtin_amdgcn_readfirstlane((unsigned)(U0 * 16)), so8 = __builtin_amdgcn_readfirstlane((unsigned)(U0 * 8));   // + step * st{16,8}
     bool row_ok_last = false;
     float2 res[F], selfv[F];
     float hl[F];
@@ -377,32 +424,38 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
         // window rows of the steps before the start: columns < 0 (zero guards in HBM) except at the extra positions, whose
         // rows sit further up the diagonal (lane < 0: column s - lane can be >= 0 for s < 0)
         for (int i = lane; i < 2 * NSLOT * WP; i += 64) winA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ex_lane)
-            for (int t = 1; t <= NSLOT; t++)
-                wex[((NSLOT - t) & (NSLOT - 1)) * WP * 2] = *reinterpret_cast<const float2 *>(bex + ((long)lane * 16 - (long)t * RP * 16));
+        for (int t = 1; t <= NSLOT; t++) {
+            const float4 ea = bload16(rA, vE, so16 - (F - 1) * 16u - t * st16), eb = bload16(rB, vE, so16 - (F - 1) * 16u - t * st16);
+            if (ex_lane) { winA[((NSLOT - t) & (NSLOT - 1)) * WP + lane] = ea; winB[((NSLOT - t) & (NSLOT - 1)) * WP + lane] = eb; }
+        }
     }
     { const int r = r0 + lane - (F - 1); row_ok_last = r >= 0 && r < H; }
-    char *bx = reinterpret_cast<char *>(a.x + (size_t)job * a.ent + U0);
-    unsigned vo16 = lane * 16u, vo8 = lane * 8u;                  // + step * RP * {16, 8}
-    const unsigned st16 = RP * 16u, st8 = RP * 8u;
+    // final iterate (last stage): entry of (step s, sweep F-1) = U0 + s*RP - (F-1)*FOFF + lane; lanes outside the image are sent out of range
+    const unsigned so8_last = __builtin_amdgcn_readfirstlane((unsigned)((U0 - (long)(F - 1) * FOFF) * 8));
     unsigned long long *e_mine = a.edge + (size_t)job * a.edge_job + ((size_t)b * a.K + k0) * a.Wp + a.EP;
     const unsigned long long *e_up = a.edge + (size_t)job * a.edge_job + ((size_t)(b - 1) * a.K + k0) * a.Wp + a.EP;
     unsigned *gmine = a.gflags + ((size_t)job * a.NB + b) * a.NW + wave;
     const unsigned *g_up = a.gflags + ((size_t)job * a.NB + (b - 1)) * a.NW + wave;      // (b-1, w)
     const unsigned *g_up2 = g_up - 1;                                                    // (b-1, w-1)
+#ifdef SFA_X_NOBAND       // timing experiment only: bands do not wait for each other
+    const bool has_up = false, publishes = false;
+#else
     const bool has_up = b > 0, publishes = b + 1 < a.NB;
-    // lane t = fi*MC + j fetches lane 0's "lane -1" value of step j of the macro chunk: fi = 0: right of f = 0 (sweep
+#endif
+    // lane t = fi*TN + j fetches lane 0's "lane -1" value of step j of the chunk: fi = 0: right of f = 0 (sweep
     // k0-1, column s+1); fi = f+1: top of f (sweep k0+f, column s-f)
-    // ROT (all shapes with (F+1)*CH <= 16): the fetch covers one CH-step chunk, 12 lanes for the default shape, all within DPP row 0,
-    // so a row shift brings a step's value to lane 0 and the lane shift keeps it there -- no SGPR round trip (v_readlane + v_mov)
-    constexpr bool ROT = (F + 1) * CH <= 16;
-    constexpr int TN = ROT ? CH : MC;                            // steps covered by one fetch
+    // BC (all shapes with (F+1)*CH <= 16): the fetch covers one CH-step chunk; the fetched values are parked in LDS (tvbuf, two chunks) and every
+    // step reads its F+1 values back with wave-uniform (broadcast) addresses into the registers the DPP shifts then write into: lane 0
+    // keeps the broadcast value, lanes 1.. receive their neighbour's.  Other shapes: one fetch per macro chunk, v_readlane per value.
+    constexpr bool BC = (F + 1) * CH <= 16;
+    constexpr int TN = BC ? CH : MC;                             // steps covered by one fetch
     const int tfi = lane / TN, tj = lane % TN;
     const bool tv_lane = has_up && lane < (F + 1) * TN && (tfi > 0 || !FIRST);
     const long tv_off = tfi == 0 ? (long)(-1) * a.Wp + tj + 1 : (long)(tfi - 1) * a.Wp + tj - (tfi - 1);
+    if (BC && lane < (F + 1) * TN) tvbuf[lane] = 0ull;       // no band above: every "lane -1" value is a zero
 
     float4 sa0[CH], sb0[CH];
-    float2 ex[CH];
+    float4 exa[CH], exb[CH];
     unsigned long long xb[CH], xr[CH], tv = 0;
     unsigned known_up = 0, known_up2 = 0, pend_up = 0, pend_up2 = 0;
     auto need_up = [&](int m) { return (unsigned)min(m + 1 + (64 + MC - 1) / MC, NMC); };
@@ -427,17 +480,16 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     }
 #pragma unroll
     for (int j = 0; j < CH; j++) {
-        sa0[j] = *reinterpret_cast<const float4 *>(ba0 + (vo16 + j * st16));
-        sb0[j] = *reinterpret_cast<const float4 *>(bb0 + (vo16 + j * st16));
-        ex[j] = make_float2(0.f, 0.f);
-        if (ex_lane) ex[j] = *reinterpret_cast<const float2 *>(bex + (vo16 + j * st16));
+        sa0[j] = bload16(rA, vA, so16 + j * st16);
+        sb0[j] = bload16(rB, vA, so16 + j * st16);
+        if (F > 1) { exa[j] = bload16(rA, vE, so16 - (F - 1) * 16u + j * st16); exb[j] = bload16(rB, vE, so16 - (F - 1) * 16u + j * st16); }
     }
     if (FIRST) {
-        selfv[0] = u2f(*reinterpret_cast<const unsigned long long *>(bx + vo8));
+        selfv[0] = u2f(bload8(rX, vX, so8));
 #pragma unroll
         for (int j = 0; j < CH; j++) {
-            xr[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (j + 1) * st8));
-            xb[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (j + 1) * st8 + 8));
+            xr[j] = bload8(rX, vX, so8 + (j + 1) * st8);
+            xb[j] = bload8(rX, vX, so8 + (j + 1) * st8 + 8u);
         }
     } else if (has_up && lane == 0) selfv[0] = u2f(ld_x(e_up - a.Wp));                  // x^(k0-1)(0, r0): band above, lane 63
     if (tv_lane) tv = ld_x(e_up + tv_off);
@@ -455,11 +507,12 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
             pre = !last && ready(m + 1);
         }
         unsigned long long tv_cur = tv;
-        if (!ROT && pre && tv_lane) tv = ld_x(e_up + (s0 + MC) + tv_off);
+        if (!BC && pre && tv_lane) tv = ld_x(e_up + (s0 + MC) + tv_off);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            if (ROT) {                                           // this chunk's lane-0 values; fetch the next chunk's (the whole macro chunk is published)
-                tv_cur = tv;
+            unsigned long long *tvb = tvbuf;                              // one chunk's values: each chunk writes (in order, this wave only) before it reads
+            if (BC) {                                            // this chunk's lane-0 values into LDS; fetch the next chunk's (the whole macro chunk is published)
+                if (tv_lane) tvb[lane] = tv;
                 if ((q < NQ - 1 || pre) && tv_lane) tv = ld_x(e_up + (s0 + CH) + tv_off);
             }
             // the band above: look at its progress words as late as possible (one chunk before the next macro chunk decides on them)
@@ -486,21 +539,30 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                 const int s = s0 + j, jj = q * CH + j;
                 float2 sh[F], right0, bottom0;
                 bottom0 = u2f(xb[j]);
-                const int tvx = (int)(unsigned)(tv_cur & 0xffffffffu), tvy = (int)(unsigned)(tv_cur >> 32);
-                if (FIRST) right0 = u2f(xr[j]);
-                else if (ROT) {
-                    right0.x = lane_shr1_vec(bottom0.x, lane0_from(tvx, j));
-                    right0.y = lane_shr1_vec(bottom0.y, lane0_from(tvy, j));
-                } else {
-                    right0.x = lane_shr1(bottom0.x, __int_as_float(__builtin_amdgcn_readlane(tvx, jj)));
-                    right0.y = lane_shr1(bottom0.y, __int_as_float(__builtin_amdgcn_readlane(tvy, jj)));
-                }
+                if (BC) {
+                    // lane 0's neighbours: one broadcast read per value (the same address in every lane); the shifts write into these registers
+                    float2 fl[F + 1];
 #pragma unroll
-                for (int f = 0; f < F; f++) {
-                    if (ROT) {
-                        sh[f].x = lane_shr1_vec(res[f].x, lane0_from(tvx, (f + 1) * CH + j));
-                        sh[f].y = lane_shr1_vec(res[f].y, lane0_from(tvy, (f + 1) * CH + j));
-                    } else {
+                    for (int fi = FIRST ? 1 : 0; fi <= F; fi++) fl[fi] = u2f(tvb[fi * TN + j]);
+                    if (FIRST) right0 = u2f(xr[j]);
+                    else {
+                        right0.x = lane_shr1(bottom0.x, fl[0].x);
+                        right0.y = lane_shr1(bottom0.y, fl[0].y);
+                    }
+#pragma unroll
+                    for (int f = 0; f < F; f++) {
+                        sh[f].x = lane_shr1(res[f].x, fl[f + 1].x);
+                        sh[f].y = lane_shr1(res[f].y, fl[f + 1].y);
+                    }
+                } else {
+                    const int tvx = (int)(unsigned)(tv_cur & 0xffffffffu), tvy = (int)(unsigned)(tv_cur >> 32);
+                    if (FIRST) right0 = u2f(xr[j]);
+                    else {
+                        right0.x = lane_shr1(bottom0.x, __int_as_float(__builtin_amdgcn_readlane(tvx, jj)));
+                        right0.y = lane_shr1(bottom0.y, __int_as_float(__builtin_amdgcn_readlane(tvy, jj)));
+                    }
+#pragma unroll
+                    for (int f = 0; f < F; f++) {
                         sh[f].x = lane_shr1(res[f].x, __int_as_float(__builtin_amdgcn_readlane(tvx, (f + 1) * MC + jj)));
                         sh[f].y = lane_shr1(res[f].y, __int_as_float(__builtin_amdgcn_readlane(tvy, (f + 1) * MC + jj)));
                     }
@@ -511,8 +573,12 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
 #pragma unroll
                 for (int f = 1; f < F; f++) {
                     const int slot = (jj - 2 * f + 4 * NSLOT) & (NSLOT - 1);
+#ifdef SFA_X_NOWIN        // timing experiment only
+                    oa[f] = sa0[j]; ob[f] = sb0[j]; (void)slot;
+#else
                     oa[f] = winA[slot * WP + lane + (F - 1 - f)];
                     ob[f] = winB[slot * WP + lane + (F - 1 - f)];
+#endif
                 }
                 float2 nres[F];
 #pragma unroll
@@ -521,34 +587,40 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                     const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
                     const v2f xn = sor_point(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hl[f], oa[f], ob[f], omega);
                     nres[f] = make_float2(xn.x, xn.y);
-                    // lane 63's iterate of every sweep is band b+1's lane-0 input (zeros outside the image land in the row pads)
-                    if (publishes && lane == 63) estage[f][jj] = f2u(xn.x, xn.y);      // staged in LDS, stored once per macro chunk
-                    if (f == F - 1 && !LASTW) ring[wave][s & (RING - 1)][lane] = f2u(xn.x, xn.y);
                     hl[f] = ob[f].z;
                     selfv[f] = right;
                 }
 #pragma unroll
                 for (int f = 0; f < F; f++) res[f] = nres[f];
+                // ---- the step's lane-masked work, behind the arithmetic and in front of the plain LDS / memory instructions -------------------
+                // lane 63's iterate of every sweep is band b+1's lane-0 input (zeros outside the image land in the row pads): staged in LDS,
+                // stored once per macro chunk
+                if (publishes && lane == 63) {
+#pragma unroll
+                    for (int f = 0; f < F; f++) estage[f][jj] = f2u(res[f].x, res[f].y);
+                }
+#ifndef SFA_X_NOWIN
                 if (F > 1) {                                      // this step's operands become window row s
                     const int slot = jj & (NSLOT - 1);
+                    if (ex_lane) { winA[slot * WP + lane] = exa[j]; winB[slot * WP + lane] = exb[j]; }
                     winA[slot * WP + lane + (F - 1)] = sa0[j];
                     winB[slot * WP + lane + (F - 1)] = sb0[j];
-                    if (ex_lane) wex[slot * WP * 2] = ex[j];
                 }
+#endif
+                if (!LASTW) ring[wave][s & (RING - 1)][lane] = f2u(res[F - 1].x, res[F - 1].y);
                 // refill slot j for step s + CH (beyond the last step this reads zero guards)
-                sa0[j] = *reinterpret_cast<const float4 *>(ba0 + (vo16 + CH * st16));
-                sb0[j] = *reinterpret_cast<const float4 *>(bb0 + (vo16 + CH * st16));
-                if (ex_lane) ex[j] = *reinterpret_cast<const float2 *>(bex + (vo16 + CH * st16));
+                sa0[j] = bload16(rA, vA, so16 + CH * st16);
+                sb0[j] = bload16(rB, vA, so16 + CH * st16);
+                if (F > 1) { exa[j] = bload16(rA, vE, so16 - (F - 1) * 16u + CH * st16); exb[j] = bload16(rB, vE, so16 - (F - 1) * 16u + CH * st16); }
                 if (FIRST) {
-                    xr[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8));
-                    xb[j] = *reinterpret_cast<const unsigned long long *>(bx + (vo8 + (CH + 1) * st8 + 8));
+                    xr[j] = bload8(rX, vX, so8 + (CH + 1) * st8);
+                    xb[j] = bload8(rX, vX, so8 + (CH + 1) * st8 + 8u);
                 }
                 // the final iterate leaves behind this step's refills: vmcnt retires in order, so a store queued ahead of the operand
                 // loads would have to be acknowledged before they count as arrived (one step of prefetch depth lost to the write latency)
-                if (LASTW && row_ok_last && (unsigned)(s - lane - (F - 1)) < (unsigned)W)
-                    *reinterpret_cast<unsigned long long *>(bx - (long)(F - 1) * FOFF * 8 + vo8) = f2u(res[F - 1].x, res[F - 1].y);
-                vo16 += st16;
-                vo8 += st8;
+                if (LASTW) bstore8(rX, (row_ok_last && (unsigned)(s - lane - (F - 1)) < (unsigned)W) ? vX : kOobOffset, so8_last + (unsigned)s * st8, res[F - 1].x, res[F - 1].y);
+                so16 += st16;
+                so8 += st8;
             }
             s0 += CH;
             // tell wave+1 / wave-1 (LDS words are written in order behind the ring writes)
@@ -556,6 +628,8 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
             // band b+1 (HBM): the previous macro chunk's edge store is older than the CH * 2 operand loads issued since (in-order
             // vmcnt), so this counted wait covers it without draining the prefetch; its progress word goes out now, CH steps late
             if (q == 0 && publishes && m > 0) {
+                // INVARIANT (checked by tools/check_publish_vmcnt.py on the ISA): at least SFA_PUBLISH_MIN VMEM instructions are issued between the
+                // edge store of the previous macro chunk and this wait in every role of every shape
                 if (CH >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(gmine, (unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -597,6 +671,8 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     constexpr int WINB = F > 1 ? 2 * (F - 1) * (64 + F - 1) * 32 : 0;                                // operand window per wave (bytes)
     unsigned char *win0 = smem + (size_t)(NW - 1) * RING * 64 * 8 + 256;                             // 16-byte aligned behind the progress words
     unsigned long long(*est0)[MC] = reinterpret_cast<unsigned long long(*)[MC]>(win0 + (size_t)NW * WINB);   // [NW][F][MC] edge staging
+    constexpr int TVB = (F + 1) * CH <= 16 ? (F + 1) * CH : 0;                                        // lane-0 values of one chunk per wave (BC shapes)
+    unsigned long long *tvb0 = reinterpret_cast<unsigned long long *>(est0 + (size_t)NW * F);         // [NW][TVB]
     unsigned &s_ticket = lprog[NW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -606,10 +682,10 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;                     // band-major tickets
-    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, job, b, wave, lane);
-    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, job, b, wave, lane);
-    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, job, b, wave, lane);
-    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, job, b, wave, lane);
+    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane);
+    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane);
+    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane);
+    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -711,6 +787,72 @@ __global__ void k_sor_readable(float *du_, float *dv_, const float *a11_, const 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// LABELLED MODE `slow_flow_sor_order red_black` -- a DIFFERENT ALGORITHM, never the default and never presented as matching the
+// reference: per sweep all points with (x + y) even are updated from the current values, then all points with (x + y) odd.  The point
+// update is the fast solver's (solver.c:183-196), operation for operation, so the kernels have an exact CPU twin among the test checkers;
+// the ORDER differs from solver.c, and with it the result (1e-2 .. 1e-1 after 30 sweeps).  What it buys: every point of a
+// colour is independent, so one frame pair is not bound by the W + H + 2K step critical path of the raster order.
+// Row-major planes as the stage API has them; one launch per colour pass.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rb_invert(float *__restrict__ a11, float *__restrict__ a12, float *__restrict__ a22, const float *__restrict__ sh,
+                                                   const float *__restrict__ sv, Geo g) {
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= g.w || y >= g.h) return;
+    const size_t o = b * g.es + (size_t)y * g.pitch + x;
+    const float hp = sh[o], hl = x > 0 ? sh[o - 1] : 0.0f;
+    float dpsis = hl + hp;                                                               // solver.c:101,159,214
+    if (y > 0) dpsis = dpsis + sv[o - g.pitch];
+    if (y < g.h - 1) dpsis = dpsis + sv[o];
+    const float m12 = a12[o];
+    const float A11 = a22[o] + dpsis, A22 = a11[o] + dpsis;                               // solver.c:102
+    const float det = A11 * A22 - m12 * m12;
+    a11[o] = __fdiv_rn(A11, det); a22[o] = __fdiv_rn(A22, det); a12[o] = __fdiv_rn(m12, -det);   // solver.c:104-106
+}
+__global__ void __launch_bounds__(256) k_rb_pass(float *__restrict__ du, float *__restrict__ dv, const float *__restrict__ i11, const float *__restrict__ i12,
+                                                 const float *__restrict__ i22, const float *__restrict__ b1, const float *__restrict__ b2,
+                                                 const float *__restrict__ sh, const float *__restrict__ sv, Geo g, int color, float omega) {
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int x = 2 * (blockIdx.x * 64 + threadIdx.x) + ((y + color) & 1);
+    if (x >= g.w || y >= g.h) return;
+    const size_t o = b * g.es + (size_t)y * g.pitch + x;
+    const float hp = sh[o], hl = x > 0 ? sh[o - 1] : 0.0f;
+    const float dur = x < g.w - 1 ? du[o + 1] : 0.0f, dvr = x < g.w - 1 ? dv[o + 1] : 0.0f;
+    float s1 = hp * dur, s2 = hp * dvr;                                                   // solver.c:108,166,221
+    if (y > 0) { const float vt = sv[o - g.pitch]; s1 = s1 + vt * du[o - g.pitch]; s2 = s2 + vt * dv[o - g.pitch]; }
+    if (y < g.h - 1) { const float vp = sv[o]; s1 = s1 + vp * du[o + g.pitch]; s2 = s2 + vp * dv[o + g.pitch]; }
+    s1 = s1 + b1[o];
+    s2 = s2 + b2[o];
+    float B1 = s1, B2 = s2;
+    if (x > 0) { B1 = hl * du[o - 1] + s1; B2 = hl * dv[o - 1] + s2; }                   // solver.c:113-114
+    const float u = du[o], v = dv[o];
+    du[o] = u + omega * (i11[o] * B1 + i12[o] * B2 - u);                                  // solver.c:115-116
+    dv[o] = v + omega * (i12[o] * B1 + i22[o] * B2 - v);
+}
+int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2, const float *sh,
+               const float *sv, int K, float omega) {
+    if (K < 1) return SFA_OK;
+    const dim3 blk(64, 4);
+    hipLaunchKernelGGL(k_rb_invert, dim3((g.w + 63) / 64, (g.h + 3) / 4, g.nb), blk, 0, c->stream, a11, a12, a22, sh, sv, g);
+    const dim3 grid((g.w + 127) / 128, (g.h + 3) / 4, g.nb);
+    const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
+    if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+    for (int k = 0; k < K; k++)
+        for (int color = 0; color < 2; color++)
+            hipLaunchKernelGGL(k_rb_pass, grid, blk, 0, c->stream, du, dv, a11, a12, a22, b1, b2, sh, sv, g, color, omega);
+    if (prof) {
+        (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
+        c->ev_used += 2;
+        c->sor_bytes += (44.0 * K + 12.0) * (double)g.w * g.h * g.nb;
+    }
+    SFA_HIP(c, hipGetLastError());
+    return SFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 // band kernel (all K sweeps of a band in one workgroup): F fused sweeps per wave, NW = K/F waves; 0 = not applicable
@@ -732,7 +874,10 @@ static int band_shape(int K, int nb) {
 // of prefetch hide the Infinity-Cache latency of the first-touch operand rows under load (2 -> 3: -6 .. -10 % solve time);
 // for the default F = 3 only: (F + 1) * MC lanes fetch the band above's values (F = 5: MC <= 10), and the 15 / 16-wave shapes of
 // F = 2 / 1 have 128 registers per lane, which the deeper ring does not fit.
-constexpr int band_ch(int F) { return F == 3 ? 3 : F == 5 ? 4 : 2; }
+#ifndef SFA_BAND_CH3
+#define SFA_BAND_CH3 4
+#endif
+constexpr int band_ch(int F) { return F == 3 ? SFA_BAND_CH3 : F == 5 ? 4 : 2; }
 constexpr int band_mc(int F) { return F == 3 ? 12 : 8; }
 static int band_ring(int F) { return F == 2 ? 8 : 16; }      // LDS ring slots per wave pair, power of two
 static size_t band_window(int F) { return F > 1 ? (size_t)2 * (F - 1) * (64 + F - 1) * 32 : 0; }   // operand window bytes per wave
@@ -841,7 +986,8 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(band_ch(ws.F) + 2, std::min(atoi(e), band_ring(ws.F)));
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
-        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F) + (size_t)ws.NG * ws.F * band_mc(ws.F) * 8;
+        const size_t tvb = (ws.F + 1) * band_ch(ws.F) <= 16 ? (size_t)(ws.F + 1) * band_ch(ws.F) * 8 : 0;            // lane-0 values, one chunk per wave
+        const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F) + (size_t)ws.NG * ws.F * band_mc(ws.F) * 8 + ws.NG * tvb;
         if (ws.F == 5)      hipLaunchKernelGGL((k_sor_band<5, 6, band_ch(5), band_mc(5), 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 3) hipLaunchKernelGGL((k_sor_band<3, 10, band_ch(3), band_mc(3), 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, band_ch(2), band_mc(2), 8>), bgrid, bblock, lds, c->stream, ba);

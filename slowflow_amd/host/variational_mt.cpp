@@ -57,6 +57,8 @@ sfa_params sfa_params_from_cfg(ParameterList &params, bool one_direction) {
     p.occlusion_penalty = params.parameter<float>("slow_flow_occlusion_penalty", "1.0");
     p.occlusion_alpha = params.parameter<float>("slow_flow_occlusion_alpha", "0.5");
     p.niter_graphc = params.parameter<int>("slow_flow_niter_graphc", "10");
+    // additive key: "red_black" selects the labelled two-colour mode (a different algorithm: does not reproduce the reference); anything else the reference order
+    p.sor_order = (params.exists("slow_flow_sor_order") && params.parameter("slow_flow_sor_order") == "red_black") ? 1 : 0;
     p.layers = params.parameter<int>("slow_flow_layers");
     p.p_scale = params.parameter<float>("slow_flow_p_scale");
     p.presmooth_sigma = params.parameter<float>("sigma", "0") > 0 ? params.parameter<float>("slow_flow_sigma") : 0.0f;   // :590-591

@@ -922,3 +922,50 @@ def test_smoothness_full_size_exact(ctx, oracle):
         b = ctx.smoothness(1, c_(uu), c_(vv), c_(dps), w, 4.0, sfa.Penalty(1, 0.001, 0.5))
         for x, y in zip(a, b):
             assert np.array_equal(valid(x, w), valid(y, w))
+
+
+# ------------------------------------------------------------------------------------------------------
+# LABELLED MODE slow_flow_sor_order red_black: a different algorithm (never the default); parity is stated against its own CPU twin,
+# the deviation from the reference order is measured and reported, not hidden
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (130, 98), (2, 2), (1024, 436)])
+@pytest.mark.parametrize("K", [1, 30])
+def test_red_black_solver_against_its_cpu_twin(ctx, oracle, w, h, K):
+    rng = np.random.default_rng(w + h + K)
+    s0 = sor_system(rng, w, h)
+    s0["du"][:, :w] = rng.uniform(-.2, .2, (h, w)); s0["dv"][:, :w] = rng.uniform(-.2, .2, (h, w))
+    a = copy_sys(s0)
+    oracle.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, K, 1.9, red_black=True)
+    b = {k: c_(v).copy() for k, v in s0.items()}
+    ctx.sor_coupled(b["du"], b["dv"], b["a11"], b["a12"], b["a22"], b["b1"], b["b2"], b["sh"], b["sv"], w, K, 1.9, red_black=True)
+    for k in ("du", "dv", "a11", "a12", "a22"):
+        assert np.array_equal(valid(a[k], w), valid(b[k], w)), k
+
+
+def test_red_black_mode_is_labelled_and_deviates(ctx, oracle):
+    """the whole path with sor_order = 1: GPU == the oracle run in the same mode (<= 1e-4), and BOTH are measurably away from the reference order --
+    the number that every results line of this mode carries"""
+    w, h = 130, 98
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=5)
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=3, layers=3)
+    lex_o, lex_g = run_both(ctx, oracle, po, ps, frames, w, h, level_only=False)
+    po.sor_order = 1; ps.sor_order = 1
+    rb_o, rb_g = run_both(ctx, oracle, po, ps, frames, w, h, level_only=False)
+    d_twin = max(np.abs(valid(rb_o[0], w) - valid(rb_g[0], w)).max(), np.abs(valid(rb_o[1], w) - valid(rb_g[1], w)).max())
+    d_ref = max(np.abs(valid(lex_g[0], w) - valid(rb_g[0], w)).max(), np.abs(valid(lex_g[1], w) - valid(rb_g[1], w)).max())
+    assert d_twin <= TOL_UV, d_twin
+    assert d_ref > TOL_UV, d_ref                                   # it does NOT meet the reference's 1e-4: a different algorithm
+    assert abs(np.median(valid(rb_g[0], w)) - 2.0) < 0.2           # still a flow estimate of the same motion
+    # batches and thresholds go through the same mode
+    ps.thres_outer = 1e-3
+    job = sfa.Job(ctx, ps, w, h, 3)
+    for b in range(3):
+        job.upload(b, [c_(f) for f in frames])
+    job.run()
+    one = sfa.Job(ctx, ps, w, h, 1)
+    one.upload(0, [c_(f) for f in frames]); one.run()
+    ref = one.download(0)
+    for b in range(3):
+        got = job.download(b)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    job.close(); one.close()
