@@ -191,23 +191,35 @@ def measured_traffic(batch):
 
 
 def one_window_latency(ctx, reps=3):
-    """the whole path for ONE frame window on one stream, inputs resident: what a single pair (BASELINE config 2 is literally one) costs"""
-    p = bench_params()
+    """the whole path for ONE frame window on one stream, inputs resident: what a single pair (BASELINE config 2 is literally one) costs.
+    Returns (ms in the reference order, dict for the labelled red-black mode: its latency and how far its flow is from the reference order's)."""
     win = synth_window(1)
     avg, std = ctx.normalize(win, W)
-    for k in range(3):
-        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
-    job = sfa.Job(ctx, p, W, H, 1)
-    job.upload(0, win)
-    job.run(); ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        job.run()
-    ctx.sync()
-    ms = (time.perf_counter() - t0) / reps * 1e3
-    job.close()
-    return ms
-
+    out = []
+    for order in (0, 1):
+        p = bench_params()
+        p.sor_order = order
+        for k in range(3):
+            p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+        job = sfa.Job(ctx, p, W, H, 1)
+        job.upload(0, win)
+        job.run(); ctx.sync()
+        ctx.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            job.run()
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        n, sor_ms, _ = ctx.profile_read()
+        ctx.profile_enable(False)
+        wx, wy, _ = job.download(0)
+        job.close()
+        out.append((ms, sor_ms / max(n, 1), wx[:, :W], wy[:, :W]))
+    dev = float(max(np.abs(out[0][2] - out[1][2]).max(), np.abs(out[0][3] - out[1][3]).max()))
+    rb = {"label": "slow_flow_sor_order red_black: a DIFFERENT ALGORITHM (two-colour sweeps), never the default; does not reproduce the reference",
+          "latency_one_window_ms": round(out[1][0], 3), "sor_ms_per_solve_avg_over_levels": round(out[1][1], 4),
+          "max_abs_flow_deviation_from_reference_order_px": round(dev, 5), "meets_1e-4_parity": bool(dev <= 1e-4)}
+    return out[0][0], out[0][1], rb
 
 def sor_only(ctx, B, rank):
     from synth import sor_system
@@ -299,7 +311,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frame windows per GPU solved in lockstep (fwd/bwd of several jets)")
+    ap.add_argument("--batch", type=int, default=128, help="frame windows per GPU (fwd/bwd of several jets), refined as --streams lockstep groups")
     ap.add_argument("--streams", type=int, default=2, help="the batch is refined as this many lockstep groups on separate HIP streams, one host thread each "
                     "(the reference drives its windows from OpenMP threads, slow_flow.cpp:706): the groups fill each other's ramp-up / drain phases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -437,7 +449,10 @@ def main():
                                                       "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                       "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}
         try:
-            out["latency_one_window_ms"] = round(one_window_latency(ctx), 3)
+            lat, sor1, rb = one_window_latency(ctx)
+            out["latency_one_window_ms"] = round(lat, 3)
+            out["latency_one_window_sor_ms_per_solve"] = round(sor1, 4)
+            out["labelled_modes"] = {"red_black": rb}
         except Exception as e:                                    # a reported extra
             out["latency_one_window_ms"] = None
         try:

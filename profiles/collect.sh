@@ -1,14 +1,16 @@
 #!/bin/bash
 # Profiles of the bench command, run on the GPU box (gpurun) from the repo root:
-#   bash profiles/collect.sh r01        -> gpurun_out/<tag>_{stats,fetch,write}/...
-# pass 1: kernel trace + stats; pass 2/3: HBM-side PMC counters, each in its own run (MI355X_MICROARCH.md:
-# FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2; --pmc is never combined with the trace domains).
+#   bash profiles/collect.sh r02 [batch]        -> gpurun_out/<tag>_{stats,fetch,write,sq1,sq2}/...
+# pass 1: kernel trace + stats; passes 2/3: HBM-side PMC counters; passes 4/5: SQ counters (VALU / LDS activity, instruction mix) -- every --pmc pass in its
+# own run with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2; --pmc is never combined with the trace domains).
 # Afterwards, in the container:  python profiles/summarize.py <tag> <windows per launch = batch / streams>   (writes profiles/<tag>_*.{csv,json})
 set -e
-TAG=${1:-r01}
-BATCH=${2:-64}
+TAG=${1:-r02}
+BATCH=${2:-128}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats -o bench -f csv -- python3 bench.py --batch $BATCH --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_stats.json 2> gpurun_out/${TAG}_stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_fetch.json 2> gpurun_out/${TAG}_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${TAG}_write -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_write.json 2> gpurun_out/${TAG}_write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d gpurun_out/${TAG}_sq1 -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_sq1.json 2> gpurun_out/${TAG}_sq1.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d gpurun_out/${TAG}_sq2 -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_sq2.json 2> gpurun_out/${TAG}_sq2.err
 echo done

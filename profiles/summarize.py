@@ -66,6 +66,39 @@ if sor:
     res["traffic_bytes_per_launch"] = res["kernels"][sor[0]]["traffic_bytes_per_launch"]
     res["kernel"] = sor[0]
 json.dump(res, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
+# SQ passes (when collected): per kernel the share of SIMD time with a VALU instruction active, the LDS bank-conflict share and the instruction mix
+try:
+    sq = {}
+    for d in (f"{tag}_sq1", f"{tag}_sq2"):
+        for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+            k = r["Kernel_Name"].split("(")[0]
+            sq.setdefault(k, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT",
+             "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "GRBM_GUI_ACTIVE"]
+    sqj = {"note": "means per dispatch; SQ_*_CYCLES / ACTIVE / WAIT counters are in quad-cycles summed over waves (MI355X_MICROARCH.md); valu_active = 4 * SQ_ACTIVE_INST_VALU / "
+                   "(1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE", "kernels": {}}
+    with open(os.path.join(out, f"{tag}_sq_by_kernel.csv"), "w") as f:
+        f.write("kernel,dispatches," + ",".join(names) + ",valu_active_frac,lds_conflict_frac,wave_active_frac,wave_wait_frac\n")
+        for k, v in sorted(sq.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
+            if "sfa::" not in k:
+                continue
+            m = {n: (sum(v[n]) / len(v[n]) if v.get(n) else 0.0) for n in names}
+            cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+            valu = 4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * cyc) if cyc else 0.0
+            conf = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"] if m["SQ_LDS_IDX_ACTIVE"] else 0.0
+            act = m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else 0.0
+            wait = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else 0.0
+            n = len(v.get("SQ_WAVE_CYCLES", v.get("SQ_WAVES", [])))
+            f.write('"%s",%d,' % (k, n) + ",".join("%.0f" % m[x] for x in names) + ",%.4f,%.4f,%.4f,%.4f\n" % (valu, conf, act, wait))
+            sqj["kernels"][k] = {"valu_active_frac": round(valu, 4), "lds_conflict_frac": round(conf, 4), "wave_active_frac": round(act, 4), "wave_wait_frac": round(wait, 4)}
+    sor_k = [k for k in sqj["kernels"] if "k_sor_band" in k]
+    if sor_k:
+        sqj["valu_busy_frac"] = sqj["kernels"][sor_k[0]]["valu_active_frac"]
+        sqj["kernel"] = sor_k[0]
+    json.dump(sqj, open(os.path.join(out, f"{tag}_sq.json"), "w"), indent=1)
+    print("SQ:", {k[-40:]: v for k, v in list(sqj["kernels"].items())[:4]})
+except FileNotFoundError:
+    print("no SQ passes under gpurun_out/ for", tag)
 print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
 for k, v in res["kernels"].items():
     print(f"{k[:60]:60s} n={v['dispatches']:5d} fetch(x2) {v['fetch_bytes_per_launch_x2'] / 1e6:10.1f} MB  write {v['write_bytes_per_launch'] / 1e6:10.1f} MB")

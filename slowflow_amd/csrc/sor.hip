@@ -878,7 +878,10 @@ static int band_shape(int K, int nb) {
 #define SFA_BAND_CH3 4
 #endif
 constexpr int band_ch(int F) { return F == 3 ? SFA_BAND_CH3 : F == 5 ? 4 : 2; }
-constexpr int band_mc(int F) { return F == 3 ? 12 : 8; }
+#ifndef SFA_BAND_MC3
+#define SFA_BAND_MC3 12
+#endif
+constexpr int band_mc(int F) { return F == 3 ? SFA_BAND_MC3 : 8; }
 static int band_ring(int F) { return F == 2 ? 8 : 16; }      // LDS ring slots per wave pair, power of two
 static size_t band_window(int F) { return F > 1 ? (size_t)2 * (F - 1) * (64 + F - 1) * 32 : 0; }   // operand window bytes per wave
 

@@ -188,6 +188,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         pool.wait_all();
     }
     if (!load_error.empty()) { std::cerr << load_error << std::endl; return 3; }
+    const double decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (preprocess && scale != 1) {                                                  // blur + resize against aliasing (:550-553), on the GPU
         sfa_ctx *ingest_ctx = nullptr;
         if (sfa_ctx_create(params.parameter<int>("gpu_device", "0"), &ingest_ctx) != SFA_OK) { std::cerr << sfa_last_error(nullptr) << std::endl; return 4; }
@@ -246,7 +247,9 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         }
     }
 
+    const auto t_norm = std::chrono::steady_clock::now();
     normalize(&seq[start_f], end_f - start_f, params);                               // :673
+    const double normalize_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_norm).count();
     {
         std::ofstream infos((params.output + "config.cfg").c_str());                 // :684-688
         infos << "# SlowFlow variational estimation\n" << params;
@@ -416,7 +419,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         tj << "\n]\n";
         std::ofstream rj((params.output + "run.json").c_str());
         rj << "{\"windows\": " << todo.size() << ", \"gpus\": " << ngpu << ", \"streams\": " << streams << ", \"batch\": " << batch << ", \"io_threads\": " << io_threads
-           << ", \"ingest_seconds\": " << ingest_seconds << ", \"refine_seconds\": " << compute_seconds << ", \"total_seconds\": " << total_seconds << "}\n";
+           << ", \"decode_seconds\": " << decode_seconds << ", \"normalize_seconds\": " << normalize_seconds << ", \"ingest_seconds\": " << ingest_seconds << ", \"refine_seconds\": " << compute_seconds << ", \"total_seconds\": " << total_seconds << "}\n";
     }
     for (unsigned f = start_f; f < end_f; f++) color_image_delete(seq[f]);
     for (auto g : gt) if (g) { image_delete(g[0]); image_delete(g[1]); free(g); }

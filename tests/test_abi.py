@@ -89,3 +89,16 @@ def test_product_does_not_touch_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "slowflow_oracle" not in txt and "import oracle" not in txt and "orc_" not in txt, fn
+
+
+def test_counted_publish_covers_the_edge_store():
+    """the band kernel publishes a band's progress behind a hand-counted `s_waitcnt vmcnt(N)`; the count is only right while at least
+    N vector-memory instructions are issued between the edge store and the wait.  tools/check_publish_vmcnt.py verifies that on the ISA of every
+    instantiated shape and role; a toolchain bump or a change of the refill code that breaks it fails here, not as a rare stale read on the GPU."""
+    import shutil
+    import subprocess
+    import sys
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_publish_vmcnt.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "counted publishes cover their edge store" in r.stdout, r.stdout + r.stderr
