@@ -176,6 +176,18 @@ int sfa_gaussian_presmooth(sfa_ctx *ctx, float *dst, const float *src, int w, in
 int sfa_resize_linear_fx(sfa_ctx *ctx, float *dst, int dw, int dh, int dstride, const float *src, int sw, int sh, int sstride, double fx, double fy);
 int sfa_pyramid_sizes(int w, int h, int layers, float p_scale, int *ws, int *hs);
 
+/* ---- a sequence's frames resident in HBM (the multi-pair driver) ----------------------------------------------------------------------
+ * The reference keeps the whole sequence in host memory (slow_flow.cpp:447-592), normalises it in place (:673) and hands windows of it to the solver
+ * (:721-724).  Here the frames cross PCIe once: uploaded, normalised on the GPU (same arithmetic as sfa_normalize, which is built on this), and copied
+ * device-to-device into the jobs that need them. */
+typedef struct sfa_sequence sfa_sequence;
+int  sfa_sequence_create(sfa_ctx *ctx, int w, int h, int n_frames, sfa_sequence **out);
+void sfa_sequence_destroy(sfa_sequence *seq);
+int  sfa_sequence_upload(sfa_sequence *seq, int f, const float *frame3, int stride);      /* asynchronous on the context's stream */
+int  sfa_sequence_download(sfa_sequence *seq, int f, float *frame3, int stride);
+/* normalize() (variational_mt.cpp:17-85) over the frames [f0, f0 + n) in place on the GPU; avg / std as sfa_normalize */
+int  sfa_sequence_normalize(sfa_sequence *seq, int f0, int n, double avg[3], double std_dev[3]);
+
 /* ---- device-resident batches (measurement and the multi-pair driver) ------------------------------
  * A job = `batch` independent frame windows of identical size solved in lockstep by the same launches
  * (forward + backward of a jet, several jets ...), all inputs resident in HBM. */
@@ -185,6 +197,9 @@ void sfa_job_destroy(sfa_job *job);
 /* frames / initial flow of batch element b (host -> HBM); chw NULL = ones */
 int  sfa_job_upload(sfa_job *job, int b, const float *const *frames, int n_frames, const float *wx, const float *wy,
                     int stride, const float *const chw[3]);
+/* the same with the frames of the window taken from a resident sequence on the same GPU: frame f of the window = sequence frame frame_index[f] */
+int  sfa_job_upload_resident(sfa_job *job, int b, const sfa_sequence *seq, const int *frame_index, int n_frames, const float *wx, const float *wy,
+                             int stride, const float *const chw[3]);
 int  sfa_job_reset_flow(sfa_job *job);               /* re-arm every element with the uploaded initial flow */
 int  sfa_job_run(sfa_job *job);                      /* the whole coarse-to-fine path on the ctx stream; may be called again on the same uploads
                                                         (same result: presmoothing, cfg sigma > 0, is applied once per upload) */

@@ -66,7 +66,8 @@ EXPORTS = [
     "sfa_variational", "sfa_variational_2frame", "sfa_params_2frame_default", "variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sfa_sor_red_black", "sor_coupled",
     "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
     "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_resize_linear_fx", "sfa_gaussian_presmooth", "sfa_pyramid_sizes",
-    "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters",
+    "sfa_sequence_create", "sfa_sequence_destroy", "sfa_sequence_upload", "sfa_sequence_download", "sfa_sequence_normalize",
+    "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_upload_resident", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
     "sfa_profile_enable", "sfa_profile_read", "sfa_timer_start", "sfa_timer_stop",
 ]
@@ -86,7 +87,7 @@ def lib():
         L.sfa_last_error.argtypes = [C.c_void_p]
         L.sfa_job_mpix_iters.restype = C.c_double
         L.sfa_job_mpix_iters.argtypes = [C.c_void_p]
-        for name in ("sfa_ctx_destroy", "sfa_job_destroy", "sfa_sor_batch_destroy"):
+        for name in ("sfa_ctx_destroy", "sfa_job_destroy", "sfa_sor_batch_destroy", "sfa_sequence_destroy"):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [C.c_void_p]
         _lib = L
@@ -308,6 +309,12 @@ class Job:
         cw = (_f * 3)(fptr(chw[0]), fptr(chw[1]), fptr(chw[2])) if chw is not None else None
         self.ctx._ck(lib().sfa_job_upload(self.h_, b, arr, F, fptr(wx) if wx is not None else None, fptr(wy) if wy is not None else None, stride, cw), "sfa_job_upload")
 
+    def upload_resident(self, b, seq, frame_index, wx=None, wy=None, chw=None):
+        idx = (C.c_int * len(frame_index))(*frame_index)
+        cw = (_f * 3)(fptr(chw[0]), fptr(chw[1]), fptr(chw[2])) if chw is not None else None
+        self.ctx._ck(lib().sfa_job_upload_resident(self.h_, b, seq.h_, idx, len(frame_index), fptr(wx) if wx is not None else None,
+                                                   fptr(wy) if wy is not None else None, stride_of(self.w), cw), "sfa_job_upload_resident")
+
     def run(self):
         self.ctx._ck(lib().sfa_job_run(self.h_), "sfa_job_run")
 
@@ -339,6 +346,39 @@ class Job:
     def close(self):
         if self.h_:
             lib().sfa_job_destroy(self.h_)
+            self.h_ = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sequence:
+    """sfa_sequence: the frames of a sequence resident on the GPU, normalised there"""
+
+    def __init__(self, ctx, w, h, n):
+        self.ctx, self.w, self.h, self.n = ctx, w, h, n
+        self.h_ = C.c_void_p()
+        ctx._ck(lib().sfa_sequence_create(ctx.h, w, h, n, C.byref(self.h_)), "sfa_sequence_create")
+
+    def upload(self, f, frame3):
+        self.ctx._ck(lib().sfa_sequence_upload(self.h_, f, fptr(frame3), frame3.shape[2]), "sfa_sequence_upload")
+
+    def download(self, f):
+        a = np.zeros((3, self.h, stride_of(self.w)), np.float32)
+        self.ctx._ck(lib().sfa_sequence_download(self.h_, f, fptr(a), a.shape[2]), "sfa_sequence_download")
+        return a
+
+    def normalize(self, f0=0, n=None):
+        avg, std = (C.c_double * 3)(), (C.c_double * 3)()
+        self.ctx._ck(lib().sfa_sequence_normalize(self.h_, f0, self.n - f0 if n is None else n, avg, std), "sfa_sequence_normalize")
+        return list(avg), list(std)
+
+    def close(self):
+        if self.h_:
+            lib().sfa_sequence_destroy(self.h_)
             self.h_ = C.c_void_p()
 
     def __del__(self):

@@ -879,32 +879,83 @@ void variational(sfa_image *wx, sfa_image *wy, const sfa_color_image *im1, const
     }
 }
 
-// ---- normalize ---------------------------------------------------------------------------------------------
+// ---- frames resident in HBM, normalize (variational_mt.cpp:17-85) on them ------------------------------------------------------------
+struct sfa_sequence {
+    sfa_ctx *ctx = nullptr;
+    int w = 0, h = 0, n = 0, pitch = 0;
+    long pl = 0;
+    DevMem mem;                        // n x 3 planes at the device pitch
+    DevMem sums;                       // n x 6 doubles: per frame and channel sum(I), sum(I*I)
+    float *frame(int f) const { return mem.f() + (long)f * 3 * pl; }
+    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, 1ull}; }
+};
+
+int sfa_sequence_create(sfa_ctx *ctx, int w, int h, int n_frames, sfa_sequence **out) {
+    CHECK_ARGS(ctx && out && w > 0 && h > 0 && n_frames > 0, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<sfa_sequence> q(new sfa_sequence());
+    q->ctx = ctx; q->w = w; q->h = h; q->n = n_frames; q->pitch = dev_pitch(w); q->pl = (long)q->pitch * h;
+    SFA_TRY(q->mem.alloc(ctx, (size_t)n_frames * 3 * q->pl * sizeof(float)));
+    SFA_HIP(ctx, hipMemsetAsync(q->mem.p, 0, (size_t)n_frames * 3 * q->pl * sizeof(float), ctx->stream));
+    SFA_TRY(q->sums.alloc(ctx, (size_t)n_frames * 6 * sizeof(double)));
+    *out = q.release();
+    return SFA_OK;
+}
+void sfa_sequence_destroy(sfa_sequence *q) {
+    if (!q) return;
+    (void)hipSetDevice(q->ctx->device);
+    (void)hipStreamSynchronize(q->ctx->stream);
+    delete q;
+}
+int sfa_sequence_upload(sfa_sequence *q, int f, const float *frame3, int stride) {
+    sfa_ctx *ctx = q ? q->ctx : nullptr;
+    CHECK_ARGS(q && f >= 0 && f < q->n && frame3 && stride >= q->w, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < 3; k++) SFA_TRY(upload_plane(ctx, q->frame(f) + k * q->pl, q->pitch, frame3 + (size_t)k * stride * q->h, stride, q->w, q->h));
+    return SFA_OK;                                           // asynchronous on the context's stream; sfa_ctx_sync / any later call orders behind it
+}
+int sfa_sequence_download(sfa_sequence *q, int f, float *frame3, int stride) {
+    sfa_ctx *ctx = q ? q->ctx : nullptr;
+    CHECK_ARGS(q && f >= 0 && f < q->n && frame3 && stride >= q->w, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < 3; k++) SFA_TRY(download_plane(ctx, frame3 + (size_t)k * stride * q->h, stride, q->frame(f) + k * q->pl, q->pitch, q->w, q->h));
+    return sfa_ctx_sync(ctx);
+}
+// normalize() over frames [f0, f0 + n): statistics over exactly these frames (the reference's `-jet k` mode normalises over that jet's frames only,
+// slow_flow.cpp:418-424,673), every frame's sums by the same kernels in the same order whatever the number of frames
+int sfa_sequence_normalize(sfa_sequence *q, int f0, int n, double avg[3], double std_dev[3]) {
+    sfa_ctx *ctx = q ? q->ctx : nullptr;
+    CHECK_ARGS(q && avg && std_dev && f0 >= 0 && n > 0 && f0 + n <= q->n, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    double *dsum = reinterpret_cast<double *>(q->sums.p);
+    for (int f = f0; f < f0 + n; f++) launch_normalize_sums(ctx, q->geo(), q->frame(f), dsum + 6 * f);
+    std::vector<double> hs((size_t)6 * n);
+    SFA_HIP(ctx, hipMemcpyAsync(hs.data(), dsum + 6 * f0, hs.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; k++) { avg[k] = 0; std_dev[k] = 0; }
+    for (int f = 0; f < n; f++)
+        for (int k = 0; k < 3; k++) {
+            avg[k] += hs[6 * f + 2 * k] / (q->h * q->w);                                 // variational_mt.cpp:41-47
+            std_dev[k] += hs[6 * f + 2 * k + 1] / (q->h * q->w);
+        }
+    for (int k = 0; k < 3; k++) {
+        avg[k] /= n;
+        std_dev[k] = sqrt((std_dev[k] / n) - avg[k] * avg[k]) / 255.0f;                 // :52
+    }
+    for (int f = f0; f < f0 + n; f++) launch_normalize_apply(ctx, q->geo(), q->frame(f), avg, std_dev);
+    return sfa_ctx_sync(ctx);
+}
+
 int sfa_normalize(sfa_ctx *ctx, float *const *frames, int F, int w, int h, int stride, double avg[3], double std_dev[3]) {
     CHECK_ARGS(ctx && frames && F > 0 && w > 0 && h > 0 && stride >= w && avg && std_dev, "bad arguments");
-    Staging s;
-    SFA_TRY(s.init(ctx, w, h, 3 * F));
-    for (int k = 0; k < 3; k++) { avg[k] = 0; std_dev[k] = 0; }
-    for (int f = 0; f < F; f++) {
-        CHECK_ARGS(frames[f], "null frame");
-        SFA_TRY(s.up(3 * f, frames[f], stride, 3));
-        launch_normalize_sums(ctx, s.geo(), s.plane(3 * f), ctx->d_red);
-        SFA_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < 3; k++) {
-            avg[k] += ctx->h_red[2 * k] / (h * w);                                     // variational_mt.cpp:41-47
-            std_dev[k] += ctx->h_red[2 * k + 1] / (h * w);
-        }
-    }
-    for (int k = 0; k < 3; k++) {
-        avg[k] /= F;
-        std_dev[k] = sqrt((std_dev[k] / F) - avg[k] * avg[k]) / 255.0f;               // :52
-    }
-    for (int f = 0; f < F; f++) {
-        launch_normalize_apply(ctx, s.geo(), s.plane(3 * f), avg, std_dev);
-        SFA_TRY(s.down(frames[f], stride, 3 * f, 3));
-    }
-    return sfa_ctx_sync(ctx);
+    for (int f = 0; f < F; f++) CHECK_ARGS(frames[f], "null frame");
+    sfa_sequence *q = nullptr;
+    SFA_TRY(sfa_sequence_create(ctx, w, h, F, &q));
+    std::unique_ptr<sfa_sequence, void (*)(sfa_sequence *)> guard(q, sfa_sequence_destroy);
+    for (int f = 0; f < F; f++) SFA_TRY(sfa_sequence_upload(q, f, frames[f], stride));
+    SFA_TRY(sfa_sequence_normalize(q, 0, F, avg, std_dev));
+    for (int f = 0; f < F; f++) SFA_TRY(sfa_sequence_download(q, f, frames[f], stride));
+    return SFA_OK;
 }
 
 // ---- job ------------------------------------------------------------------------------------------------------
@@ -946,23 +997,8 @@ void sfa_job_destroy(sfa_job *j) {
 }
 double sfa_job_mpix_iters(const sfa_job *j) { return j ? j->mpix_iters : 0; }
 
-int sfa_job_upload(sfa_job *j, int b, const float *const *frames, int n_frames, const float *wx, const float *wy, int stride, const float *const chw[3]) {
-    sfa_ctx *ctx = j ? j->ctx : nullptr;
-    CHECK_ARGS(j && b >= 0 && b < j->nb && frames && n_frames == j->F && stride >= j->w, "bad arguments (n_frames must be 2*(S-1)+1)");
-    SFA_HIP(ctx, hipSetDevice(ctx->device));
-    Level L0 = j->level(0);
-    j->host_stride0 = stride;
-    j->presmoothed &= ~(1ull << b);
-    for (int f = 0; f < j->F; f++) {
-        CHECK_ARGS(frames[f], "null frame");
-        for (int k = 0; k < 3; k++)
-            SFA_TRY(upload_plane(ctx, L0.frame(f) + b * j->es + k * L0.pl, L0.pitch, frames[f] + (size_t)k * stride * j->h, stride, j->w, j->h));
-    }
-    float *f0 = j->init_flow.f() + (long)b * 2 * L0.pl;
-    if (wx) SFA_TRY(upload_plane(ctx, f0, L0.pitch, wx, stride, j->w, j->h));
-    else SFA_HIP(ctx, hipMemsetAsync(f0, 0, L0.pl * sizeof(float), ctx->stream));
-    if (wy) SFA_TRY(upload_plane(ctx, f0 + L0.pl, L0.pitch, wy, stride, j->w, j->h));
-    else SFA_HIP(ctx, hipMemsetAsync(f0 + L0.pl, 0, L0.pl * sizeof(float), ctx->stream));
+static int job_set_channel_weights(sfa_job *j, int b, int stride, const float *const chw[3]) {
+    sfa_ctx *ctx = j->ctx;
     if (chw) {
         // weights keep the level-0 host geometry, padding lanes included (the reference indexes them linearly)
         CHECK_ARGS((long)stride * j->h < (1L << 31), "channel weights: the linear pixel index must fit 31 bits");
@@ -982,7 +1018,53 @@ int sfa_job_upload(sfa_job *j, int b, const float *const *frames, int n_frames, 
         // a slot that held weighted channels before (jobs are reused for batch after batch) goes back to all ones
         launch_fill(ctx, j->chw.f() + (long)b * 3 * dev_pitch(j->chw_stride0) * j->h, (size_t)3 * dev_pitch(j->chw_stride0) * j->h, 1.0f);
     }
+    return SFA_OK;
+}
+
+int sfa_job_upload(sfa_job *j, int b, const float *const *frames, int n_frames, const float *wx, const float *wy, int stride, const float *const chw[3]) {
+    sfa_ctx *ctx = j ? j->ctx : nullptr;
+    CHECK_ARGS(j && b >= 0 && b < j->nb && frames && n_frames == j->F && stride >= j->w, "bad arguments (n_frames must be 2*(S-1)+1)");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    Level L0 = j->level(0);
+    j->host_stride0 = stride;
+    j->presmoothed &= ~(1ull << b);
+    for (int f = 0; f < j->F; f++) {
+        CHECK_ARGS(frames[f], "null frame");
+        for (int k = 0; k < 3; k++)
+            SFA_TRY(upload_plane(ctx, L0.frame(f) + b * j->es + k * L0.pl, L0.pitch, frames[f] + (size_t)k * stride * j->h, stride, j->w, j->h));
+    }
+    float *f0 = j->init_flow.f() + (long)b * 2 * L0.pl;
+    if (wx) SFA_TRY(upload_plane(ctx, f0, L0.pitch, wx, stride, j->w, j->h));
+    else SFA_HIP(ctx, hipMemsetAsync(f0, 0, L0.pl * sizeof(float), ctx->stream));
+    if (wy) SFA_TRY(upload_plane(ctx, f0 + L0.pl, L0.pitch, wy, stride, j->w, j->h));
+    else SFA_HIP(ctx, hipMemsetAsync(f0 + L0.pl, 0, L0.pl * sizeof(float), ctx->stream));
+    SFA_TRY(job_set_channel_weights(j, b, stride, chw));
     SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFA_OK;
+}
+
+// the same as sfa_job_upload with the frames taken from a sequence resident on the job's GPU (device-to-device copies on the job's stream): a frame is
+// sent over PCIe once however many windows it is part of (S=3: five windows, both directions) and normalize never brings it back to the host
+int sfa_job_upload_resident(sfa_job *j, int b, const sfa_sequence *q, const int *frame_index, int n_frames, const float *wx, const float *wy, int stride,
+                            const float *const chw[3]) {
+    sfa_ctx *ctx = j ? j->ctx : nullptr;
+    CHECK_ARGS(j && q && frame_index && b >= 0 && b < j->nb && n_frames == j->F && stride >= j->w, "bad arguments (n_frames must be 2*(S-1)+1)");
+    CHECK_ARGS(q->w == j->w && q->h == j->h && q->ctx->device == ctx->device, "the sequence must have the job's frame size and live on the job's GPU");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
+    Level L0 = j->level(0);
+    j->host_stride0 = stride;
+    j->presmoothed &= ~(1ull << b);
+    for (int f = 0; f < j->F; f++) {
+        CHECK_ARGS(frame_index[f] >= 0 && frame_index[f] < q->n, "frame index out of range");
+        SFA_HIP(ctx, hipMemcpyAsync(L0.frame(f) + b * j->es, q->frame(frame_index[f]), (size_t)3 * L0.pl * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    float *f0 = j->init_flow.f() + (long)b * 2 * L0.pl;
+    if (wx) SFA_TRY(upload_plane(ctx, f0, L0.pitch, wx, stride, j->w, j->h));
+    else SFA_HIP(ctx, hipMemsetAsync(f0, 0, L0.pl * sizeof(float), ctx->stream));
+    if (wy) SFA_TRY(upload_plane(ctx, f0 + L0.pl, L0.pitch, wy, stride, j->w, j->h));
+    else SFA_HIP(ctx, hipMemsetAsync(f0 + L0.pl, 0, L0.pl * sizeof(float), ctx->stream));
+    SFA_TRY(job_set_channel_weights(j, b, stride, chw));
+    if (wx || wy || chw) SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may go away after the call
     return SFA_OK;
 }
 

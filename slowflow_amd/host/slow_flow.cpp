@@ -4,8 +4,8 @@
 //   frames -> normalize -> per jet: forward / backward Variational_MT::variational -> flow * steps -> .flo
 // The jets of a sequence are independent; they are sharded over the node's GPUs (shard.h: `gpu_streams` host threads per
 // GPU, each with its own context = HIP stream) and each worker refines `gpu_batch` frame windows in lockstep.  The driver is
-// a pipeline: frames are decoded by a pool of host threads, every worker keeps ONE resident job for all its batches
-// (upload / run / download), and results go to the output pool (.flo, colour PNG, occlusion images) while the worker
+// a pipeline: frames are decoded by a pool of host threads, sent to every GPU once and normalised there (sfa_sequence), every worker
+// keeps ONE resident job for all its batches (device-to-device window copies / run / download), and results go to the output pool (.flo, colour PNG, occlusion images) while the worker
 // already refines its next batch; with two workers per GPU the uploads of one overlap the kernels of the other.
 // Out of scope here (and rejected with a message): the third-party demosaicers (raw_demosaicing 1, 2) and the
 // DeepMatching/EpicFlow initialisation -- third-party code (OpenCV, MATLAB SED, DeepMatching) outside the path.
@@ -247,8 +247,40 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         }
     }
 
+    // ---- the frames go to the GPUs once and are normalised there (:673; sfa_sequence = normalize() on resident frames: same kernels, same statistics
+    //      as the host-plane normalize() of variational_mt.h).  Every GPU holds the loaded frames -- 133 frames of 1024x436 are 0.7 GB -- so no GPU
+    //      waits for another; the statistics are those of GPU 0 (identical on all: same data, same deterministic kernels). --------------------------
     const auto t_norm = std::chrono::steady_clock::now();
-    normalize(&seq[start_f], end_f - start_f, params);                               // :673
+    int ngpu = sfa_device_count();
+    if (ngpu <= 0) { std::cerr << "no HIP device: slowflow_amd has no CPU fallback" << std::endl; return 4; }
+    if (params.exists("gpus")) ngpu = std::max(1, std::min(ngpu, params.parameter<int>("gpus")));
+    const int dev0 = params.parameter<int>("gpu_device", "0");
+    const int n_loaded = (int)(end_f - start_f);
+    std::vector<sfa_ctx *> seq_ctx(ngpu, nullptr);
+    std::vector<sfa_sequence *> seq_dev(ngpu, nullptr);
+    std::vector<double> stat_avg(3 * ngpu, 0.0), stat_std(3 * ngpu, 0.0);
+    std::vector<string> seq_err(ngpu);
+    {
+        std::vector<std::thread> up;
+        for (int g = 0; g < ngpu; g++)
+            up.emplace_back([&, g] {
+                int rc = sfa_ctx_create(dev0 + g, &seq_ctx[g]);
+                if (rc == SFA_OK) rc = sfa_sequence_create(seq_ctx[g], width, height, n_loaded, &seq_dev[g]);
+                for (int f = 0; f < n_loaded && rc == SFA_OK; f++) rc = sfa_sequence_upload(seq_dev[g], f, seq[start_f + f]->c1, seq[start_f + f]->stride);
+                if (rc == SFA_OK) rc = sfa_sequence_normalize(seq_dev[g], 0, n_loaded, &stat_avg[3 * g], &stat_std[3 * g]);
+                if (rc != SFA_OK) seq_err[g] = sfa_last_error(seq_ctx[g]);
+            });
+        for (auto &t : up) t.join();
+    }
+    auto release_sequences = [&] {
+        for (int g = 0; g < ngpu; g++) {
+            if (seq_dev[g]) sfa_sequence_destroy(seq_dev[g]);
+            if (seq_ctx[g]) sfa_ctx_destroy(seq_ctx[g]);
+        }
+    };
+    for (int g = 0; g < ngpu; g++)
+        if (!seq_err[g].empty()) { std::cerr << "GPU " << dev0 + g << ": " << seq_err[g] << std::endl; release_sequences(); return 4; }
+    publish_normalization(params, &stat_avg[0], &stat_std[0]);                       // the slow_flow_img_norm_* parameters (variational_mt.cpp:71-84)
     const double normalize_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_norm).count();
     {
         std::ofstream infos((params.output + "config.cfg").c_str());                 // :684-688
@@ -269,10 +301,6 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         else std::cout << "Backward flow from frame " << start + f * skip << " to " << start + f * skip + steps * skip << " already exist!" << std::endl;
     }
 
-    int ngpu = sfa_device_count();
-    if (ngpu <= 0) { std::cerr << "no HIP device: slowflow_amd has no CPU fallback" << std::endl; return 4; }
-    if (params.exists("gpus")) ngpu = std::max(1, std::min(ngpu, params.parameter<int>("gpus")));
-    const int dev0 = params.parameter<int>("gpu_device", "0");
     const int batch = std::max(1, std::min(64, params.parameter<int>("gpu_batch", "32")));
     const int F = 2 * ref + 1;
     const bool backward_forward_only = params.exists("method") && params.parameter("method") == "forward";   // :1019-1020
@@ -349,13 +377,13 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                 for (int e = 0; e < nb && rc == SFA_OK; e++) {
                     const Window &wd = todo[mine[b0 + e]];
                     const int f = wd.jet * steps;
-                    color_image_t *const *im = wd.backward ? &seq_back[frames - 1 - f - 3 * steps] : &seq[f];   // :721-724
-                    std::vector<const float *> fr(F);
-                    for (int k = 0; k < F; k++) fr[k] = im[k]->c1;
+                    // the window's frames in the loaded sequence: forward seq[f + k]; backward seq_back[frames - 1 - f - 3*steps + k] = seq[f + 3*steps - k] (:590-591, :721-724)
+                    std::vector<int> idx(F);
+                    for (int k = 0; k < F; k++) idx[k] = (wd.backward ? f + 3 * steps - k : f + k) - (int)start_f;
                     const float *chw[3] = {channel_weights->c1, channel_weights->c2, channel_weights->c3};
                     // only the forward solver gets the channel weights (:876 vs :1018); without raw weighting they are all ones (:597-598), which is
                     // what a NULL pointer means to the library (x * 1.0f is exact: same bits, three planes less to read per pixel)
-                    rc = sfa_job_upload(job, e, fr.data(), F, nullptr, nullptr, im[0]->stride, (wd.backward || !raw) ? nullptr : chw);
+                    rc = sfa_job_upload_resident(job, e, seq_dev[wp.gpu], idx.data(), F, nullptr, nullptr, seq[start_f]->stride, (wd.backward || !raw) ? nullptr : chw);
                 }
                 if (rc == SFA_OK) rc = sfa_job_run(job);
                 std::vector<std::shared_ptr<WindowResult>> results;
@@ -421,6 +449,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         rj << "{\"windows\": " << todo.size() << ", \"gpus\": " << ngpu << ", \"streams\": " << streams << ", \"batch\": " << batch << ", \"io_threads\": " << io_threads
            << ", \"decode_seconds\": " << decode_seconds << ", \"normalize_seconds\": " << normalize_seconds << ", \"ingest_seconds\": " << ingest_seconds << ", \"refine_seconds\": " << compute_seconds << ", \"total_seconds\": " << total_seconds << "}\n";
     }
+    release_sequences();
     for (unsigned f = start_f; f < end_f; f++) color_image_delete(seq[f]);
     for (auto g : gt) if (g) { image_delete(g[0]); image_delete(g[1]); free(g); }
     color_image_delete(channel_weights);

@@ -81,10 +81,14 @@ void normalize(color_image_t **seq, u_int32_t F, ParameterList &params) {
     const std::string err = rc == SFA_OK ? "" : sfa_last_error(c);
     sfa_ctx_destroy(c);
     if (rc != SFA_OK) throw std::runtime_error("slowflow_amd normalize: " + err);
-    if (params.verbosity(VER_CMD))
-        for (int k = 0; k < 3; k++) std::cout << "Intensities normalized by (I - " << avg[k] << ") / " << sd[k] << std::endl;
+    publish_normalization(params, avg, sd);
+}
+
+void publish_normalization(ParameterList &params, const double avg[3], const double sd[3]) {
     const char *ka[3] = {"slow_flow_img_norm_avg_1", "slow_flow_img_norm_avg_2", "slow_flow_img_norm_avg_3"};
     const char *ks[3] = {"slow_flow_img_norm_std_1", "slow_flow_img_norm_std_2", "slow_flow_img_norm_std_3"};
+    if (params.verbosity(VER_CMD))
+        for (int k = 0; k < 3; k++) std::cout << "Intensities normalized by (I - " << avg[k] << ") / " << sd[k] << std::endl;
     for (int k = 0; k < 3; k++) {                                                    // stringstream <<: 6 significant digits (:71-84)
         std::stringstream a, s;
         a << avg[k];

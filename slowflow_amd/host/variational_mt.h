@@ -17,6 +17,10 @@
  * params["gpu_device"] (default 0). */
 void normalize(color_image_t **seq, u_int32_t F, ParameterList &params);
 
+/* what normalize() does with its six statistics: publish them as slow_flow_img_norm_{avg,std}_{1,2,3}, 6 significant digits (variational_mt.cpp:71-84);
+ * for callers that normalise frames already resident on a GPU (sfa_sequence_normalize) */
+void publish_normalization(ParameterList &params, const double avg[3], const double std_dev[3]);
+
 /* fill the C-ABI parameter block from the cfg keys exactly as Variational_MT::variational / compute_one_level read
  * them (variational_mt.cpp:173-192, 533-568), including defaults and the grad->color fallback */
 sfa_params sfa_params_from_cfg(ParameterList &params, bool one_direction);

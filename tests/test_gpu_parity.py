@@ -969,3 +969,38 @@ def test_red_black_mode_is_labelled_and_deviates(ctx, oracle):
         got = job.download(b)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     job.close(); one.close()
+
+
+def test_resident_sequence_is_normalize_plus_upload(ctx, oracle):
+    """sfa_sequence (frames sent to the GPU once, normalised there, copied device-to-device into jobs) gives the statistics, the frames and the flow of
+    the host-plane route: sfa_normalize + sfa_job_upload"""
+    w, h, n = 130, 98, 5
+    frames = [c_(texture_frame(w, h, k)) for k in range(n)]
+    host = [f.copy() for f in frames]
+    avg_h, std_h = ctx.normalize(host, w)
+    seq = sfa.Sequence(ctx, w, h, n)
+    for f in range(n):
+        seq.upload(f, frames[f])
+    avg_d, std_d = seq.normalize()
+    assert avg_d == avg_h and std_d == std_h
+    for f in range(n):
+        assert np.array_equal(seq.download(f)[:, :, :w], host[f][:, :, :w])
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=[float("%g" % a) for a in avg_h], norm_std=[float("%g" % s) for s in std_h], layers=2, niter_outer=2)
+    a = sfa.Job(ctx, ps, w, h, 2)
+    a.upload(0, host[0:3]); a.upload(1, host[4:1:-1])
+    a.run()
+    b = sfa.Job(ctx, ps, w, h, 2)
+    b.upload_resident(0, seq, [0, 1, 2]); b.upload_resident(1, seq, [4, 3, 2])
+    b.run()
+    for e in (0, 1):
+        x, y = a.download(e), b.download(e)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    # statistics over a sub-range (the reference's -jet k mode normalises over that jet's frames only)
+    seq2 = sfa.Sequence(ctx, w, h, n)
+    for f in range(n):
+        seq2.upload(f, frames[f])
+    sub = [f.copy() for f in frames[1:4]]
+    got, want = seq2.normalize(1, 3), ctx.normalize(sub, w)
+    assert list(got[0]) == list(want[0]) and list(got[1]) == list(want[1])
+    assert np.array_equal(seq2.download(2)[:, :, :w], sub[1][:, :, :w]) and np.array_equal(seq2.download(0)[:, :, :w], frames[0][:, :, :w])   # frames outside the range untouched
+    a.close(); b.close(); seq.close(); seq2.close()

@@ -498,8 +498,9 @@ def test_config4_cfg_over_64_jets_1024x436(host_build, tmp_path):
     run = json.load(open(str(out / "run.json")))
     assert run["windows"] == 128 and run["refine_seconds"] <= run["total_seconds"]
     print("config 4 through the driver on one GPU: %s" % run)
-    # the pipeline hides ingest and output: beyond the refinement itself the run may spend 15 % + 1.5 s (133 frames decoded, normalize, config echo)
-    assert run["total_seconds"] <= 1.15 * run["refine_seconds"] + 1.5, run
+    # the pipeline hides output behind the refinement and sends every frame to the GPU once: beyond the refinement itself (which includes creating the
+    # workers' contexts and jobs) the run may spend 15 % (measured on MI355X: 2.40 s total, 2.20 s refinement, 0.15 s ingest)
+    assert run["total_seconds"] <= 1.15 * run["refine_seconds"] + 0.3, run
     # ---- a sample of windows through the binding ------------------------------------------------------------------------------
     ctx = sfa.Context(0)
     stride = sfa.stride_of(W)
