@@ -13,4 +13,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch -o bench -f
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${TAG}_write -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_write.json 2> gpurun_out/${TAG}_write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d gpurun_out/${TAG}_sq1 -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_sq1.json 2> gpurun_out/${TAG}_sq1.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d gpurun_out/${TAG}_sq2 -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_sq2.json 2> gpurun_out/${TAG}_sq2.err
+# pass 6: the same workload on ONE stream (no second group sharing the GPU): the per-kernel maxima here against pass 1 show what the overlap costs a kernel
+rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats1 -o bench -f csv -- python3 bench.py --batch $((BATCH / 2)) --streams 1 --steps 5 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_stats1.json 2> gpurun_out/${TAG}_stats1.err
 echo done

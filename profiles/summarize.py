@@ -29,6 +29,11 @@ def find(d, suffix):
 shutil.copy(find(f"{tag}_stats", "kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(go, f"{tag}_stats.json"), os.path.join(out, f"{tag}_bench_under_rocprof.json"))
 
+try:                                  # the one-stream run of the same workload (collect.sh pass 6)
+    shutil.copy(find(f"{tag}_stats1", "kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats_one_stream.csv"))
+except FileNotFoundError:
+    pass
+
 # SOR kernel per level from the trace
 rows = list(csv.DictReader(open(find(f"{tag}_stats", "kernel_trace.csv"))))
 acc = collections.defaultdict(list)

@@ -401,6 +401,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     // row up per sweep (FOFF): the wave keeps its last 2(F-1) operand rows in LDS and sweeps f >= 1 read them back at
     // lane offset -f.  Rows r0-(F-1) .. r0-1 (positions 0 .. F-2 of a window row) come through a second, (F-1)-lane load per plane.
     constexpr int NSLOT = F > 1 ? 2 * (F - 1) : 1, WP = 64 + F - 1;      // window rows (steps) / positions per row
+    static_assert(MC % NSLOT == 0 && MC % CH == 0 && F * MC <= 64 && (F + 1) * CH <= 64, "band shape: window rows, chunks and the edge / lane-0 fetch lanes must fit");
 #ifdef SFA_X_NOLOAD       // timing experiment only: zero records, the range check drops every operand load
     const __amdgpu_buffer_rsrc_t rA = plane_rsrc(a.sa + (size_t)job * a.ent, 0);
     const __amdgpu_buffer_rsrc_t rB = plane_rsrc(a.sb + (size_t)job * a.ent, 0);
@@ -426,7 +427,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
         for (int i = lane; i < 2 * NSLOT * WP; i += 64) winA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int t = 1; t <= NSLOT; t++) {
             const float4 ea = bload16(rA, vE, so16 - (F - 1) * 16u - t * st16), eb = bload16(rB, vE, so16 - (F - 1) * 16u - t * st16);
-            if (ex_lane) { winA[((NSLOT - t) & (NSLOT - 1)) * WP + lane] = ea; winB[((NSLOT - t) & (NSLOT - 1)) * WP + lane] = eb; }
+            if (ex_lane) { winA[((NSLOT - t) % NSLOT) * WP + lane] = ea; winB[((NSLOT - t) % NSLOT) * WP + lane] = eb; }
         }
     }
     { const int r = r0 + lane - (F - 1); row_ok_last = r >= 0 && r < H; }
@@ -444,10 +445,10 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
 #endif
     // lane t = fi*TN + j fetches lane 0's "lane -1" value of step j of the chunk: fi = 0: right of f = 0 (sweep
     // k0-1, column s+1); fi = f+1: top of f (sweep k0+f, column s-f)
-    // BC (all shapes with (F+1)*CH <= 16): the fetch covers one CH-step chunk; the fetched values are parked in LDS (tvbuf, two chunks) and every
+    // BC (all shapes with (F+1)*CH <= 64 lanes): the fetch covers one CH-step chunk; the fetched values are parked in LDS (tvbuf, two chunks) and every
     // step reads its F+1 values back with wave-uniform (broadcast) addresses into the registers the DPP shifts then write into: lane 0
     // keeps the broadcast value, lanes 1.. receive their neighbour's.  Other shapes: one fetch per macro chunk, v_readlane per value.
-    constexpr bool BC = (F + 1) * CH <= 16;
+    constexpr bool BC = (F + 1) * CH <= 64;
     constexpr int TN = BC ? CH : MC;                             // steps covered by one fetch
     const int tfi = lane / TN, tj = lane % TN;
     const bool tv_lane = has_up && lane < (F + 1) * TN && (tfi > 0 || !FIRST);
@@ -572,7 +573,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                 oa[0] = sa0[j]; ob[0] = sb0[j];
 #pragma unroll
                 for (int f = 1; f < F; f++) {
-                    const int slot = (jj - 2 * f + 4 * NSLOT) & (NSLOT - 1);
+                    const int slot = (jj - 2 * f + 4 * NSLOT) % NSLOT;      // window row of step s - 2f (MC is a multiple of NSLOT: jj and s agree modulo NSLOT)
 #ifdef SFA_X_NOWIN        // timing experiment only
                     oa[f] = sa0[j]; ob[f] = sb0[j]; (void)slot;
 #else
@@ -601,7 +602,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                 }
 #ifndef SFA_X_NOWIN
                 if (F > 1) {                                      // this step's operands become window row s
-                    const int slot = jj & (NSLOT - 1);
+                    const int slot = jj % NSLOT;
                     if (ex_lane) { winA[slot * WP + lane] = exa[j]; winB[slot * WP + lane] = exb[j]; }
                     winA[slot * WP + lane + (F - 1)] = sa0[j];
                     winB[slot * WP + lane + (F - 1)] = sb0[j];
@@ -671,7 +672,7 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     constexpr int WINB = F > 1 ? 2 * (F - 1) * (64 + F - 1) * 32 : 0;                                // operand window per wave (bytes)
     unsigned char *win0 = smem + (size_t)(NW - 1) * RING * 64 * 8 + 256;                             // 16-byte aligned behind the progress words
     unsigned long long(*est0)[MC] = reinterpret_cast<unsigned long long(*)[MC]>(win0 + (size_t)NW * WINB);   // [NW][F][MC] edge staging
-    constexpr int TVB = (F + 1) * CH <= 16 ? (F + 1) * CH : 0;                                        // lane-0 values of one chunk per wave (BC shapes)
+    constexpr int TVB = (F + 1) * CH <= 64 ? (F + 1) * CH : 0;                                        // lane-0 values of one chunk per wave (BC shapes)
     unsigned long long *tvb0 = reinterpret_cast<unsigned long long *>(est0 + (size_t)NW * F);         // [NW][TVB]
     unsigned &s_ticket = lprog[NW];
     const int lane = threadIdx.x & 63;
@@ -860,11 +861,12 @@ static int band_shape(int K, int nb) {
     // default: batches (>= 8 systems in lockstep: the two kernels tie at 8, and the band kernel leaves most CUs to a second stream) take
     // the band kernel, single solves the task kernel whose K stages
     // spread over K CUs (shorter critical path); SFA_SOR_BAND = 0 (never) / 1..3 (always, that many fused sweeps)
-    int F = nb >= 8 ? 3 : 0;
+    int F = nb >= 8 ? 5 : 0;                                 // round 2: with buffer addressing the 6-stage shape (5 sweeps per wave) beats the 10-stage one by 5-7 %
     if (const char *e = getenv("SFA_SOR_BAND")) F = atoi(e);
-    if (F <= 0 || F > 5 || F == 4) return 0;
-    auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f <= (f == 5 ? 6 : f == 3 ? 10 : 16); };
+    if (F <= 0 || F > 6 || F == 4) return 0;
+    auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f <= (f == 6 ? 5 : f == 5 ? 6 : f == 3 ? 10 : 16); };
     if (fits(F)) return F;
+    if (fits(5)) return 5;
     if (fits(3)) return 3;
     if (fits(2)) return 2;
     if (fits(1)) return 1;
@@ -877,11 +879,23 @@ static int band_shape(int K, int nb) {
 #ifndef SFA_BAND_CH3
 #define SFA_BAND_CH3 4
 #endif
-constexpr int band_ch(int F) { return F == 3 ? SFA_BAND_CH3 : F == 5 ? 4 : 2; }
+#ifndef SFA_BAND_CH2
+#define SFA_BAND_CH2 2
+#endif
+#ifndef SFA_BAND_CH5
+#define SFA_BAND_CH5 4
+#endif
+constexpr int band_ch(int F) { return F == 3 ? SFA_BAND_CH3 : F == 5 ? SFA_BAND_CH5 : F == 6 ? 5 : F == 2 ? SFA_BAND_CH2 : 2; }
 #ifndef SFA_BAND_MC3
 #define SFA_BAND_MC3 12
 #endif
-constexpr int band_mc(int F) { return F == 3 ? SFA_BAND_MC3 : 8; }
+#ifndef SFA_BAND_MC2
+#define SFA_BAND_MC2 8
+#endif
+#ifndef SFA_BAND_MC5
+#define SFA_BAND_MC5 8
+#endif
+constexpr int band_mc(int F) { return F == 3 ? SFA_BAND_MC3 : F == 2 ? SFA_BAND_MC2 : F == 5 ? SFA_BAND_MC5 : F == 6 ? 10 : 8; }
 static int band_ring(int F) { return F == 2 ? 8 : 16; }      // LDS ring slots per wave pair, power of two
 static size_t band_window(int F) { return F > 1 ? (size_t)2 * (F - 1) * (64 + F - 1) * 32 : 0; }   // operand window bytes per wave
 
@@ -989,9 +1003,10 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(band_ch(ws.F) + 2, std::min(atoi(e), band_ring(ws.F)));
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
-        const size_t tvb = (ws.F + 1) * band_ch(ws.F) <= 16 ? (size_t)(ws.F + 1) * band_ch(ws.F) * 8 : 0;            // lane-0 values, one chunk per wave
+        const size_t tvb = (ws.F + 1) * band_ch(ws.F) <= 64 ? (size_t)(ws.F + 1) * band_ch(ws.F) * 8 : 0;            // lane-0 values, one chunk per wave
         const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F) + (size_t)ws.NG * ws.F * band_mc(ws.F) * 8 + ws.NG * tvb;
-        if (ws.F == 5)      hipLaunchKernelGGL((k_sor_band<5, 6, band_ch(5), band_mc(5), 16>), bgrid, bblock, lds, c->stream, ba);
+        if (ws.F == 6)      hipLaunchKernelGGL((k_sor_band<6, 5, band_ch(6), band_mc(6), 16>), bgrid, bblock, lds, c->stream, ba);
+        else if (ws.F == 5) hipLaunchKernelGGL((k_sor_band<5, 6, band_ch(5), band_mc(5), 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 3) hipLaunchKernelGGL((k_sor_band<3, 10, band_ch(3), band_mc(3), 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, band_ch(2), band_mc(2), 8>), bgrid, bblock, lds, c->stream, ba);
         else                hipLaunchKernelGGL((k_sor_band<1, 16, band_ch(1), band_mc(1), 16>), bgrid, bblock, lds, c->stream, ba);

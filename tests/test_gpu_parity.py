@@ -253,14 +253,15 @@ def test_sor_full_size_and_batch(ctx, oracle):
 SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1"}, "task_f2": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "2"},
                 "task_f3": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "3", "SFA_SOR_CH": "4"},
                 "band_f1": {"SFA_SOR_BAND": "1"}, "band_f2": {"SFA_SOR_BAND": "2"}, "band_f3": {"SFA_SOR_BAND": "3"},
-                "band_f5": {"SFA_SOR_BAND": "5"}}
+                "band_f5": {"SFA_SOR_BAND": "5"}, "band_f6": {"SFA_SOR_BAND": "6"}}
 
 
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))
 @pytest.mark.parametrize("w,h,K", [(67, 45, 6), (130, 98, 12), (300, 70, 30), (64, 200, 6), (1024, 436, 30), (2, 2, 6), (700, 5, 30), (200, 150, 10),
                                    (150, 130, 7), (90, 140, 15), (129, 65, 16), (100, 100, 1), (257, 33, 31)])
 def test_sor_kernel_variants(ctx, oracle, monkeypatch, variant, w, h, K):
-    """every solver kernel (task pipeline with 1/2/3 fused sweeps per wave, band pipeline with 1/2/3) gives the
+    """every solver kernel (task pipeline with 1/2/3 fused sweeps per wave, band pipeline with 1/2/3/5/6: a shape that does not divide K falls back
+    to the next that does) gives the
     raster-order result bit for bit, for each element of a batch of two different systems"""
     for k, v in SOR_VARIANTS[variant].items():
         monkeypatch.setenv(k, v)
