@@ -332,15 +332,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     import torch
+    # one rank per GPU over RCCL ("nccl" is RCCL on ROCm).  SFA_BENCH_BACKEND=gloo is the rehearsal of the same code on fewer GPUs than ranks (the
+    # ranks then share the visible GPUs and exchange over CPU tensors): it exists to run the N>1 path end to end on a one-GPU box, never for a result
+    backend = os.environ.get("SFA_BENCH_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    xdev = "cuda" if backend == "nccl" else "cpu"                 # where the tensors of the timing exchange live
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % ndev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
 
     import threading
-    dev = local_rank if world > 1 else 0
+    dev = (local_rank % ndev) if world > 1 else 0
     S = max(1, args.streams)
     B = args.batch
     if B % S:
@@ -399,10 +407,10 @@ def main():
     from slowflow_amd import shard
     if dist is not None:
         dist.barrier()
-    elapsed_max = shard.max_over_ranks(dist, elapsed, device="cuda")
+    elapsed_max = shard.max_over_ranks(dist, elapsed, device=xdev)
     # the per-window timings of every rank: the only exchange of the path (a few hundred bytes over RCCL)
     lo, hi = shard.partition(B * world, world, rank)
-    window_seconds = shard.gather_timings(dist, {i: elapsed / args.steps / B for i in range(lo, hi)}, B * world, device="cuda")
+    window_seconds = shard.gather_timings(dist, {i: elapsed / args.steps / B for i in range(lo, hi)}, B * world, device=xdev)
 
     # SOR-only: the metric's own kernel at 1024x436, same batch, HIP events on the launch stream
     n1 = ms1 = by1 = n2 = ms2 = by2 = 0
@@ -423,7 +431,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 1024x436, S=2 (3 frames), 5 pyramid levels, 5 outer x 1 inner x 30 SOR sweeps, "
                                    "symmetric window, modified-L1 penalties, thresholds off",
                        "frame_windows_per_gpu": B, "streams": S, "windows_per_launch": BL, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
-                       "parallelism": f"frame-window data parallel x{world}"},
+                       "parallelism": f"frame-window data parallel x{world}" + ("" if backend == "nccl" or world == 1 else f" (REHEARSAL over {backend}: ranks share {ndev} GPU(s))")},
             "roofline": {"bound": "hbm", "kernel": "k_sor_band<5,6,4,8,16> (batched lockstep solves: 6 stages x 5 fused sweeps per 64-row band; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
@@ -467,6 +475,7 @@ def main():
     for c in ctxs:
         c.close()
     if dist is not None:
+        dist.barrier()                                            # nobody tears the group down while rank 0 is still measuring its extras
         dist.destroy_process_group()
 
 
