@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     float(*sZ2)[NM] = reinterpret_cast<float(*)[NM]>(lds + 6 * NM);             // [2 terms][3 ch] Iz = I1-I2, same geometry (aligned 16-byte rows)
     float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM);             // Ix, Iy of the term in work: halo 2 (rows x AT_W1)
     float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM + 3 * N1);
-    static_assert(TY * 65 * 10 <= 12 * NM + 6 * N1, "operand tile must fit the staging block");
+    static_assert(TY * (67 * 8 + 69 * 2) <= 12 * NM + 6 * N1, "operand tile must fit the staging block");
     static_assert(DT_W % 4 == 0 && AT_W1 % 4 == 0 && NM % 4 == 0 && N1 % 4 == 0, "16-byte LDS rows");
     const int b = blockIdx.z;
     // reset the solver's progress words and ticket -- for EVERY window of the launch: the solver that follows runs all of them, also the
@@ -997,9 +997,12 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             else          term_succ<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
         }
     }
-    float4(*tA)[65] = reinterpret_cast<float4(*)[65]>(lds);                     // [TY][65] each; live after the last barrier below
-    float4(*tB)[65] = tA + TY;
-    float2(*tX)[65] = reinterpret_cast<float2(*)[65]>(tB + TY);
+    // row strides chosen for the anti-diagonal read-out below (entry 64*rl + dl of a 65-wide row puts the TY rows of a diagonal into one bank group:
+    // PMC of round 2 showed 37 % of this kernel's LDS cycles in bank conflicts): with 67 float4 / 69 float2 per row the 16 lanes of a b128 pass
+    // (32 of a b64 pass) land on distinct banks
+    float4(*tA)[67] = reinterpret_cast<float4(*)[67]>(lds);                     // [TY][67] each; live after the last barrier below
+    float4(*tB)[67] = tA + TY;
+    float2(*tX)[69] = reinterpret_cast<float2(*)[69]>(tB + TY);
     if (a.op.sa) __syncthreads();                                   // every thread is done with the staged planes
 #pragma unroll
     for (int k = 0; k < NP; k++) {
@@ -1146,7 +1149,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ u
 // along the anti-diagonals (16 consecutive entries = 128 B each, as k_sor_prepare writes them) into LDS and works row-major from there.
 __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ uu, float *__restrict__ vv, float *__restrict__ wx, float *__restrict__ wy,
                                                             const unsigned long long *__restrict__ xs, long ent, int RP, int G, double *__restrict__ partial, Geo g) {
-    __shared__ unsigned long long tX[16][65];
+    __shared__ unsigned long long tX[16][67];                    // 67: the 16 rows of an anti-diagonal land on distinct banks (65 put them all on one: 69 % conflict cycles)
     const int b = blockIdx.z;
     const int tid = threadIdx.y * BX + threadIdx.x;
     const int c0 = blockIdx.x * 64;

@@ -705,9 +705,9 @@ struct PrepArgs {
 // (c,r) entries are written; the zero guards are set once when the workspace is (re)shaped and never touched again.
 constexpr int PT_C = 64, PT_R = 16;
 __global__ void __launch_bounds__(256) k_sor_prepare(PrepArgs p) {
-    __shared__ float4 tA[PT_R][PT_C + 1];
-    __shared__ float4 tB[PT_R][PT_C + 1];
-    __shared__ float2 tX[PT_R][PT_C + 1];
+    __shared__ float4 tA[PT_R][PT_C + 2];            // odd (row stride - 1): the 16 rows of an anti-diagonal on distinct bank groups
+    __shared__ float4 tB[PT_R][PT_C + 2];
+    __shared__ float2 tX[PT_R][PT_C + 3];
     const int job = blockIdx.z;
     const int c0 = blockIdx.x * PT_C, r0 = blockIdx.y * PT_R;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
