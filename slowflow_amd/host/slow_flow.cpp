@@ -7,8 +7,8 @@
 // a pipeline: frames are decoded by a pool of host threads, sent to every GPU once and normalised there (sfa_sequence), every worker
 // keeps ONE resident job for all its batches (device-to-device window copies / run / download), and results go to the output pool (.flo, colour PNG, occlusion images) while the worker
 // already refines its next batch; with two workers per GPU the uploads of one overlap the kernels of the other.
-// Out of scope here (and rejected with a message): the third-party demosaicers (raw_demosaicing 1, 2) and the
-// DeepMatching/EpicFlow initialisation -- third-party code (OpenCV, MATLAB SED, DeepMatching) outside the path.
+// deep_matching 1 initialises the flow with EpicFlow's interpolation (epic.h) of match and edge files found at the reference's locations; producing those files
+// (DeepMatching, the MATLAB SED detector) and the third-party demosaicers (raw_demosaicing 1, 2) are outside this build and reported as such.
 //
 // New, additive keys: gpus (default: all visible), gpu_batch (windows refined in lockstep per job, default 32), gpu_streams
 // (default 2), gpu_device (first device, default 0), io_threads (decode / output pool, default min(16, cores)),
@@ -28,6 +28,7 @@
 #include <thread>
 #include <vector>
 
+#include "epic.h"
 #include "flow_vis.h"
 #include "image.h"
 #include "ingest.h"
@@ -138,6 +139,26 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         end_j = std::min((int)params.Jets, opt.selected_jet + 1);
     }
     if (start_f > end_f) return 0;
+
+    // ---- deep_matching 1 (:744-863): the flow is initialised by EpicFlow's interpolation (epic.h) of DeepMatching matches along SED edges.  The reference starts
+    //      both tools with system() (MATLAB + a binary, third-party); this build reads their outputs from the reference's own locations and says so if they are missing.
+    const bool enable_dm = params.parameter<bool>("deep_matching");
+    auto edges_file = [&](int frame_number) { return params.output + "tmp/edges_" + std::to_string(frame_number) + ".dat"; };                    // :740-741
+    auto matches_file = [&](int a, int b) { return params.output + "tmp/matches_" + std::to_string(a) + "_" + std::to_string(b) + ".dat"; };    // :742-743
+    if (enable_dm) {
+        if (params.parameter<float>("dm_scale", "1.0") != 1.0f) { std::cerr << "deep_matching with dm_scale != 1 is not supported: provide matches and edges at the frames' resolution" << std::endl; return 2; }
+        for (unsigned j = start_j; j < end_j; j++) {
+            const int a = (int)params.sequence_start + (int)j * steps * skip, b = a + ref * skip;
+            const string need[4] = {edges_file(a), edges_file(b), matches_file(a, b), matches_file(b, a)};
+            for (const string &f : need)
+                if (!file_exists(f)) {
+                    std::cerr << "deep_matching 1: " << f << " is missing. The matches come from DeepMatching and the edge maps from the SED detector (matlab/detect_edges.m), "
+                                 "third-party programs this build does not start; place their outputs there (raw float edge map of the frame size; one match 'x1 y1 x2 y2 ...' per line) "
+                                 "and run with -resume or -overwrite, or set deep_matching 0" << std::endl;
+                    return 2;
+                }
+        }
+    }
 
     // ---- read the image sequence (:447-592, without OpenCV: PNG, binary PPM / PGM / PFM): decoded, demosaiced and cropped by the
     //      io pool, one frame per task ----------------------------------------------------------------------------------------------
@@ -309,7 +330,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     // the per-alternation labels (:878-884: <output>tmp/frame_<n>_<alter>.png), with WRITE_FILES verbosity only
     const bool out_alt_occ = out_occ && occ_on && params.verbosity(WRITE_FILES) && params.parameter<int>("slow_flow_niter_alter", "1") > 1;
     if (out_occ) mkdirs(params.output + "occlusion/");                               // :676-677
-    if (out_alt_occ) mkdirs(params.output + "tmp/");
+    if (out_alt_occ || enable_dm) mkdirs(params.output + "tmp/");
 
     std::mutex io_mu;
     std::atomic<bool> failed(false);
@@ -381,9 +402,39 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                     std::vector<int> idx(F);
                     for (int k = 0; k < F; k++) idx[k] = (wd.backward ? f + 3 * steps - k : f + k) - (int)start_f;
                     const float *chw[3] = {channel_weights->c1, channel_weights->c2, channel_weights->c3};
+                    image_t *iwx = nullptr, *iwy = nullptr;
+                    if (enable_dm) {                                                 // :801-863 / :960-1004: EpicFlow's interpolation of the matches, per single frame step
+                        const int a = (int)params.sequence_start + f * skip, b = a + ref * skip;
+                        const color_image_t *un_ref = seq[wd.backward ? f + 2 * ref : f + ref];      // un_im[ref] / un_im_back[ref]: the window's reference frame, not normalised
+                        epic_matches mt;
+                        epic_edges ed;
+                        epic_params_t ep;
+                        epic_params_default(&ep);
+                        ep.pref_nn = 25; ep.nn = 160; ep.coef_kernel = 1.1f;         // :271-275
+                        if (!read_matches((wd.backward ? matches_file(b, a) : matches_file(a, b)).c_str(), mt) ||
+                            !read_edges((wd.backward ? edges_file(b) : edges_file(a)).c_str(), width, height, ed)) rc = SFA_ERR_ARG;
+                        else {
+                            color_image_t *lab = rgb_to_lab(un_ref);
+                            iwx = image_new(width, height); iwy = image_new(width, height);
+                            image_erase(iwx); image_erase(iwy);
+                            const int er = epic(ctx, iwx, iwy, lab, mt, ed, &ep);
+                            color_image_delete(lab);
+                            if (er < 0) rc = SFA_ERR_HIP;
+                            else if (er > 0) { image_erase(iwx); image_erase(iwy); }  // no usable match: start from zero like deep_matching 0
+                            image_mul_scalar(iwx, 1.0f / steps);                    // :842-843
+                            image_mul_scalar(iwy, 1.0f / steps);
+                            if (rc == SFA_OK && params.verbosity(WRITE_FILES) && !wd.backward)     // :845-858
+                                png_write((params.output + "tmp/frame_" + std::to_string(a) + "_INIT.png").c_str(), flowColorImg(iwx, iwy, 0));
+                        }
+                        if (rc != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << "EpicFlow initialisation of jet " << wd.jet << " failed" << std::endl; }
+                    }
                     // only the forward solver gets the channel weights (:876 vs :1018); without raw weighting they are all ones (:597-598), which is
                     // what a NULL pointer means to the library (x * 1.0f is exact: same bits, three planes less to read per pixel)
-                    rc = sfa_job_upload_resident(job, e, seq_dev[wp.gpu], idx.data(), F, nullptr, nullptr, seq[start_f]->stride, (wd.backward || !raw) ? nullptr : chw);
+                    if (rc == SFA_OK)
+                        rc = sfa_job_upload_resident(job, e, seq_dev[wp.gpu], idx.data(), F, iwx ? iwx->data : nullptr, iwy ? iwy->data : nullptr, seq[start_f]->stride,
+                                                     (wd.backward || !raw) ? nullptr : chw);
+                    if (iwx) image_delete(iwx);
+                    if (iwy) image_delete(iwy);
                 }
                 if (rc == SFA_OK) rc = sfa_job_run(job);
                 std::vector<std::shared_ptr<WindowResult>> results;
@@ -478,7 +529,6 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "-jet") && i + 1 < argc) { opt.selected_jet = atoi(argv[++i]); opt.resume_frame = true; }
         else { fprintf(stderr, "unknown argument %s", a); usage(); }
     }
-    if (params.parameter<bool>("deep_matching")) { std::cerr << "deep_matching=1 needs the external DeepMatching/SED/EpicFlow stage: not part of this build (set deep_matching 0)" << std::endl; return 2; }
     const bool raw = params.exists("raw") && params.parameter<bool>("raw");
     if (raw && params.parameter<int>("raw_demosaicing", "0") != 0) {
         std::cerr << "raw_demosaicing 1 (Hamilton-Adams, P. Getreuer) and 2 (OpenCV) are third-party code absent from the reference tree: use raw_demosaicing 0 "

@@ -580,3 +580,75 @@ def test_driver_adaptive_frame_rates_and_alternation_outputs(host_build, tmp_pat
     pgm = open(str(hi / "occlusion" / "frame_10.pgm"), "rb").read()
     assert np.array_equal(rows[:, 1:], np.frombuffer(pgm[-W * H:], dtype=np.uint8).reshape(H, W))
     assert set(np.unique(rows[:, 1:])) <= {0, 255}
+
+
+@pytest.mark.gpu
+def test_driver_deep_matching_initialisation(host_build, tmp_path):
+    """deep_matching 1 (slow_flow.cpp:744-863, 960-1004): with match and edge files at the reference's locations (<output>tmp/matches_<a>_<b>.dat, edges_<n>.dat) the
+    driver initialises every window with EpicFlow's interpolation and refines from there: the .flo equals the binding run from the same initial flow (epic through
+    tests/host/epic_tool.cpp, divided by steps), and a large motion that the zero-initialised refinement cannot reach at one level is recovered."""
+    import slowflow_amd as sfa
+    from synth import texture_frame
+    w, h, jets, S = 128, 96, 1, 2
+    steps = S - 1
+    nframes = 1 + (jets + 2) * steps
+    DX, DY = 9.0, -6.0                                               # large motion: out of reach for a single-level variational refinement from zero
+    frames = [np.clip(np.round(texture_frame(w, h, k, dx=DX, dy=DY)[:, :, :w]), 0, 255) for k in range(nframes)]
+    for k, f in enumerate(frames):
+        write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), f)
+    out = tmp_path / "out"
+    (out / "tmp").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for a, b, sx, sy in ((10, 11, DX, DY), (11, 10, -DX, -DY)):                           # forward and backward matches of the constant translation (+ noise)
+        with open(str(out / "tmp" / ("matches_%d_%d.dat" % (a, b))), "w") as f:
+            for _ in range(500):
+                x, y = rng.uniform(12, w - 13), rng.uniform(8, h - 9)
+                f.write("%.3f %.3f %.3f %.3f 3.1 1\n" % (x, y, x + sx + rng.normal(0, 0.2), y + sy + rng.normal(0, 0.2)))
+    for n in (10, 11):
+        (0.05 + 0.02 * rng.uniform(0, 1, (h, w))).astype(np.float32).tofile(str(out / "tmp" / ("edges_%d.dat" % n)))
+    cfg = tmp_path / "run.cfg"
+    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t1\ndm_scale\t1.0\nverbose\t00001\n"
+                   "slow_flow_S\t%d\nslow_flow_layers\t1\nslow_flow_niter_alter\t1\nslow_flow_niter_outer\t5\nslow_flow_occlusion_reasoning\t0\n"
+                   "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\n" % (tmp_path, tmp_path, jets, S))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    u, v = read_flo(str(out / "f_010.flo"))
+    inner = (slice(10, h - 10), slice(14, w - 14))
+    assert abs(np.median(u[inner]) - DX) < 0.3 and abs(np.median(v[inner]) - DY) < 0.3
+    ub, vb = read_flo(str(out / "f_011_back.flo"))
+    assert abs(np.median(ub[inner]) + DX) < 0.3 and abs(np.median(vb[inner]) + DY) < 0.3
+    assert open(str(out / "tmp" / "frame_10_INIT.png"), "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    # without the initialisation the same schedule stays near zero: it IS the initial flow that carries the motion
+    cfg0 = tmp_path / "run0.cfg"
+    cfg0.write_text(cfg.read_text().replace("deep_matching\t1", "deep_matching\t0").replace("%s/out" % tmp_path, "%s/out0" % tmp_path))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg0), "-overwrite"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0
+    u0, _ = read_flo(str(tmp_path / "out0" / "f_010.flo"))
+    assert abs(np.median(u0[inner]) - DX) > 3.0
+    # the forward window through the binding from the same initial flow
+    exe = _link_host_test(tmp_path, ["epic_tool.cpp"], "epic_tool")
+    st = sfa.stride_of(w)
+    rgb = np.zeros((3, h, st), np.float32); rgb[:, :, :w] = frames[1]
+    rgb.tofile(str(tmp_path / "epic_rgb.bin"))
+    import shutil
+    shutil.copy(str(out / "tmp" / "matches_10_11.dat"), str(tmp_path / "epic_matches.txt"))
+    shutil.copy(str(out / "tmp" / "edges_10.dat"), str(tmp_path / "epic_edges.bin"))
+    r = subprocess.run([exe, str(tmp_path), str(w), str(h), "LA", "0.045", "25", "5.0", "160", "1.1", "0.001", "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ix = np.fromfile(str(tmp_path / "epic_fx.bin"), dtype=np.float32).reshape(h, st) * np.float32(1.0 / steps)
+    iy = np.fromfile(str(tmp_path / "epic_fy.bin"), dtype=np.float32).reshape(h, st) * np.float32(1.0 / steps)
+    ctx = sfa.Context(0)
+    fr = []
+    for f in frames:
+        a = np.zeros((3, h, st), np.float32); a[:, :, :w] = f
+        fr.append(a)
+    avg, std = ctx.normalize(fr, w)
+    p = sfa.default_params()
+    p.S = S; p.layers = 1; p.niter_alter = 1; p.niter_outer = 5; p.occlusion_reasoning = 0; p.thres_outer = 0; p.thres_inner = 0; p.hbit = 0; p.smoothing = 1
+    p.rho[0] = 1; p.omega[0] = 0
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    wx, wy = np.ascontiguousarray(ix), np.ascontiguousarray(iy)
+    ctx.variational(p, wx, wy, fr[0:3], w)
+    assert np.array_equal(u, wx[:, :w] * steps) and np.array_equal(v, wy[:, :w] * steps)
+    ctx.close()
