@@ -432,7 +432,7 @@ def main():
                                    "symmetric window, modified-L1 penalties, thresholds off",
                        "frame_windows_per_gpu": B, "streams": S, "windows_per_launch": BL, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
                        "parallelism": f"frame-window data parallel x{world}" + ("" if backend == "nccl" or world == 1 else f" (REHEARSAL over {backend}: ranks share {ndev} GPU(s))")},
-            "roofline": {"bound": "hbm", "kernel": "k_sor_band<5,6,4,8,16> (batched lockstep solves: 6 stages x 5 fused sweeps per 64-row band; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_sor_band_mixed<4,6,3,2,4,12,16> (batched lockstep solves: 8 pipeline stages of 4,4,4,4,4,4,3,3 fused sweeps per 64-row band; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
                          "algorithmic_bytes_per_launch": round(sor_bytes / max(n_sor, 1)),

@@ -32,6 +32,9 @@
 namespace sfa {
 
 constexpr unsigned kSpinLimit = 1u << 22;
+#ifndef SFA_BAND_STARTLAG
+#define SFA_BAND_STARTLAG 2          // macro chunks a band starts behind the strictly needed progress of the band above (see the prologue of band_wave)
+#endif
 #ifndef SFA_PUBLISH_VMCNT
 #define SFA_PUBLISH_VMCNT (2 * CH - 1)
 #endif
@@ -386,12 +389,12 @@ namespace sfa {
 //     (BC shapes) instead of one row-shift DPP per value and step;
 //   * the only lane-masked regions left in a step (lane 63's edge staging, the window's extra positions) sit behind the arithmetic and in
 //     front of plain LDS / memory instructions, so no hazard nops are needed between an exec write and the next step's DPP block.
-template <int F, int CH, int MC, int RING, int ROLE>
+// FP: sweeps of the PREVIOUS stage (stages may differ in width: k_sor_band_mixed); k0: first sweep of this stage
+template <int F, int CH, int MC, int RING, int ROLE, int FP = F>
 __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long (*ring)[RING][64], unsigned *lprog, unsigned char *win, unsigned long long (*estage)[MC],
-                                          unsigned long long *tvbuf, int job, int b, int wave, int lane) {
+                                          unsigned long long *tvbuf, int job, int b, int wave, int lane, int k0) {
     constexpr bool FIRST = ROLE == 0 || ROLE == 3, LASTW = ROLE == 2 || ROLE == 3;
     constexpr int NQ = MC / CH;
-    const int k0 = wave * F;
     const int W = a.W, H = a.H, RP = a.RP, NMC = a.NCH, NSP = a.NS;   // NS: steps padded to a multiple of MC
     const float omega = a.omega;
     const int r0 = 64 * b - k0;
@@ -460,7 +463,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     unsigned long long xb[CH], xr[CH], tv = 0;
     unsigned known_up = 0, known_up2 = 0, pend_up = 0, pend_up2 = 0;
     auto need_up = [&](int m) { return (unsigned)min(m + 1 + (64 + MC - 1) / MC, NMC); };
-    auto need_up2 = [&](int m) { return (unsigned)min(m + 1 + (64 + F + MC - 1) / MC, NMC); };
+    auto need_up2 = [&](int m) { return (unsigned)min(m + 1 + (64 + FP + MC - 1) / MC, NMC); };     // the band above's PREVIOUS stage: its last sweep is FP - 1 columns behind
     auto ready = [&](int m) { return !has_up || (known_up >= need_up(m) && (FIRST || known_up2 >= need_up2(m))); };
 
 #ifdef SFA_BAND_TIMING
@@ -475,9 +478,9 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     if (has_up) {
         // start one macro chunk further behind the band above than strictly needed: its progress is seen one macro chunk
         // stale and published one late; at equal speed the lag of the start is the lag of the whole run
-        known_up = wait_ge(g_up, need_up(2), a.err);
+        known_up = wait_ge(g_up, need_up(SFA_BAND_STARTLAG), a.err);
         if (known_up == 0xffffffffu) return;
-        if (!FIRST) { known_up2 = wait_ge(g_up2, need_up2(2), a.err); if (known_up2 == 0xffffffffu) return; }
+        if (!FIRST) { known_up2 = wait_ge(g_up2, need_up2(SFA_BAND_STARTLAG), a.err); if (known_up2 == 0xffffffffu) return; }
     }
 #pragma unroll
     for (int j = 0; j < CH; j++) {
@@ -522,12 +525,12 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                 if (!FIRST) pend_up2 = __hip_atomic_load(g_up2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (!FIRST) {                                        // the previous stage: its last iterate through the LDS ring
-                const unsigned need = (unsigned)min(s0 + CH - 1 + F, NSP);
+                const unsigned need = (unsigned)min(s0 + CH - 1 + FP, NSP);
                 SFA_T0();
                 if (!wait_lds_ge(&lprog[wave - 1], need, a.err)) return;
                 SFA_T1(t_up);
 #pragma unroll
-                for (int j = 0; j < CH; j++) xb[j] = ring[wave - 1][(s0 + j + F - 1) & (RING - 1)][lane];
+                for (int j = 0; j < CH; j++) xb[j] = ring[wave - 1][(s0 + j + FP - 1) & (RING - 1)][lane];
             }
             if (!LASTW) {                                        // back-pressure: do not overrun slots wave+1 has not read
                 const int need = s0 + CH - 1 - a.lead - F + 2;
@@ -683,10 +686,45 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;                     // band-major tickets
-    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane);
-    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane);
-    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane);
-    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane);
+    if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
+    else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
+    else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
+    else                       band_wave<F, CH, MC, RING, 1>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
+}
+
+// Stages of two widths: NA stages of FA sweeps followed by NB_ stages of FB sweeps (FA >= FB, NA*FA + NB_*FB = K).  With 8 stages the waves of a workgroup sit
+// two per SIMD; 6 x 4 + 2 x 3 = 30 sweeps puts 8, 8, 7, 7 sweeps on the four SIMDs where the uniform 6 x 5 shape puts 10, 10, 5, 5.
+template <int FA, int NA, int FB, int NB_, int CH, int MC, int RING>
+__global__ void __launch_bounds__((NA + NB_) * 64) k_sor_band_mixed(BandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW = NA + NB_;
+    static_assert(FA >= FB && NB_ >= 1 && NA >= 2, "shape");
+    unsigned long long(*ring)[RING][64] = reinterpret_cast<unsigned long long(*)[RING][64]>(smem);   // [NW-1][RING][64]
+    unsigned *lprog = reinterpret_cast<unsigned *>(smem + (size_t)(NW - 1) * RING * 64 * 8);
+    constexpr int WINA = 2 * (FA - 1) * (64 + FA - 1) * 32, WINB_ = FB > 1 ? 2 * (FB - 1) * (64 + FB - 1) * 32 : 0;
+    unsigned char *win0 = smem + (size_t)(NW - 1) * RING * 64 * 8 + 256;
+    unsigned long long(*est0)[MC] = reinterpret_cast<unsigned long long(*)[MC]>(win0 + (size_t)NA * WINA + (size_t)NB_ * WINB_);   // [NW][FA][MC]
+    constexpr int TVB = (FA + 1) * CH;
+    unsigned long long *tvb0 = reinterpret_cast<unsigned long long *>(est0 + (size_t)NW * FA);                                   // [NW][TVB]
+    unsigned &s_ticket = lprog[NW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * NW, 1u);
+    if (threadIdx.x < NW) lprog[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
+    if (t >= (unsigned)(a.nb * a.NB)) return;
+    const int job = t % a.nb, b = t / a.nb;
+    unsigned char *win = wave < NA ? win0 + (size_t)wave * WINA : win0 + (size_t)NA * WINA + (size_t)(wave - NA) * WINB_;
+    unsigned long long(*est)[MC] = est0 + (size_t)wave * FA;
+    unsigned long long *tvb = tvb0 + (size_t)wave * TVB;
+    const int k0 = wave < NA ? wave * FA : NA * FA + (wave - NA) * FB;
+    if (wave == 0)                   band_wave<FA, CH, MC, RING, 0, FA>(a, ring, lprog, win, est, tvb, job, b, wave, lane, k0);
+    else if (wave < NA)              band_wave<FA, CH, MC, RING, 1, FA>(a, ring, lprog, win, est, tvb, job, b, wave, lane, k0);
+    else if (wave == NA && NB_ == 1) band_wave<FB, CH, MC, RING, 2, FA>(a, ring, lprog, win, est, tvb, job, b, wave, lane, k0);
+    else if (wave == NA)             band_wave<FB, CH, MC, RING, 1, FA>(a, ring, lprog, win, est, tvb, job, b, wave, lane, k0);
+    else if (wave == NW - 1)         band_wave<FB, CH, MC, RING, 2, FB>(a, ring, lprog, win, est, tvb, job, b, wave, lane, k0);
+    else                             band_wave<FB, CH, MC, RING, 1, FB>(a, ring, lprog, win, est, tvb, job, b, wave, lane, k0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -861,8 +899,10 @@ static int band_shape(int K, int nb) {
     // default: batches (>= 8 systems in lockstep: the two kernels tie at 8, and the band kernel leaves most CUs to a second stream) take
     // the band kernel, single solves the task kernel whose K stages
     // spread over K CUs (shorter critical path); SFA_SOR_BAND = 0 (never) / 1..3 (always, that many fused sweeps)
-    int F = nb >= 8 ? 5 : 0;                                 // round 2: with buffer addressing the 6-stage shape (5 sweeps per wave) beats the 10-stage one by 5-7 %
+    int F = nb >= 8 ? 43 : 0;                                // round 2: 8 stages of 4,4,4,4,4,4,3,3 sweeps (two waves and 8,8,7,7 sweeps per SIMD) for K = 30, else the 6-stage shape
+                                                             // (5 sweeps per wave), which with buffer addressing beats the 10-stage one by 5-7 %
     if (const char *e = getenv("SFA_SOR_BAND")) F = atoi(e);
+    if (F == 43) { if (K == 30) return 43; F = 5; }           // 6 x 4 + 2 x 3 sweeps: K = 30 only; otherwise the uniform shapes
     if (F <= 0 || F > 6 || F == 4) return 0;
     auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f <= (f == 6 ? 5 : f == 5 ? 6 : f == 3 ? 10 : 16); };
     if (fits(F)) return F;
@@ -913,12 +953,13 @@ static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
 int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     int F_, CH_;
     const int band_ = band_shape(K_, nb_);
-    if (band_) { F_ = band_; CH_ = band_mc(band_); }
+    if (band_ == 43) { F_ = 4; CH_ = 12; }                   // mixed shape: widest stage 4 sweeps, macro chunk 12
+    else if (band_) { F_ = band_; CH_ = band_mc(band_); }
     else sor_shape(K_, nb_ * ((h_ + K_ - 1 + 63) / 64) * K_, F_, CH_);
     if (ctx == c && w == w_ && h == h_ && K == K_ && nb == nb_ && F == F_ && CHK == CH_ && band == band_) return SFA_OK;
     ctx = c; w = w_; h = h_; K = K_; nb = nb_; F = F_; CHK = CH_; band = band_;
     NB = (h + K - 1 + 63) / 64;
-    NG = (K + F - 1) / F;
+    NG = band == 43 ? 8 : (K + F - 1) / F;
     G = K + 64;
     RP = round_up(h + 2 * G, 16);
     NS = w + 63 + F - 1;
@@ -1005,7 +1046,10 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
         const size_t tvb = (ws.F + 1) * band_ch(ws.F) <= 64 ? (size_t)(ws.F + 1) * band_ch(ws.F) * 8 : 0;            // lane-0 values, one chunk per wave
         const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F) + (size_t)ws.NG * ws.F * band_mc(ws.F) * 8 + ws.NG * tvb;
-        if (ws.F == 6)      hipLaunchKernelGGL((k_sor_band<6, 5, band_ch(6), band_mc(6), 16>), bgrid, bblock, lds, c->stream, ba);
+        if (ws.band == 43) {
+            const size_t lds43 = (size_t)7 * 16 * 64 * 8 + 256 + 6 * (size_t)(2 * 3 * 67 * 32) + 2 * (size_t)(2 * 2 * 66 * 32) + (size_t)8 * 4 * 12 * 8 + (size_t)8 * 5 * 4 * 8;
+            hipLaunchKernelGGL((k_sor_band_mixed<4, 6, 3, 2, 4, 12, 16>), bgrid, bblock, lds43, c->stream, ba);
+        } else if (ws.F == 6) hipLaunchKernelGGL((k_sor_band<6, 5, band_ch(6), band_mc(6), 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 5) hipLaunchKernelGGL((k_sor_band<5, 6, band_ch(5), band_mc(5), 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 3) hipLaunchKernelGGL((k_sor_band<3, 10, band_ch(3), band_mc(3), 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, band_ch(2), band_mc(2), 8>), bgrid, bblock, lds, c->stream, ba);

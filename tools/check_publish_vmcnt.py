@@ -32,7 +32,7 @@ def isa():
 def kernels(lines):
     cur, body = None, []
     for l in lines:
-        m = re.match(r"^(_ZN3sfa10k_sor_band\S*):", l)
+        m = re.match(r"^(_ZN3sfa1[06]k_sor_band\S*):", l)
         if m:
             cur, body = m.group(1), []
         elif cur and ".end_amdhsa_kernel" in l:
@@ -84,8 +84,8 @@ def main():
     total = 0
     for name, body in kernels(isa()):
         res = check(name, body)
-        shape = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
-        tag = "k_sor_band<%s>" % ",".join(shape.groups()) if shape else name
+        shape = re.findall(r"Li(\d+)E", name)
+        tag = ("k_sor_band_mixed<%s>" if "mixed" in name else "k_sor_band<%s>") % ",".join(shape) if shape else name
         for n, cnt in res:
             total += 1
             ok = cnt is not None and cnt >= n   # <= n outstanding and >= n issued after the store: the store is not among them
