@@ -401,7 +401,8 @@ void launch_smoothness(sfa_ctx *c, const Geo &g, int method, float *sh, float *s
 //   b = (((b - th[x-1]) + th[x]) - tv[y-1]) + tv[y],   th[x] = wh[x]*(src[x+1]-src[x]), tv likewise,
 // with absent border terms skipped (not added as zero).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float laplacian_gather(float bval, const PlaneAcc &src, const PlaneAcc &wh, const PlaneAcc &wv, int x, int y, int w, int h) {
+template <class SrcAcc>
+__device__ __forceinline__ float laplacian_gather(float bval, const SrcAcc &src, const SrcAcc &wh, const SrcAcc &wv, int x, int y, int w, int h) {
     const float c = src(x, y);
     if (x > 0) bval -= wh(x - 1, y) * (c - src(x - 1, y));
     if (x < w - 1) bval += wh(x, y) * (src(x + 1, y) - c);
@@ -563,6 +564,13 @@ void launch_fill(sfa_ctx *c, float *p, size_t n, float v) {
 // (variational_aux_mt.cpp:166-403, 408-634; call order of variational_mt.cpp:343-361) accumulated in
 // registers in the reference's order, then sub_laplacian(b1,uu), (b2,vv) (:364-365), one store per plane.
 // ---------------------------------------------------------------------------------------------------
+#ifdef SFA_X_ROWS
+#define SFA_X_ROWCOND && ly < SFA_X_ROWS
+#define SFA_X_ROWCOND2 || ly >= SFA_X_ROWS
+#else
+#define SFA_X_ROWCOND
+#define SFA_X_ROWCOND2
+#endif
 #define DATANORM (0.1f * 0.1f)   // variational_aux_mt.h:23
 
 struct Acc { float a11, a12, a22, b1, b2; };
@@ -818,6 +826,10 @@ void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const floa
 // on the fly from the occlusion plane.  Same operations in the same order as the unfused kernels: bit-identical.
 // ---------------------------------------------------------------------------------------------------
 constexpr int AT_W1 = DT_X + 4;                                      // halo-2 planes
+struct Tile1Acc {     // a staged plane of DT_W columns whose first entry is pixel (x0, y0)
+    const float *t; int x0, y0;
+    __device__ __forceinline__ float operator()(int x, int y) const { return t[(y - y0) * DT_W + (x - x0)]; }
+};
 struct Tile2Acc {
     const float *t; int x0, y0;      // global coordinates of the halo-2 origin
     __device__ __forceinline__ float operator()(int x, int y) const { return t[(y - y0) * AT_W1 + (x - x0)]; }
@@ -828,6 +840,18 @@ __device__ __forceinline__ float d5x_in(const float *t, int c) { return tap5(t[c
 template <int W>
 __device__ __forceinline__ float d5y_in(const float *t, int c) { return tap5(t[c - 2 * W], t[c - W], t[c], t[c + W], t[c + 2 * W]); }
 
+#ifdef SFA_ASM_TIMING
+__device__ unsigned long long g_asm_timing[16];
+} // namespace sfa
+extern "C" int sfa_debug_asm_timing(unsigned long long *out, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sfa::g_asm_timing), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sfa::g_asm_timing), sizeof(unsigned long long) * 16);
+}
+namespace sfa {
+#define AT_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); at_acc[i] += n_ - at_t; at_t = n_; } while (0)
+#else
+#define AT_MARK(i)
+#endif
 // TY rows x 64 columns per block of NT threads (NT/64 rows in flight, TY*64/NT pixels per thread).
 // Column borders: the staged planes carry REPLICATED columns outside the image, so the clamped taps of image.c:501-516
 // become fixed LDS offsets.  Row borders use folded coefficients (different expressions, image.c:433-457): rows are
@@ -847,8 +871,14 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     float(*sZ2)[NM] = reinterpret_cast<float(*)[NM]>(lds + 6 * NM);             // [2 terms][3 ch] Iz = I1-I2, same geometry (aligned 16-byte rows)
     float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM);             // Ix, Iy of the term in work: halo 2 (rows x AT_W1)
     float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM + 3 * N1);
-    static_assert(TY * (67 * 8 + 69 * 2) <= 12 * NM + 6 * N1, "operand tile must fit the staging block");
+    // the smoothness-side operands of the epilogue (uu, vv, sh, sv with a halo of one) take the place of the M planes once the last term's Ix, Iy exist
+    constexpr int GR = TY + 2, NGQ = 4 * GR * (DT_W / 4), NGF = 4 * GR * DT_W;
+    static_assert(NGF <= 6 * NM, "the epilogue's operand planes replace the M planes");
+    static_assert(NGF + TY * (67 * 8 + 69 * 2) <= 12 * NM + 6 * N1, "operand tile must fit the staging block");
     static_assert(DT_W % 4 == 0 && AT_W1 % 4 == 0 && NM % 4 == 0 && N1 % 4 == 0, "16-byte LDS rows");
+#ifdef SFA_ASM_TIMING
+    unsigned long long at_acc[14] = {0}, at_t = __builtin_readcyclecounter();
+#endif
     const int b = blockIdx.z;
     // reset the solver's progress words and ticket -- for EVERY window of the launch: the solver that follows runs all of them, also the
     // passengers whose operands this launch leaves alone (Geo::active), and draws its tickets from window 0's block whoever is active
@@ -888,40 +918,94 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         fwd[k] = __fdiv_rn((oc <= 0.0f) ? 1.0f : 0.0f, factor);
     }
     constexpr int QM = DT_W / 4, Q1 = AT_W1 / 4;                     // float4 quads per staged row
+    // global -> LDS by DMA like the image quads: rows y-1 .. y+TY of the four planes, the 18 aligned quads that cover columns x0 .. x0+71.  Quads outside
+    // the planes are skipped; the border rules of the gather never read them.
+    const bool need_g = a.do_laplacian || a.op.sa;
+    auto stage_epilogue_operands = [&]() {
+        if (!need_g) return;
+        for (int i0 = 0; i0 < NGQ; i0 += NT) {
+            const int item = i0 + (int)threadIdx.x;
+            const int q = item % QM, row = (item / QM) % GR, pl = item / (QM * GR);
+            const int gy = y0 + DT_H - 1 + row, gx = x0 + 4 * q;
+            const float *src = pl == 0 ? uu : pl == 1 ? vv : pl == 2 ? sh : sv;
+            if (item < NGQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.pitch && (pl >= 2 || a.do_laplacian))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + eb + (size_t)gy * g.pitch + gx),
+                                                 (__attribute__((address_space(3))) void *)(lds + 4 * (i0 + 64 * ty)), 16, 0, 0);
+        }
+    };
+    AT_MARK(13);
+    if (a.n == 0) stage_epilogue_operands();
     for (int t = 0; t < a.n; t++) {
         const Term &T = a.t[t];
         const int ub = t & 1;                                      // staging buffer of this term
         float(*sM)[NM] = sM2 + 3 * ub;
         float(*sZ)[NM] = sZ2 + 3 * ub;
         if (ub == 0) {
-        __syncthreads();                                           // the staged planes are free again
+        AT_MARK(0);
+        if (t > 0) __syncthreads();                                // the staged planes are free again
+        AT_MARK(1);
         // stage 0 for this term and the next: M and Iz (halo 4) of the three channels, one float4 of a row per item; columns outside
         // the image are replicated (clamped source column), rows outside are never read
+        // The raw image quads go global -> LDS by DMA (no register staging: at this kernel's VGPR budget a register pipeline spills, and the
+        // plain load -> convert -> store loop exposed one HBM round trip per item).  Four image sets of three planes: I1, I2 of this term into the
+        // M / Iz planes of buffer 0, those of the next term into buffer 1; a set's quad order == its LDS order, so a wave-instruction's 64 quads
+        // land on 64 consecutive 16-byte slots.  An image that both terms use (the reference frame: I2 of the backward pair is I1 of the forward
+        // pair) is fetched once.  A second pass converts in place.
         const int npair = t + 1 < a.n ? 2 : 1;
-        for (int item = threadIdx.x; item < npair * TR * 3 * QM; item += NT) {
-            const int q = item % QM, ch = (item / QM) % 3, ly = (item / (3 * QM)) % TR, uu_ = item / (TR * 3 * QM);
-            const Term &TT = a.t[t + uu_];
-            const float *pa = base + eb + TT.i1_off, *pb = base + eb + TT.i2_off;
-            float(*sM)[NM] = sM2 + 3 * uu_;
-            float(*sZ)[NM] = sZ2 + 3 * uu_;
-            const int gy = y0 + ly, gx = x0 + 4 * q;
-            if (gy < 0 || gy >= g.h) continue;
-            const float *ra = pa + ch * g.pl + (size_t)gy * g.pitch, *rb = pb + ch * g.pl + (size_t)gy * g.pitch;
-            float4 va, vb;
-            if (gx >= 0 && gx + 3 < g.w) {
-                va = *reinterpret_cast<const float4 *>(ra + gx);
-                vb = *reinterpret_cast<const float4 *>(rb + gx);
-            } else {
-                const int c0 = clampi(gx, 0, g.w - 1), c1 = clampi(gx + 1, 0, g.w - 1), c2 = clampi(gx + 2, 0, g.w - 1), c3 = clampi(gx + 3, 0, g.w - 1);
-                va = make_float4(ra[c0], ra[c1], ra[c2], ra[c3]);
-                vb = make_float4(rb[c0], rb[c1], rb[c2], rb[c3]);
+        constexpr int NSQ = 3 * TR * QM, NSI = (NSQ + 63) / 64;        // quads / wave-instructions per image set
+        const Term &T0 = a.t[t], &T1 = a.t[t + npair - 1];
+        // where the next term's I1 / I2 come from: 0 this term's I1, 1 this term's I2, 2 own fetch
+        const int from_a = npair == 2 ? (T1.i1_off == T0.i1_off ? 0 : T1.i1_off == T0.i2_off ? 1 : 2) : 0;
+        const int from_b = npair == 2 ? (T1.i2_off == T0.i1_off ? 0 : T1.i2_off == T0.i2_off ? 1 : 2) : 0;
+        const long set_src[4] = {T0.i1_off, T0.i2_off, T1.i1_off, T1.i2_off};
+        const int set_dst[4] = {0, 6 * NM, 3 * NM, 9 * NM};
+#pragma unroll
+        for (int set = 0; set < 4; set++) {
+            if (set >= 2 && (npair == 1 || (set == 2 ? from_a : from_b) != 2)) continue;
+            for (int part = ty; part < NSI; part += NR) {              // one wave-instruction per part
+                const int k = part * 64 + tx;
+                const int q = k % QM, ly = (k / QM) % TR, ch = k / (QM * TR);
+                const int gy = y0 + ly, gx = x0 + 4 * q;
+                if (k < NSQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.w SFA_X_ROWCOND)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(base + eb + set_src[set] + (size_t)ch * g.pl + (size_t)gy * g.pitch + gx),
+                        (__attribute__((address_space(3))) void *)(lds + set_dst[set] + 256 * part), 16, 0, 0);      // the hardware adds 16 bytes per lane
             }
-            *reinterpret_cast<float4 *>(&sM[ch][ly * DT_W + 4 * q]) =
-                make_float4(0.5f * (vb.x + va.x), 0.5f * (vb.y + va.y), 0.5f * (vb.z + va.z), 0.5f * (vb.w + va.w));        // variational_mt.cpp:120
-            *reinterpret_cast<float4 *>(&sZ[ch][ly * DT_W + 4 * q]) = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);   // :122
         }
+        AT_MARK(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AT_MARK(3);
+        __syncthreads();                                           // the DMA of every wave has landed
+        AT_MARK(4);
+        for (int item = threadIdx.x; item < NSQ; item += NT) {     // both terms of the pair in one item: the shared image is read before it is overwritten
+            const int q = item % QM, ly = (item / QM) % TR, ch = item / (QM * TR);
+            const int gy = y0 + ly, gx = x0 + 4 * q;
+            if (gy < 0 || gy >= g.h SFA_X_ROWCOND2) continue;
+            const bool interior = gx >= 0 && gx + 3 < g.w;
+            const float *row = base + eb + ch * g.pl + (size_t)gy * g.pitch;
+            auto fetch = [&](long src_off, int lds_off) {          // columns outside the image: replicated (clamped source column)
+                if (interior) return *reinterpret_cast<const float4 *>(lds + lds_off + 4 * item);
+                const float *r = row + src_off;
+                return make_float4(r[clampi(gx, 0, g.w - 1)], r[clampi(gx + 1, 0, g.w - 1)], r[clampi(gx + 2, 0, g.w - 1)], r[clampi(gx + 3, 0, g.w - 1)]);
+            };
+            auto convert = [&](const float4 &va, const float4 &vb, int lds_off) {
+                *reinterpret_cast<float4 *>(lds + lds_off + 4 * item) =
+                    make_float4(0.5f * (vb.x + va.x), 0.5f * (vb.y + va.y), 0.5f * (vb.z + va.z), 0.5f * (vb.w + va.w));        // variational_mt.cpp:120
+                *reinterpret_cast<float4 *>(lds + 6 * NM + lds_off + 4 * item) = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);   // :122
+            };
+            const float4 a0 = fetch(T0.i1_off, 0), b0 = fetch(T0.i2_off, 6 * NM);
+            if (npair == 2) {
+                const float4 a1 = from_a == 0 ? a0 : from_a == 1 ? b0 : fetch(T1.i1_off, 3 * NM);
+                const float4 b1 = from_b == 0 ? a0 : from_b == 1 ? b0 : fetch(T1.i2_off, 9 * NM);
+                convert(a1, b1, 3 * NM);
+            }
+            convert(a0, b0, 0);
         }
+        AT_MARK(5);
+        }
+        AT_MARK(0);
         __syncthreads();                                           // staged planes complete / the previous term is done with Ix, Iy
+        AT_MARK(6);
         // stage 1: Ix, Iy on the halo-2 region, four columns per item (two aligned quads of M per tap row)
         for (int item = threadIdx.x; item < AT_R1 * 3 * Q1; item += NT) {
             const int q = item % Q1, ch = (item / Q1) % 3, ly = item / (3 * Q1);
@@ -956,7 +1040,18 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             *reinterpret_cast<float4 *>(&sX[ch][ly * AT_W1 + 4 * q]) = make_float4(X[0], X[1], X[2], X[3]);
             *reinterpret_cast<float4 *>(&sY[ch][ly * AT_W1 + 4 * q]) = make_float4(Y[0], Y[1], Y[2], Y[3]);
         }
+        float mk[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) mk[k] = ok[k] ? base[eb + T.mask_off + (size_t)(y0 + DT_H + ty + NR * k) * g.pitch + x] : 0.0f;
+        AT_MARK(7);
         __syncthreads();
+        AT_MARK(8);
+        if (t == a.n - 1) {
+            // no ordinary load may be outstanding while the DMA flies (the compiler would wait for everything at its first use)
+#pragma unroll
+            for (int k = 0; k < NP; k++) asm volatile("" : "+v"(mk[k]));
+            stage_epilogue_operands();
+        }
 #pragma unroll
         for (int k = 0; k < NP; k++) {
             const int y = y0 + DT_H + ty + NR * k;
@@ -991,7 +1086,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 p.ixz[ch] = d5x_in<DT_W>(sZ[ch], cz);                                  // :132
             }
             if (!ok[k]) continue;
-            float m = base[eb + T.mask_off + (size_t)y * g.pitch + x];
+            float m = mk[k];
             if (!a.one_direction || !T.backward) m = T.backward ? 1.0f * bwd[k] * m : 1.0f * fwd[k] * m;   // :314,316
             if (T.is_ref) term_ref<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
             else          term_succ<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
@@ -1000,29 +1095,35 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     // row strides chosen for the anti-diagonal read-out below (entry 64*rl + dl of a 65-wide row puts the TY rows of a diagonal into one bank group:
     // PMC of round 2 showed 37 % of this kernel's LDS cycles in bank conflicts): with 67 float4 / 69 float2 per row the 16 lanes of a b128 pass
     // (32 of a b64 pass) land on distinct banks
-    float4(*tA)[67] = reinterpret_cast<float4(*)[67]>(lds);                     // [TY][67] each; live after the last barrier below
+    float4(*tA)[67] = reinterpret_cast<float4(*)[67]>(lds + NGF);               // [TY][67] each; live after the last barrier below
     float4(*tB)[67] = tA + TY;
     float2(*tX)[69] = reinterpret_cast<float2(*)[69]>(tB + TY);
-    if (a.op.sa) __syncthreads();                                   // every thread is done with the staged planes
+    AT_MARK(0);
+    if (need_g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                            // the DMA has landed / every thread is done with the staged planes
+    }
+    AT_MARK(9);
+    const Tile1Acc U{lds, x0, y0 + DT_H - 1}, V{lds + GR * DT_W, x0, y0 + DT_H - 1}, Hh{lds + 2 * GR * DT_W, x0, y0 + DT_H - 1},
+        Wv{lds + 3 * GR * DT_W, x0, y0 + DT_H - 1};
 #pragma unroll
     for (int k = 0; k < NP; k++) {
         if (!ok[k]) continue;
         const int yl = ty + NR * k, y = y0 + DT_H + yl;
         const size_t o = (size_t)y * g.pitch + x;
         if (a.do_laplacian) {                                                            // variational_mt.cpp:364-365
-            PlaneAcc U{uu + eb, g.pitch}, V{vv + eb, g.pitch}, H{sh + eb, g.pitch}, W{sv + eb, g.pitch};
-            A[k].b1 = laplacian_gather(A[k].b1, U, H, W, x, y, g.w, g.h);
-            A[k].b2 = laplacian_gather(A[k].b2, V, H, W, x, y, g.w, g.h);
+            A[k].b1 = laplacian_gather(A[k].b1, U, Hh, Wv, x, y, g.w, g.h);
+            A[k].b2 = laplacian_gather(A[k].b2, V, Hh, Wv, x, y, g.w, g.h);
         }
         if (!a.op.sa) {
             a11[eb + o] = A[k].a11; a12[eb + o] = A[k].a12; a22[eb + o] = A[k].a22; b1[eb + o] = A[k].b1; b2[eb + o] = A[k].b2;
             continue;
         }
         // k_sor_prepare's per-pixel part (solver.c:101-106,159,214): neighbour weights, inverted 2x2 block
-        const float hp = sh[eb + o];
-        const float hl = x > 0 ? sh[eb + o - 1] : 0.0f;                                  // f1[0] = 0, solver.c:82
-        const float vp = sv[eb + o];
-        const float vt = y > 0 ? sv[eb + o - g.pitch] : 0.0f;
+        const float hp = Hh(x, y);
+        const float hl = x > 0 ? Hh(x - 1, y) : 0.0f;                                    // f1[0] = 0, solver.c:82
+        const float vp = Wv(x, y);
+        const float vt = y > 0 ? Wv(x, y - 1) : 0.0f;
         float dpsis = hl + hp;
         if (y > 0) dpsis = dpsis + vt;
         if (y < g.h - 1) dpsis = dpsis + vp;
@@ -1035,7 +1136,9 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         tX[yl][tx] = make_float2(u[k], v[k]);
     }
     if (!a.op.sa) return;
+    AT_MARK(10);
     __syncthreads();
+    AT_MARK(11);
     // the tile's anti-diagonals: TY consecutive entries of the diagonal-major operand planes each
     const int c0 = x0 + DT_H, r0 = y0 + DT_H;
     for (int item = threadIdx.x; item < (DT_X + TY - 1) * TY; item += NT) {
@@ -1051,6 +1154,11 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         __builtin_memcpy(&xu, &xv, 8);
         a.op.x[e] = xu;
     }
+#ifdef SFA_ASM_TIMING
+    AT_MARK(12);
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 14; i++) atomicAdd(&g_asm_timing[i], at_acc[i]);
+#endif
 }
 void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
@@ -1066,6 +1174,8 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, con
     case 2: SFA_LAUNCH_AI(8, 256, 4); break;
     case 3: SFA_LAUNCH_AI(16, 1024, 4); break;
     case 4: SFA_LAUNCH_AI(16, 512, 4); break;
+    case 5: SFA_LAUNCH_AI(16, 512, 1); break;
+    case 6: SFA_LAUNCH_AI(16, 1024, 1); break;
     default: SFA_LAUNCH_AI(8, 512, 4); break;
     }
 #undef SFA_LAUNCH_AI
@@ -1364,31 +1474,50 @@ void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl,
 }
 
 // One pyramid step in one pass (variational_mt.cpp:607,611): GaussianBlur then resize of `nplanes` planes per window.  A block owns a
-// 64x8 tile of the DESTINATION; the source footprint (+ blur radius, replicated at the image border) is staged in LDS,
+// 64 x td tile of the DESTINATION (td = 32 when the footprint fits LDS: the row pass runs over the footprint plus 2r rows, 1.2x the tile at 32 rows
+// against 1.9x at 8); the source footprint (+ blur radius, replicated at the image border) is staged in LDS,
 // blurred along rows, then along columns, and sampled bilinearly -- the same operations in the same order as k_gauss_h,
 // k_gauss_v, k_resize, without the two intermediate images.
 template <int R>
 __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int dw, int dh, int dpitch, long dpl, long des, const float *__restrict__ src, int sw, int sh,
-                                                  int spitch, long spl, long ses, int nplanes, double scale_x, double scale_y, Taps t, int CM, int RM) {
+                                                  int spitch, long spl, long ses, int nplanes, double scale_x, double scale_y, Taps t, int CM, int RM, int td) {
     extern __shared__ __attribute__((aligned(16))) float pyr_lds[];
     constexpr int r = R;                                              // compile-time radius: the tap loops unroll, the row buffer stays in registers
     const int CS = (CM + 2 * r + 3) / 4 * 4 + 4, RS = RM + 2 * r;       // CM, CS multiples of 4; CS leaves room for the aligned quads of the row pass
     float *S = pyr_lds, *Hb = S + RS * CS, *V = Hb + RS * CM;
     const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
-    const int dx0 = blockIdx.x * 64, dy0 = blockIdx.y * 8;
+    const int dx0 = blockIdx.x * 64, dy0 = blockIdx.y * td;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     // first source column / row any pixel of the tile samples (k_resize's own coordinate arithmetic)
     int mx0 = (int)floorf((float)((dx0 + 0.5) * scale_x - 0.5)), my0 = (int)floorf((float)((dy0 + 0.5) * scale_y - 0.5));
     mx0 = mx0 < 0 ? 0 : mx0; my0 = my0 < 0 ? 0 : my0;
     const float *s = src + b * ses + pl * spl;
-    // (row, column) of a thread's items advance incrementally: one division per thread and loop instead of one per item
+    // staging: S column c is source column mx0 - r + c (replicated outside the image).  The source is read as ALIGNED quads -- one 16-byte load per
+    // item instead of four scalar ones; the scalar version spent over half of the kernel issuing loads -- and scattered into S, which keeps
+    // its own alignment for the row pass.  (row, quad) of a thread's items advance incrementally: one division per thread instead of one per item.
     {
-        int j = tid / CS, c = tid % CS;
-        const int dj = 256 / CS, dc = 256 % CS;
+        const int sx0 = mx0 - r, sxa = sx0 & ~3, off = sx0 - sxa;    // two's complement: & ~3 floors negative columns too
+        const int NQ = (CS + off + 3) / 4;
+        int j = tid / NQ, qa = tid % NQ;
+        const int dj = 256 / NQ, dq = 256 % NQ;
         while (j < RS) {
-            S[j * CS + c] = s[(size_t)clampi(my0 - r + j, 0, sh - 1) * spitch + clampi(mx0 - r + c, 0, sw - 1)];
-            c += dc; j += dj;
-            if (c >= CS) { c -= CS; j++; }
+            const float *row = s + (size_t)clampi(my0 - r + j, 0, sh - 1) * spitch;
+            const int gx = sxa + 4 * qa;
+            float v[4];
+            if (gx >= 0 && gx + 3 < sw) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(row + gx);
+                v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = row[clampi(gx + e, 0, sw - 1)];
+            }
+            float *Sr = S + j * CS;
+            const int c0 = 4 * qa - off;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (c0 + e >= 0 && c0 + e < CS) Sr[c0 + e] = v[e];
+            qa += dq; j += dj;
+            if (qa >= NQ) { qa -= NQ; j++; }
         }
     }
     __syncthreads();
@@ -1440,7 +1569,7 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
     if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
     const int sx1 = sx + 1 < sw ? sx + 1 : sx;
     const float a0 = 1.f - fx, a1 = fx;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < td / 4; k++) {
         const int dy = dy0 + threadIdx.y + 4 * k;
         if (dy >= dh) break;
         float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -1460,14 +1589,20 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
 bool launch_pyr_down(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
                      int nplanes, int nb, const float *taps, int radius) {
     const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
-    const int CM = (((int)ceil(64 * scale_x) + 2) + 3) / 4 * 4, RM = (int)ceil(8 * scale_y) + 2, CS = (CM + 2 * radius + 3) / 4 * 4 + 4, RS = RM + 2 * radius;
-    const size_t lds = (size_t)(RS * CS + RS * CM + RM * CM) * sizeof(float);
+    const int CM = (((int)ceil(64 * scale_x) + 2) + 3) / 4 * 4, CS = (CM + 2 * radius + 3) / 4 * 4 + 4;
+    int td = 32, RM = 0, RS = 0;
+    size_t lds = 0;
+    for (;; td /= 2) {                                               // the tallest tile whose footprint fits
+        RM = (int)ceil(td * scale_y) + 2; RS = RM + 2 * radius;
+        lds = (size_t)(RS * CS + RS * CM + RM * CM) * sizeof(float);
+        if (lds <= 60 * 1024 || td == 8) break;
+    }
     if (lds > 60 * 1024 || radius > 8) return false;
     Taps t;
     t.r = radius;
     for (int i = 0; i < 2 * radius + 1; i++) t.k[i] = taps[i];
-    const dim3 grid((dw + 63) / 64, (dh + 7) / 8, nb * nplanes), block(64, 4);
-#define SFA_PYR(RR) case RR: hipLaunchKernelGGL(k_pyr_down<RR>, grid, block, lds, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes, scale_x, scale_y, t, CM, RM); break
+    const dim3 grid((dw + 63) / 64, (dh + td - 1) / td, nb * nplanes), block(64, 4);
+#define SFA_PYR(RR) case RR: hipLaunchKernelGGL(k_pyr_down<RR>, grid, block, lds, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes, scale_x, scale_y, t, CM, RM, td); break
     switch (radius) {
         SFA_PYR(1); SFA_PYR(2); SFA_PYR(3); SFA_PYR(4); SFA_PYR(5); SFA_PYR(6); SFA_PYR(7); SFA_PYR(8);
     default: return false;

@@ -1,0 +1,8 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/asm_kernel_time.sh <lib.so>...   -> average duration of the assembly and SOR kernels per library (rocprofv3 kernel trace, batch 64)
+cd /tmp && export TMPDIR=/tmp
+for lib in "$@"; do
+  d=$GRAFT_REPO_ROOT/gpurun_out/akt_$(basename $lib .so)
+  SFA_LIB=$lib rocprofv3 --kernel-trace --stats -d $d -o a -f csv -- python3 $GRAFT_REPO_ROOT/tools/bench_kernels.py 64 > /dev/null 2>&1
+  echo "== $(basename $lib)"; python3 $GRAFT_REPO_ROOT/tools/profsum.py $(find $d -name "*kernel_stats.csv") 2
+done
