@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 void rawWeighting(color_image_t *weights, int red_x, int red_y, float weight) {
     weight = fminf(fmaxf(weight, 0.0f), 3.0f);                                        // utils.cpp:1337
@@ -54,6 +55,47 @@ void bayer2rgbGR(const image_t *src, color_image_t *dst, int red_x, int red_y) {
                 else                            { dst->c1[o] = S(y, x); dst->c3[o] = diag; }  // red pixel
             }
         }
+}
+
+void bayer2rgb_cv8u(const image_t *src, color_image_t *dst, int red_x, int red_y) {
+    const int W = src->width, H = src->height;
+    std::vector<int> m((size_t)W * H);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const long v = lrintf(src->data[(size_t)y * src->stride + x]);            // cvRound under the default rounding mode: half to even
+            m[(size_t)y * W + x] = (int)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    auto M = [&](int y, int x) { return m[(size_t)y * W + x]; };
+    auto put = [&](int y, int x, int r, int g, int b) {
+        const size_t o = (size_t)y * dst->stride + x;
+        dst->c1[o] = (float)r; dst->c2[o] = (float)g; dst->c3[o] = (float)b;
+    };
+    auto copy = [&](int y, int x, int ys, int xs) {
+        const size_t o = (size_t)y * dst->stride + x, s = (size_t)ys * dst->stride + xs;
+        dst->c1[o] = dst->c1[s]; dst->c2[o] = dst->c2[s]; dst->c3[o] = dst->c3[s];
+    };
+    if (W < 3 || H < 3) {                                                              // no interior: nothing to interpolate from
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) put(y, x, 0, 0, 0);
+        return;
+    }
+    for (int y = 1; y < H - 1; y++) {
+        const bool red_row = ((y - red_y) & 1) == 0;
+        for (int x = 1; x < W - 1; x++) {
+            const bool red_col = ((x - red_x) & 1) == 0;
+            const int c = M(y, x);
+            if (red_row == red_col) {                                                  // a red or a blue site
+                const int cross = (M(y - 1, x) + M(y + 1, x) + M(y, x - 1) + M(y, x + 1) + 2) >> 2;
+                const int diag = (M(y - 1, x - 1) + M(y - 1, x + 1) + M(y + 1, x - 1) + M(y + 1, x + 1) + 2) >> 2;
+                if (red_row) put(y, x, c, cross, diag); else put(y, x, diag, cross, c);
+            } else {                                                                   // a green site: its row's colour left and right, the other one above and below
+                const int horiz = (M(y, x - 1) + M(y, x + 1) + 1) >> 1, vert = (M(y - 1, x) + M(y + 1, x) + 1) >> 1;
+                if (red_row) put(y, x, horiz, c, vert); else put(y, x, vert, c, horiz);
+            }
+        }
+        copy(y, 0, y, 1);
+        copy(y, W - 1, y, W - 2);
+    }
+    for (int x = 0; x < W; x++) { copy(0, x, 1, x); copy(H - 1, x, H - 2, x); }
 }
 
 color_image_t *color_image_crop(const color_image_t *img, int cx, int cy, int ex, int ey) {

@@ -1,6 +1,7 @@
 // io.cpp -- see io.h
 #include "io.h"
 #include "png.h"
+#include "tiff.h"
 
 #include <cctype>
 #include <cstdio>
@@ -63,10 +64,14 @@ color_image_t *color_image_load(const char *filename, int *maxval_out) {
     FILE *f = fopen(filename, "rb");
     if (!f) { fprintf(stderr, "could not open %s\n", filename); return nullptr; }
     unsigned char sig[4] = {0, 0, 0, 0};
-    if (fread(sig, 1, 4, f) == 4 && sig[0] == 0x89 && sig[1] == 'P' && sig[2] == 'N' && sig[3] == 'G') {   // PNG (what the reference's sequences are stored as)
+    const bool got_sig = fread(sig, 1, 4, f) == 4;
+    const bool is_png = got_sig && sig[0] == 0x89 && sig[1] == 'P' && sig[2] == 'N' && sig[3] == 'G';       // PNG (what the reference's Sintel sequences are stored as)
+    const bool is_tiff = got_sig && ((sig[0] == 'I' && sig[1] == 'I' && sig[2] == 42 && sig[3] == 0) || (sig[0] == 'M' && sig[1] == 'M' && sig[2] == 0 && sig[3] == 42));   // TIFF (cfgs/slow_flow.cfg:5)
+    if (is_png || is_tiff) {
         fclose(f);
         png_image png;
-        if (!png_read(filename, png)) { fprintf(stderr, "%s: not a PNG this reader handles (non-interlaced, 8/16 bit)\n", filename); return nullptr; }
+        if (is_png && !png_read(filename, png)) { fprintf(stderr, "%s: not a PNG this reader handles (non-interlaced, 8/16 bit)\n", filename); return nullptr; }
+        if (is_tiff && !tiff_read(filename, png)) { fprintf(stderr, "%s: not a TIFF this reader handles (strips, 8/16 bit grey or RGB, none / LZW / PackBits)\n", filename); return nullptr; }
         color_image_t *pim = color_image_new(png.width, png.height);
         color_image_erase(pim);
         for (int y = 0; y < png.height; y++)

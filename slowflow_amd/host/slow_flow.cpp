@@ -8,7 +8,7 @@
 // keeps ONE resident job for all its batches (device-to-device window copies / run / download), and results go to the output pool (.flo, colour PNG, occlusion images) while the worker
 // already refines its next batch; with two workers per GPU the uploads of one overlap the kernels of the other.
 // deep_matching 1 initialises the flow with EpicFlow's interpolation (epic.h) of match and edge files found at the reference's locations; producing those files
-// (DeepMatching, the MATLAB SED detector) and the third-party demosaicers (raw_demosaicing 1, 2) are outside this build and reported as such.
+// (DeepMatching, the MATLAB SED detector) and the third-party Hamilton-Adams demosaicer (raw_demosaicing 1) are outside this build and reported as such.
 //
 // New, additive keys: gpus (default: all visible), gpu_batch (windows refined in lockstep per job, default 32), gpu_streams
 // (default 2), gpu_device (first device, default 0), io_threads (decode / output pool, default min(16, cores)),
@@ -121,6 +121,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     const auto t_begin = std::chrono::steady_clock::now();
     const bool raw = params.exists("raw") && params.parameter<bool>("raw");
     const std::vector<int> red_loc = params.splitParameter<int>("raw_red_loc", "0,0");   // :439
+    const int demosaicing = params.parameter<int>("raw_demosaicing", "0");
     const float scale = params.parameter<float>("scale", "1.0");
     const int steps = params.parameter<int>("slow_flow_S") - 1, ref = steps;         // :208-209
     const bool sintel = params.parameter<bool>("sintel", "0");
@@ -184,12 +185,14 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
             pool.submit([&, f] {
                 int maxval = 255;
                 color_image_t *img = color_image_load(names[f].c_str(), &maxval);
-                if (!img) { std::lock_guard<std::mutex> l(err_mu); if (load_error.empty()) load_error = "cannot read frame " + names[f] + " (PNG or binary PPM/PGM/PFM expected)"; return; }
+                if (!img) { std::lock_guard<std::mutex> l(err_mu); if (load_error.empty()) load_error = "cannot read frame " + names[f] + " (PNG, TIFF or binary PPM/PGM/PFM expected)"; return; }
                 if (raw) {                                                           // demosaicing (:482-527): the mosaic is the grey image
                     image_t mosaic = {img->width, img->height, img->stride, img->c1};
                     color_image_t *rgb = color_image_new(img->width, img->height);
                     color_image_erase(rgb);
-                    bayer2rgbGR(&mosaic, rgb, red_loc.size() > 0 ? red_loc[0] : 0, red_loc.size() > 1 ? red_loc[1] : 0);
+                    const int rx = red_loc.size() > 0 ? red_loc[0] : 0, ry = red_loc.size() > 1 ? red_loc[1] : 0;
+                    if (demosaicing == 2) bayer2rgb_cv8u(&mosaic, rgb, rx, ry);          // :502-520
+                    else bayer2rgbGR(&mosaic, rgb, rx, ry);                             // :488-491
                     color_image_delete(img);
                     img = rgb;
                 }
@@ -530,9 +533,10 @@ int main(int argc, char **argv) {
         else { fprintf(stderr, "unknown argument %s", a); usage(); }
     }
     const bool raw = params.exists("raw") && params.parameter<bool>("raw");
-    if (raw && params.parameter<int>("raw_demosaicing", "0") != 0) {
-        std::cerr << "raw_demosaicing 1 (Hamilton-Adams, P. Getreuer) and 2 (OpenCV) are third-party code absent from the reference tree: use raw_demosaicing 0 "
-                     "(the reference's own bilinear / green-ratio routine) or provide demosaiced frames with raw 0" << std::endl;
+    const int demosaicing = params.parameter<int>("raw_demosaicing", "0");
+    if (raw && demosaicing != 0 && demosaicing != 2) {
+        std::cerr << "raw_demosaicing 1 (Hamilton-Adams, P. Getreuer's dmha) is third-party code absent from the reference tree: use raw_demosaicing 0 "
+                     "(the reference's own bilinear / green-ratio routine), 2 (OpenCV's 8-bit bilinear conversion, restated) or provide demosaiced frames with raw 0" << std::endl;
         return 2;
     }
 

@@ -15,6 +15,7 @@
 #include "io.h"
 #include "parameter_list.h"
 #include "png.h"
+#include "tiff.h"
 #include "shard.h"
 #include "variational_mt.h"
 
@@ -324,12 +325,51 @@ int main(int argc, char **argv) {
             color_image_t *rgb = color_image_new(w, h), *cw = color_image_new(w, h);
             color_image_erase(rgb);
             bayer2rgbGR(mosaic, rgb, rx, ry);
+            {                                                    // raw_demosaicing 2: OpenCV's 8-bit bilinear conversion, restated
+                color_image_t *cv = color_image_new(w, h);
+                color_image_erase(cv);
+                bayer2rgb_cv8u(mosaic, cv, rx, ry);
+                std::ofstream o3((tmp + "/bayer_rgb_cv.bin").c_str(), std::ios::binary);
+                o3.write(reinterpret_cast<const char *>(cv->c1), (std::streamsize)((size_t)3 * cv->stride * h * sizeof(float)));
+                color_image_delete(cv);
+            }
             for (size_t i = 0; i < (size_t)3 * cw->stride * h; i++) cw->c1[i] = 1.0f;
             rawWeighting(cw, rx, ry, weight);
             std::ofstream o1((tmp + "/bayer_rgb.bin").c_str(), std::ios::binary), o2((tmp + "/bayer_w.bin").c_str(), std::ios::binary);
             o1.write(reinterpret_cast<const char *>(rgb->c1), (std::streamsize)((size_t)3 * rgb->stride * h * sizeof(float)));
             o2.write(reinterpret_cast<const char *>(cw->c1), (std::streamsize)((size_t)3 * cw->stride * h * sizeof(float)));
             image_delete(mosaic); color_image_delete(rgb); color_image_delete(cw);
+        }
+    }
+    // ---- TIFF (tiff.h): own round trip, and files written by tests/test_host.py with Pillow (decoded there as well) --------------------------
+    {
+        for (int depth = 8; depth <= 16; depth += 8)
+            for (int ch = 1; ch <= 3; ch += 2) {
+                png_image a;
+                a.width = 37; a.height = 21; a.channels = ch; a.depth = depth;
+                a.samples.resize((size_t)a.width * a.height * ch);
+                for (size_t i = 0; i < a.samples.size(); i++) a.samples[i] = (uint16_t)((i * 2654435761u >> 7) & (depth == 16 ? 65535u : 255u));
+                const std::string fn = tmp + "/rt.tif";
+                CHECK(tiff_write(fn.c_str(), a));
+                png_image b;
+                CHECK(tiff_read(fn.c_str(), b));
+                CHECK(b.width == a.width && b.height == a.height && b.channels == ch && b.depth == depth && b.samples == a.samples);
+                int maxval = 0;
+                color_image_t *im = color_image_load(fn.c_str(), &maxval);     // the driver's loader recognises the magic
+                CHECK(im && im->width == a.width && maxval == (depth == 16 ? 65535 : 255) && im->c1[5] == (float)a.samples[5 * ch]);
+                if (im) color_image_delete(im);
+            }
+        std::ifstream list((tmp + "/tiff_list.txt").c_str());
+        std::string name;
+        while (list >> name) {
+            png_image t;
+            const bool ok = tiff_read((tmp + "/" + name).c_str(), t);
+            std::ofstream o((tmp + "/" + name + ".txt").c_str());
+            o << (ok ? 1 : 0) << " " << t.width << " " << t.height << " " << t.channels << " " << t.depth << "\n";
+            if (ok) {
+                std::ofstream ob((tmp + "/" + name + ".bin").c_str(), std::ios::binary);
+                ob.write(reinterpret_cast<const char *>(t.samples.data()), (std::streamsize)(t.samples.size() * sizeof(uint16_t)));
+            }
         }
     }
     printf(fails ? "host tests FAILED (%d)\n" : "host tests OK\n", fails);

@@ -153,6 +153,90 @@ def test_demosaic_and_raw_weights_against_numpy(host_build, tmp_path, rx, ry, we
     assert np.array_equal(cw, raw_weights_numpy(w, h, rx, ry, weight))
 
 
+def bayer_cv8u_numpy(src, rx, ry):
+    """cv::cvtColor(CV_Bayer*2RGB) on 8-bit data as the reference uses it (slow_flow.cpp:502-520), written with whole-array shifts: saturating
+    round-half-even conversion, (4 neighbours + 2) >> 2 / (4 diagonals + 2) >> 2 at red and blue sites, (2 neighbours + 1) >> 1 at green sites,
+    outer rows and columns repeated from their inner neighbours"""
+    m = np.clip(np.rint(src.astype(np.float64)), 0, 255).astype(np.int64)
+    h, w = m.shape
+    c = m[1:-1, 1:-1]
+    up, dn, lf, rt = m[:-2, 1:-1], m[2:, 1:-1], m[1:-1, :-2], m[1:-1, 2:]
+    cross = (up + dn + lf + rt + 2) >> 2
+    diag = (m[:-2, :-2] + m[:-2, 2:] + m[2:, :-2] + m[2:, 2:] + 2) >> 2
+    horiz, vert = (lf + rt + 1) >> 1, (up + dn + 1) >> 1
+    Y, X = np.mgrid[1:h - 1, 1:w - 1]
+    red_row, red_col = (Y - ry) % 2 == 0, (X - rx) % 2 == 0
+    site = red_row == red_col
+    R = np.where(site, np.where(red_row, c, diag), np.where(red_row, horiz, vert))
+    G = np.where(site, cross, c)
+    B = np.where(site, np.where(red_row, diag, c), np.where(red_row, vert, horiz))
+    out = np.zeros((3, h, w), np.int64)
+    out[:, 1:-1, 1:-1] = np.stack([R, G, B])
+    out[:, :, 0] = out[:, :, 1]; out[:, :, -1] = out[:, :, -2]
+    out[:, 0, :] = out[:, 1, :]; out[:, -1, :] = out[:, -2, :]
+    return out.astype(np.float32)
+
+
+@pytest.mark.parametrize("rx,ry", [(1, 0), (0, 0), (0, 1), (1, 1)])
+def test_opencv_style_demosaic_and_tiff_reader(host_build, tmp_path, rx, ry):
+    """raw_demosaicing 2 (OpenCV's 8-bit bilinear Bayer conversion, restated: OpenCV is not in the image) against an independent numpy formulation,
+    and the TIFF reader (the reference cfg's input format) against Pillow/libtiff on files of every compression and layout it accepts"""
+    from PIL import Image
+    w, h = 41, 26
+    st = ((w + 3) // 4) * 4
+    rng = np.random.default_rng(10 + rx + 2 * ry)
+    mosaic = np.zeros((h, st), np.float32)
+    mosaic[:, :w] = rng.uniform(-20, 300, (h, w)).astype(np.float32)
+    mosaic[3, 5:9] = [0.5, 1.5, 2.5, 254.5]                                      # halves round to even
+    mosaic.tofile(str(tmp_path / "bayer_in.bin"))
+    (tmp_path / "bayer.txt").write_text("%d %d %d %d %g\n" % (w, h, rx, ry, 1.0))
+    write_png_cases(tmp_path)
+    # TIFF files: 8 / 16 bit grey and RGB, every compression, several strips; a big-endian one assembled by hand
+    cases = {}
+    g16 = (rng.integers(0, 65536, (53, 70))).astype(np.uint16)
+    g16[10:20] = (np.arange(70) * 7)[None, :]                                    # compressible rows
+    g8 = (g16 >> 8).astype(np.uint8)
+    rgb8 = rng.integers(0, 256, (31, 45, 3)).astype(np.uint8)
+    rgb8[5:15] = 77
+    for comp in (None, "tiff_lzw", "packbits", "tiff_adobe_deflate"):
+        tag = comp or "raw"
+        for name, arr in (("g16", g16), ("g8", g8), ("rgb8", rgb8)):
+            fn = "%s_%s.tif" % (name, tag)
+            kw = {} if comp is None else {"compression": comp}
+            Image.fromarray(arr).save(str(tmp_path / fn), **kw)
+            cases[fn] = arr
+    fn = "g16_lzw_pred.tif"
+    Image.fromarray(g16).save(str(tmp_path / fn), compression="tiff_lzw", tiffinfo={317: 2})
+    cases[fn] = g16
+    fn = "rgb8_lzw_pred_strips.tif"
+    Image.fromarray(rgb8).save(str(tmp_path / fn), compression="tiff_lzw", tiffinfo={317: 2, 278: 4})
+    cases[fn] = rgb8
+    import struct
+    be = g16[:7, :9]
+    ifd = [(256, 3, 1, 9), (257, 3, 1, 7), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1), (273, 4, 1, 8), (277, 3, 1, 1), (278, 3, 1, 7), (279, 4, 1, be.size * 2)]
+    blob = b"MM" + struct.pack(">HI", 42, 8 + be.size * 2) + be.astype(">u2").tobytes() + struct.pack(">H", len(ifd))
+    for tag, typ, cnt, val in ifd:
+        blob += struct.pack(">HHI", tag, typ, cnt) + (struct.pack(">HH", val, 0) if typ == 3 else struct.pack(">I", val))
+    blob += struct.pack(">I", 0)
+    (tmp_path / "g16_be.tif").write_bytes(blob)
+    cases["g16_be.tif"] = be
+    (tmp_path / "tiff_list.txt").write_text("\n".join(cases) + "\n")
+    exe = _link_host_test(tmp_path, ["test_host.cpp"], "test_host")
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "host tests OK" in r.stdout, r.stdout + r.stderr
+    got = np.fromfile(str(tmp_path / "bayer_rgb_cv.bin"), dtype=np.float32).reshape(3, h, st)[:, :, :w]
+    want = bayer_cv8u_numpy(mosaic[:, :w], rx, ry)
+    assert np.array_equal(got, want)
+    assert want.min() == 0 and want.max() == 255                                  # the saturation was exercised
+    for fn, arr in cases.items():
+        ok, tw, th, tc, td = [int(v) for v in (tmp_path / (fn + ".txt")).read_text().split()]
+        assert ok == 1, fn
+        assert (tw, th, tc, td) == (arr.shape[1], arr.shape[0], 1 if arr.ndim == 2 else 3, 16 if arr.dtype == np.uint16 else 8), fn
+        samples = np.fromfile(str(tmp_path / (fn + ".bin")), dtype=np.uint16).reshape(arr.shape)
+        assert np.array_equal(samples, arr.astype(np.uint16)), fn
+        assert np.array_equal(np.asarray(Image.open(str(tmp_path / fn))).astype(np.uint16), arr.astype(np.uint16)), fn    # Pillow agrees on what the file holds
+
+
 def test_host_mirror_cpu(host_build, tmp_path):
     write_png_cases(tmp_path)
     exe = str(tmp_path / "test_host")
@@ -342,6 +426,18 @@ def test_driver_ingest_scale_and_raw(host_build, tmp_path):
     cfg.write_text("file\t%s/m_%%03i.pgm\noutput\t%s/out_raw2\nraw\t1\nraw_demosaicing\t1\n" % (tmp_path, tmp_path) + common)
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "raw_demosaicing" in r.stderr
+    # (c) the reference cfg's own input side (cfgs/slow_flow.cfg:5,13-16): TIFF mosaics, raw_demosaicing 2 (OpenCV's 8-bit conversion, restated)
+    from PIL import Image
+    for k, f in enumerate(frames):
+        yy, xx = np.mgrid[0:h, 0:w]
+        red = (xx % 2 == 1) & (yy % 2 == 0)
+        blue = (xx % 2 == 0) & (yy % 2 == 1)
+        Image.fromarray(np.where(red, f[0], np.where(blue, f[2], f[1])).astype(np.uint16)).save(str(tmp_path / ("t_%03d.tif" % (10 - steps + k))), compression="tiff_lzw")
+    cfg.write_text("file\t%s/t_%%03i.tif\noutput\t%s/out_tif\nraw\t1\nraw_demosaicing\t2\nraw_red_loc\t1,0\nraw_weight\t1\nscale\t1.0\n" % (tmp_path, tmp_path) + common)
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    u, v = read_flo(str(tmp_path / "out_tif" / "t_010.flo"))
+    assert abs(np.median(u) - 1.5) < 0.15 and abs(np.median(v) + 0.75) < 0.15
 
 
 def _link_host_test(tmp_path, sources, name):
