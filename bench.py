@@ -221,6 +221,29 @@ def one_window_latency(ctx, reps=3):
           "max_abs_flow_deviation_from_reference_order_px": round(dev, 5), "meets_1e-4_parity": bool(dev <= 1e-4)}
     return out[0][0], out[0][1], rb
 
+def cfg_schedule_sample(ctx, B=16):
+    """what the driver's DEFAULT schedule costs per window (slow_flow.cpp:64-128: 10 alternations x 10 outer iterations with the cfg's break
+    thresholds and occlusion reasoning on; windows of a lockstep batch then stop at different iterations and ride along as passengers):
+    B windows of the bench size on one stream.  An extra beside the fixed-work metric, never part of `value`."""
+    p = sfa.default_params()
+    p.S = S; p.layers = LAYERS; p.hbit = 0
+    wins = [synth_window(900 + b) for b in range(min(B, 4))]
+    avg, std = ctx.normalize([f for w in wins for f in w], W)
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    job = sfa.Job(ctx, p, W, H, B)
+    for b in range(B):
+        job.upload(b, wins[b % len(wins)])
+    job.run(); ctx.sync()
+    t0 = time.perf_counter()
+    job.run(); ctx.sync()
+    sec = time.perf_counter() - t0
+    job.close()
+    return {"windows": B, "streams": 1, "seconds_per_window": round(sec / B, 5),
+            "schedule": "sfa_params_default: %d alternations x %d outer x %d inner x %d sweeps, thresholds %g / %g, occlusion reasoning %d, %d levels" % (
+                p.niter_alter, p.niter_outer, p.niter_inner, p.niter_solver, p.thres_outer, p.thres_inner, p.occlusion_reasoning, p.layers)}
+
+
 def sor_only(ctx, B, rank):
     from synth import sor_system
     sb = sfa.SorBatch(ctx, W, H, B)
@@ -463,6 +486,11 @@ def main():
             out["labelled_modes"] = {"red_black": rb}
         except Exception as e:                                    # a reported extra
             out["latency_one_window_ms"] = None
+        if not args.path_only:
+            try:
+                out["cfg_schedule_with_thresholds"] = cfg_schedule_sample(ctx)
+            except Exception as e:                                # a reported extra
+                out["cfg_schedule_with_thresholds"] = None
         try:
             out["roofline"]["measured_triad_gbs"] = round(hbm_triad_gbs(torch), 1)
         except Exception as e:                                    # a measurement aid only
