@@ -7,6 +7,7 @@ compute and no CPU fallback: if the HIP library is missing or no GPU is usable e
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -125,12 +126,17 @@ class Context:
 
     def __init__(self, device=0):
         self.h = C.c_void_p()
+        self._children = weakref.WeakSet()          # jobs, sequences, solver batches created on this context: they hold device memory and the stream
         rc = lib().sfa_ctx_create(int(device), C.byref(self.h))
         if rc != 0:
             raise SlowflowError(f"sfa_ctx_create({device}) -> {rc}: {lib().sfa_last_error(None).decode()}")
 
     def close(self):
+        """destroys what was created on the context first: the library's objects keep a pointer to it, and the garbage collector (cycles,
+        interpreter shutdown) may finalise a context before its jobs"""
         if self.h:
+            for child in list(getattr(self, "_children", ())):
+                child.close()
             lib().sfa_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -301,6 +307,7 @@ class Job:
         self.ctx, self.w, self.h, self.batch = ctx, w, h, batch
         self.h_ = C.c_void_p()
         ctx._ck(lib().sfa_job_create(ctx.h, C.byref(params), w, h, batch, C.byref(self.h_)), "sfa_job_create")
+        ctx._children.add(self)
 
     def upload(self, b, frames, wx=None, wy=None, chw=None):
         F = len(frames)
@@ -345,7 +352,8 @@ class Job:
 
     def close(self):
         if self.h_:
-            lib().sfa_job_destroy(self.h_)
+            if self.ctx.h:                      # a context finalised first (cyclic garbage, interpreter shutdown) took its stream along: nothing to call into
+                lib().sfa_job_destroy(self.h_)
             self.h_ = C.c_void_p()
 
     def __del__(self):
@@ -362,6 +370,7 @@ class Sequence:
         self.ctx, self.w, self.h, self.n = ctx, w, h, n
         self.h_ = C.c_void_p()
         ctx._ck(lib().sfa_sequence_create(ctx.h, w, h, n, C.byref(self.h_)), "sfa_sequence_create")
+        ctx._children.add(self)
 
     def upload(self, f, frame3):
         self.ctx._ck(lib().sfa_sequence_upload(self.h_, f, fptr(frame3), frame3.shape[2]), "sfa_sequence_upload")
@@ -378,7 +387,8 @@ class Sequence:
 
     def close(self):
         if self.h_:
-            lib().sfa_sequence_destroy(self.h_)
+            if self.ctx.h:                      # a context finalised first (cyclic garbage, interpreter shutdown) took its stream along: nothing to call into
+                lib().sfa_sequence_destroy(self.h_)
             self.h_ = C.c_void_p()
 
     def __del__(self):
@@ -395,6 +405,7 @@ class SorBatch:
         self.ctx, self.w, self.h, self.batch = ctx, w, h, batch
         self.h_ = C.c_void_p()
         ctx._ck(lib().sfa_sor_batch_create(ctx.h, w, h, batch, C.byref(self.h_)), "sfa_sor_batch_create")
+        ctx._children.add(self)
 
     def upload(self, b, du, dv, a11, a12, a22, b1, b2, sh, sv):
         stride = du.shape[1]
@@ -411,7 +422,8 @@ class SorBatch:
 
     def close(self):
         if self.h_:
-            lib().sfa_sor_batch_destroy(self.h_)
+            if self.ctx.h:                      # a context finalised first (cyclic garbage, interpreter shutdown) took its stream along: nothing to call into
+                lib().sfa_sor_batch_destroy(self.h_)
             self.h_ = C.c_void_p()
 
     def __del__(self):

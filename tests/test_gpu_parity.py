@@ -1005,3 +1005,41 @@ def test_resident_sequence_is_normalize_plus_upload(ctx, oracle):
     assert list(got[0]) == list(want[0]) and list(got[1]) == list(want[1])
     assert np.array_equal(seq2.download(2)[:, :, :w], sub[1][:, :, :w]) and np.array_equal(seq2.download(0)[:, :, :w], frames[0][:, :, :w])   # frames outside the range untouched
     a.close(); b.close(); seq.close(); seq2.close()
+
+
+@pytest.mark.gpu
+def test_objects_may_be_finalised_in_any_order():
+    """a context finalised before the jobs created on it (cyclic garbage, interpreter shutdown) must neither crash nor hang: close() on the context
+    destroys its children first, and a child whose context is already gone does not call into the library"""
+    import gc
+    import subprocess
+    import sys
+    code = r'''
+import sys, gc
+sys.path.insert(0, %r)
+import numpy as np, slowflow_amd as sfa
+ctx = sfa.Context(0)
+p = sfa.default_params(); p.layers = 1; p.niter_alter = 1; p.niter_outer = 1
+job = sfa.Job(ctx, p, 64, 48, 2)
+seq = sfa.Sequence(ctx, 64, 48, 3)
+sb = sfa.SorBatch(ctx, 64, 48, 1)
+ctx.close()                      # children first
+assert not job.h_ and not seq.h_ and not sb.h_
+job.close(); seq.close(); sb.close()
+# the garbage collector's order: a cycle through the objects, context finalised first by hand
+ctx2 = sfa.Context(0)
+job2 = sfa.Job(ctx2, p, 64, 48, 1)
+cyc = [ctx2, job2]; cyc.append(cyc)
+sfa.lib().sfa_ctx_destroy(ctx2.h); ctx2.h = sfa.C.c_void_p()     # what a finaliser run out of order amounts to
+del ctx2, job2, cyc
+gc.collect()
+# and objects simply left to the interpreter's shutdown, referenced from a cycle
+ctx3 = sfa.Context(0)
+jobs = [sfa.Job(ctx3, p, 64, 48, 1) for _ in range(2)]
+def run_all():
+    return [j for j in jobs], ctx3
+run_all.self = run_all
+print("alive")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "alive" in r.stdout, r.stdout + r.stderr
