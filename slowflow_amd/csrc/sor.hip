@@ -178,7 +178,11 @@ __device__ __forceinline__ unsigned wait_ge(const unsigned *p, unsigned target, 
 // back to a blocking wait.  A chunk is published one chunk late behind a counted s_waitcnt (no drain of the prefetch).
 template <int F, int CH>
 struct SorWave {
-    static constexpr int LAG = 3;
+    // long chunks (CH = 16, the single-solve shape): a stage starts ONE chunk behind its producers and publishes the previous chunk a quarter
+    // into the current one -- with 30 stages in a row the start-up lag of the pipeline is half of a lone solve's critical path
+    // (single 1024x436 solve: CH 8 / LAG 3 0.88 ms, CH 16 / LAG 3 0.83, LAG 1 0.72, + early publication 0.6x; CH 4 1.37, CH 32 spills)
+    static constexpr int LAG = CH >= 16 ? 1 : 3;
+    static constexpr int PUB = CH >= 16 ? CH / 4 : 0;          // steps into a chunk at which the previous chunk is published (0: at its end, by the caller)
     // wave-uniform state
     const float4 *pa[F];            // SA + U - f*FOFF
     const float4 *pb[F];
@@ -207,7 +211,7 @@ struct SorWave {
 
     // CH dependent steps.  REFILL: operand slots are refilled for the next chunk; PRE: so are the x slots.
     template <bool REFILL, bool PRE>
-    __device__ __forceinline__ void chunk() {
+    __device__ __forceinline__ void chunk(unsigned *myflag = nullptr, unsigned done = 0) {
         const unsigned long long tv_cur = tv;
         if (PRE && tv_lane) tv = ld_x(px + (long)CH * STEP + tv_off);
 #pragma unroll
@@ -247,6 +251,12 @@ struct SorWave {
 #pragma unroll
             for (int f = 0; f < F; f++) { pa[f] += STEP; pb[f] += STEP; }
             px += STEP;
+            if (REFILL && PUB > 0 && j == PUB - 1) {
+                // the previous chunk's stores are older than the 2 * PUB operand loads issued since (in-order vmcnt): this counted wait covers
+                // them without draining the prefetch
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PUB - 1) : "memory");
+                if (done > 0 && lane == 0) __hip_atomic_store(myflag, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         ch0 += CH;
     }
@@ -313,12 +323,14 @@ __global__ void __launch_bounds__(64) k_sor_solve(SorArgs a) {
         if (g > 0) pend_prev = __hip_atomic_load(f_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b > 0) pend_up = __hip_atomic_load(f_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool pre = ready(ch + 1);
-        if (pre) w.template chunk<true, true>();
-        else     w.template chunk<true, false>();
+        if (pre) w.template chunk<true, true>(myflag, (unsigned)ch);
+        else     w.template chunk<true, false>(myflag, (unsigned)ch);
         // ---- publish the PREVIOUS chunk.  Its stores are older than the >= 2*CH operand loads this chunk's body has
-        // issued since (in-order vmcnt), so this counted wait covers them without draining the prefetch. ---------------
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SFA_PUBLISH_VMCNT) : "memory");
-        if (ch > 0 && lane == 0) __hip_atomic_store(myflag, (unsigned)ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // issued since (in-order vmcnt), so this counted wait covers them without draining the prefetch.  (Long chunks did it PUB steps in.) ----
+        if (SorWave<F, CH>::PUB == 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SFA_PUBLISH_VMCNT) : "memory");
+            if (ch > 0 && lane == 0) __hip_atomic_store(myflag, (unsigned)ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (!pre) {
             // the producers were not far enough ahead: wait, then fetch the next chunk's x values
             if (g > 0) { known_prev = wait_ge(f_prev, need_prev(ch + 1), a.err); if (known_prev == 0xffffffffu) return; }
@@ -943,11 +955,11 @@ static size_t band_window(int F) { return F > 1 ? (size_t)2 * (F - 1) * (64 + F 
 static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
     // few waves (a single solve): the pipeline is latency bound, one iteration per wave is the shortest critical path;
     // many waves (batches): HBM bound, fusing two iterations halves the operand and x traffic
-    F = nwaves1 >= 900 ? 2 : 1; CHK = 8;
+    F = nwaves1 >= 900 ? 2 : 1; CHK = F == 1 ? 16 : 8;       // a lone solve: long chunks, short start lag (SorWave::LAG / PUB)
     if (const char *e = getenv("SFA_SOR_F")) F = atoi(e);
     if (const char *e = getenv("SFA_SOR_CH")) CHK = atoi(e);
-    if (!((F == 1 && CHK == 8) || (F == 2 && (CHK == 8 || CHK == 4)) || (F == 3 && CHK == 4))) { F = 2; CHK = 8; }
-    if (K % F != 0) { F = 1; CHK = 8; }                      // the fused kernel carries exactly F iterations per group
+    if (!((F == 1 && (CHK == 8 || CHK == 16)) || (F == 2 && (CHK == 8 || CHK == 4)) || (F == 3 && CHK == 4))) { F = 2; CHK = 8; }
+    if (K % F != 0) { F = 1; CHK = 16; }                     // the fused kernel carries exactly F iterations per group
 }
 
 int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
@@ -1056,7 +1068,8 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         else                hipLaunchKernelGGL((k_sor_band<1, 16, band_ch(1), band_mc(1), 16>), bgrid, bblock, lds, c->stream, ba);
     } else {
     const dim3 sgrid(g.nb * ws.ntasks), sblock(64);
-    if (ws.F == 1)                      hipLaunchKernelGGL((k_sor_solve<1, 8>), sgrid, sblock, 0, c->stream, a);
+    if (ws.F == 1 && ws.CHK == 16)      hipLaunchKernelGGL((k_sor_solve<1, 16>), sgrid, sblock, 0, c->stream, a);
+    else if (ws.F == 1)                 hipLaunchKernelGGL((k_sor_solve<1, 8>), sgrid, sblock, 0, c->stream, a);
     else if (ws.F == 2 && ws.CHK == 8)  hipLaunchKernelGGL((k_sor_solve<2, 8>), sgrid, sblock, 0, c->stream, a);
     else if (ws.F == 2)                 hipLaunchKernelGGL((k_sor_solve<2, 4>), sgrid, sblock, 0, c->stream, a);
     else                                hipLaunchKernelGGL((k_sor_solve<3, 4>), sgrid, sblock, 0, c->stream, a);

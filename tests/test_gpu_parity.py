@@ -250,7 +250,7 @@ def test_sor_full_size_and_batch(ctx, oracle):
     sb.close()
 
 
-SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1"}, "task_f2": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "2"},
+SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH": "8"}, "task_f1_ch16": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH": "16"}, "task_f2": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "2"},
                 "task_f3": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "3", "SFA_SOR_CH": "4"},
                 "band_f1": {"SFA_SOR_BAND": "1"}, "band_f2": {"SFA_SOR_BAND": "2"}, "band_f3": {"SFA_SOR_BAND": "3"},
                 "band_f5": {"SFA_SOR_BAND": "5"}, "band_f6": {"SFA_SOR_BAND": "6"}, "band_mixed_4x6_3x2": {"SFA_SOR_BAND": "43"}}
