@@ -16,3 +16,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS
 # pass 6: the same workload on ONE stream (no second group sharing the GPU): the per-kernel maxima here against pass 1 show what the overlap costs a kernel
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats1 -o bench -f csv -- python3 bench.py --batch $((BATCH / 2)) --streams 1 --steps 5 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_stats1.json 2> gpurun_out/${TAG}_stats1.err
 echo done
+# The raw counter files of the six passes are ~70 MB, more than gpurun merges back: summarise on the box and keep the summaries, e.g.
+#   bash profiles/collect.sh r02 128; python3 profiles/summarize.py r02 64; mkdir -p gpurun_out/r02_summary; cp profiles/r02_* gpurun_out/r02_summary/;
+#   rm -rf gpurun_out/r02_{sq1,sq2,fetch,write,stats,stats1}
