@@ -564,13 +564,6 @@ void launch_fill(sfa_ctx *c, float *p, size_t n, float v) {
 // (variational_aux_mt.cpp:166-403, 408-634; call order of variational_mt.cpp:343-361) accumulated in
 // registers in the reference's order, then sub_laplacian(b1,uu), (b2,vv) (:364-365), one store per plane.
 // ---------------------------------------------------------------------------------------------------
-#ifdef SFA_X_ROWS
-#define SFA_X_ROWCOND && ly < SFA_X_ROWS
-#define SFA_X_ROWCOND2 || ly >= SFA_X_ROWS
-#else
-#define SFA_X_ROWCOND
-#define SFA_X_ROWCOND2
-#endif
 #define DATANORM (0.1f * 0.1f)   // variational_aux_mt.h:23
 
 struct Acc { float a11, a12, a22, b1, b2; };
@@ -840,6 +833,10 @@ __device__ __forceinline__ float d5x_in(const float *t, int c) { return tap5(t[c
 template <int W>
 __device__ __forceinline__ float d5y_in(const float *t, int c) { return tap5(t[c - 2 * W], t[c - W], t[c], t[c + W], t[c + 2 * W]); }
 
+// Debug instrumentation (off in the product; tools/asm_timing.py): wave cycles of k_assemble_images by phase.  AT_MARK(i) charges the time since the
+// previous mark to slot i: 0 per-pixel term arithmetic, 1 wait for the staged planes, 2 image DMA issue, 3 its vmcnt wait, 4 barrier behind it,
+// 5 in-place conversion, 6 barrier before stage 1, 7 stage 1, 8 barrier behind it, 9 barrier before the epilogue, 10 epilogue per pixel,
+// 11 barrier behind the operand tile, 12 diagonal stores, 13 prologue.
 #ifdef SFA_ASM_TIMING
 __device__ unsigned long long g_asm_timing[16];
 } // namespace sfa
@@ -966,7 +963,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 const int k = part * 64 + tx;
                 const int q = k % QM, ly = (k / QM) % TR, ch = k / (QM * TR);
                 const int gy = y0 + ly, gx = x0 + 4 * q;
-                if (k < NSQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.w SFA_X_ROWCOND)
+                if (k < NSQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.w)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void *)(base + eb + set_src[set] + (size_t)ch * g.pl + (size_t)gy * g.pitch + gx),
                         (__attribute__((address_space(3))) void *)(lds + set_dst[set] + 256 * part), 16, 0, 0);      // the hardware adds 16 bytes per lane
@@ -980,7 +977,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         for (int item = threadIdx.x; item < NSQ; item += NT) {     // both terms of the pair in one item: the shared image is read before it is overwritten
             const int q = item % QM, ly = (item / QM) % TR, ch = item / (QM * TR);
             const int gy = y0 + ly, gx = x0 + 4 * q;
-            if (gy < 0 || gy >= g.h SFA_X_ROWCOND2) continue;
+            if (gy < 0 || gy >= g.h) continue;
             const bool interior = gx >= 0 && gx + 3 < g.w;
             const float *row = base + eb + ch * g.pl + (size_t)gy * g.pitch;
             auto fetch = [&](long src_off, int lds_off) {          // columns outside the image: replicated (clamped source column)
