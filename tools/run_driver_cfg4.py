@@ -42,3 +42,8 @@ print(r.stdout[-600:]); print(r.stderr[-400:])
 assert r.returncode==0
 tj=json.load(open(os.path.join(out,"out","timings.json")))
 print(f"driver: {len(tj)} windows ({JETS} jets x 2 directions) in {dt:.2f} s wall = {1e3*dt/len(tj):.1f} ms per window incl. frame ingest and .flo / .png output", flush=True)
+try:
+    rj=json.load(open(os.path.join(out,"out","run.json")))
+    print("run.json:", json.dumps(rj))
+except Exception as e:
+    print("no run.json", e)
