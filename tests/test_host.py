@@ -237,6 +237,28 @@ def test_opencv_style_demosaic_and_tiff_reader(host_build, tmp_path, rx, ry):
         assert np.array_equal(np.asarray(Image.open(str(tmp_path / fn))).astype(np.uint16), arr.astype(np.uint16)), fn    # Pillow agrees on what the file holds
 
 
+def test_image_readers_survive_malformed_files(host_build, tmp_path):
+    """the driver reads user files: byte-mutated and truncated PNG / TIFF inputs must be rejected or decoded, never read or written out of bounds
+    (address + undefined-behaviour sanitizers on the CPU build of the two readers)"""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    g16 = rng.integers(0, 65536, (37, 50)).astype(np.uint16); g16[5:15] = 7
+    rgb = rng.integers(0, 256, (21, 33, 3)).astype(np.uint8); rgb[3:9] = 9
+    files = []
+    for name, im, kw in (("a.tif", g16, {}), ("b.tif", g16, {"compression": "tiff_lzw", "tiffinfo": {317: 2, 278: 5}}), ("c.tif", rgb, {"compression": "packbits"}),
+                         ("d.tif", rgb, {"compression": "tiff_adobe_deflate"}), ("a.png", g16, {}), ("b.png", rgb, {})):
+        Image.fromarray(im).save(str(tmp_path / name), **kw)
+        files.append(str(tmp_path / name))
+    Image.fromarray(rgb).convert("P").save(str(tmp_path / "c.png")); files.append(str(tmp_path / "c.png"))
+    exe = str(tmp_path / "fuzz_readers")
+    r = subprocess.run(["g++", "-std=c++11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", HOST,
+                        os.path.join(ROOT, "tests", "host", "fuzz_readers.cpp"), os.path.join(HOST, "tiff.cpp"), os.path.join(HOST, "png.cpp"), "-lz", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "600", str(tmp_path / "mutant.bin")] + files, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "none crashed" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
 def test_host_mirror_cpu(host_build, tmp_path):
     write_png_cases(tmp_path)
     exe = str(tmp_path / "test_host")
