@@ -32,7 +32,8 @@ image_t **readFlowFile(const char *filename) {
     if (!f) { fprintf(stderr, "readFlow() error: could not open file  %s\n", filename); return nullptr; }
     float tag = 0;
     int w = 0, h = 0;
-    if (fread(&tag, 4, 1, f) != 1 || fread(&w, 4, 1, f) != 1 || fread(&h, 4, 1, f) != 1 || tag != 202021.25f || w <= 0 || h <= 0) { fclose(f); return nullptr; }
+    if (fread(&tag, 4, 1, f) != 1 || fread(&w, 4, 1, f) != 1 || fread(&h, 4, 1, f) != 1 || tag != 202021.25f || w <= 0 || h <= 0 || w > 65535 || h > 65535 ||
+        (long long)w * h > (1ll << 28)) { fclose(f); return nullptr; }
     image_t **flow = (image_t **)malloc(2 * sizeof(image_t *));
     flow[0] = image_new(w, h);
     flow[1] = image_new(w, h);
@@ -95,7 +96,7 @@ color_image_t *color_image_load(const char *filename, int *maxval_out) {
         h = atoi(t.c_str());
         if (!next_token(f, t)) { fclose(f); return nullptr; }
         maxv = atoi(t.c_str());                     // next_token consumed the single whitespace after maxval
-        if (w <= 0 || h <= 0 || maxv <= 0 || maxv > 65535) { fclose(f); return nullptr; }
+        if (w <= 0 || h <= 0 || w > 65535 || h > 65535 || (long long)w * h > (1ll << 28) || maxv <= 0 || maxv > 65535) { fclose(f); return nullptr; }
         const int bps = maxv > 255 ? 2 : 1;
         std::vector<unsigned char> row((size_t)w * ch * bps);
         im = color_image_new(w, h);
@@ -119,7 +120,7 @@ color_image_t *color_image_load(const char *filename, int *maxval_out) {
         h = atoi(t.c_str());
         if (!next_token(f, t)) { fclose(f); return nullptr; }
         const double scale = atof(t.c_str());
-        if (w <= 0 || h <= 0 || scale >= 0) { fclose(f); return nullptr; }   // little-endian files only (negative scale)
+        if (w <= 0 || h <= 0 || w > 65535 || h > 65535 || (long long)w * h > (1ll << 28) || scale >= 0) { fclose(f); return nullptr; }   // little-endian files only (negative scale)
         std::vector<float> row((size_t)w * ch);
         im = color_image_new(w, h);
         color_image_erase(im);

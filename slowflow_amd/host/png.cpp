@@ -64,7 +64,7 @@ bool png_read(const char *filename, png_image &out) {
         }
         pos += 12 + (size_t)len;
     }
-    if (!seen_end || ctype < 0 || w == 0 || h == 0 || w > (1u << 20) || h > (1u << 20) || interlace != 0) return false;
+    if (!seen_end || ctype < 0 || w == 0 || h == 0 || w > 65535 || h > 65535 || (uint64_t)w * h > (1ull << 28) || interlace != 0) return false;   // a corrupt header must not ask for terabytes
     int comps;
     switch (ctype) {
         case 0: comps = 1; break;
@@ -80,6 +80,7 @@ bool png_read(const char *filename, png_image &out) {
 
     const size_t bpp = (size_t)(comps * depth + 7) / 8;                   // filter unit
     const size_t line = ((size_t)w * comps * depth + 7) / 8;
+    if ((line + 1) * (size_t)h > idat.size() * (size_t)1100 + 4096) return false;      // deflate expands by at most ~1032 : 1: the data cannot hold this image
     std::vector<unsigned char> raw((line + 1) * (size_t)h);
     uLongf got = (uLongf)raw.size();
     if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return false;

@@ -137,7 +137,7 @@ bool tiff_read(const char *filename, png_image &out) {
         default: break;
         }
     }
-    if (tiled || width == 0 || height == 0 || width > 65535 || height > 65535) return false;
+    if (tiled || width == 0 || height == 0 || width > 65535 || height > 65535 || (uint64_t)width * height > (1ull << 28)) return false;   // 268 Mpx: far beyond any camera, keeps a corrupt header from asking for tens of GB
     if (spp != 1 && spp != 3 && spp != 4) return false;
     if ((spp > 1 && planar != 1) || fill_order != 1 || fmt[0] != 1) return false;
     const uint32_t bps = bits[0];
@@ -155,6 +155,13 @@ bool tiff_read(const char *filename, png_image &out) {
     if (rows_per_strip > height) rows_per_strip = height;
     const size_t row_bytes = (size_t)width * spp * (bps / 8);
     const int ch = spp == 1 ? 1 : 3;
+    {   // the strips must lie in the file, and an uncompressed image must bring its bytes, before anything is allocated for it
+        uint64_t have = 0;
+        for (size_t i = 0; i < offsets.size(); i++) { if (!r.ok(offsets[i], counts[i])) return false; have += counts[i]; }
+        if ((uint64_t)offsets.size() * rows_per_strip < height) return false;
+        if (compression == 1 && have < (uint64_t)row_bytes * height) return false;
+        if (have == 0) return false;
+    }
     out.width = (int)width; out.height = (int)height; out.channels = ch; out.depth = (int)bps;
     out.samples.assign((size_t)width * height * ch, 0);
     const uint32_t maxv = bps == 16 ? 65535u : 255u;
