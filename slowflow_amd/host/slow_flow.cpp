@@ -10,7 +10,7 @@
 // deep_matching 1 initialises the flow with EpicFlow's interpolation (epic.h) of match and edge files found at the reference's locations; producing those files
 // (DeepMatching, the MATLAB SED detector) and the third-party Hamilton-Adams demosaicer (raw_demosaicing 1) are outside this build and reported as such.
 //
-// New, additive keys: gpus (default: all visible), gpu_batch (windows refined in lockstep per job, default 32), gpu_streams
+// New, additive keys: gpus (default: all visible; gpu_oversubscribe 1 lets it exceed them: a rehearsal of the multi-GPU path), gpu_batch (windows refined in lockstep per job, default 32), gpu_streams
 // (default 2), gpu_device (first device, default 0), io_threads (decode / output pool, default min(16, cores)),
 // adaptive_fr_file (default: adaptiveFR.dat next to the executable, the reference's SOURCE_PATH).
 #include <sys/stat.h>
@@ -275,10 +275,15 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     //      as the host-plane normalize() of variational_mt.h).  Every GPU holds the loaded frames -- 133 frames of 1024x436 are 0.7 GB -- so no GPU
     //      waits for another; the statistics are those of GPU 0 (identical on all: same data, same deterministic kernels). --------------------------
     const auto t_norm = std::chrono::steady_clock::now();
-    int ngpu = sfa_device_count();
+    const int ndev = sfa_device_count();
+    int ngpu = ndev;
     if (ngpu <= 0) { std::cerr << "no HIP device: slowflow_amd has no CPU fallback" << std::endl; return 4; }
-    if (params.exists("gpus")) ngpu = std::max(1, std::min(ngpu, params.parameter<int>("gpus")));
+    // gpu_oversubscribe 1: `gpus` may exceed the devices of the box, GPU g then runs on device g mod devices -- the multi-GPU code path (one resident
+    // sequence, one set of workers and one statistics slot per GPU) rehearsed on fewer cards than it is written for; never a way to get speed
+    const bool oversubscribe = params.parameter<bool>("gpu_oversubscribe", "0");
+    if (params.exists("gpus")) ngpu = std::max(1, oversubscribe ? std::min(16, params.parameter<int>("gpus")) : std::min(ngpu, params.parameter<int>("gpus")));
     const int dev0 = params.parameter<int>("gpu_device", "0");
+    auto device_of = [&](int g) { return oversubscribe ? (dev0 + g) % ndev : dev0 + g; };
     const int n_loaded = (int)(end_f - start_f);
     std::vector<sfa_ctx *> seq_ctx(ngpu, nullptr);
     std::vector<sfa_sequence *> seq_dev(ngpu, nullptr);
@@ -288,7 +293,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         std::vector<std::thread> up;
         for (int g = 0; g < ngpu; g++)
             up.emplace_back([&, g] {
-                int rc = sfa_ctx_create(dev0 + g, &seq_ctx[g]);
+                int rc = sfa_ctx_create(device_of(g), &seq_ctx[g]);
                 if (rc == SFA_OK) rc = sfa_sequence_create(seq_ctx[g], width, height, n_loaded, &seq_dev[g]);
                 for (int f = 0; f < n_loaded && rc == SFA_OK; f++) rc = sfa_sequence_upload(seq_dev[g], f, seq[start_f + f]->c1, seq[start_f + f]->stride);
                 if (rc == SFA_OK) rc = sfa_sequence_normalize(seq_dev[g], 0, n_loaded, &stat_avg[3 * g], &stat_std[3 * g]);
@@ -303,7 +308,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         }
     };
     for (int g = 0; g < ngpu; g++)
-        if (!seq_err[g].empty()) { std::cerr << "GPU " << dev0 + g << ": " << seq_err[g] << std::endl; release_sequences(); return 4; }
+        if (!seq_err[g].empty()) { std::cerr << "GPU " << device_of(g) << ": " << seq_err[g] << std::endl; release_sequences(); return 4; }
     publish_normalization(params, &stat_avg[0], &stat_std[0]);                       // the slow_flow_img_norm_* parameters (variational_mt.cpp:71-84)
     const double normalize_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_norm).count();
     {
@@ -372,7 +377,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
 
     auto worker = [&](const WorkerPlan &wp) {
         if (wp.lo >= wp.hi) return;
-        const int device = dev0 + wp.gpu;
+        const int device = device_of(wp.gpu);
         sfa_ctx *ctx = nullptr;
         if (sfa_ctx_create(device, &ctx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; return; }
         ParameterList tp(params);                                                    // one copy per thread (:708)
@@ -475,7 +480,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                     const Window &wd = todo[mine[b0 + e]];
                     const int f = wd.jet * steps;
                     std::cout << (wd.backward ? "Backward" : "Forward") << " flow from frame " << start + f * skip << " to " << start + f * skip + steps * skip
-                              << " finished! (GPU " << device << ", " << secs / nb << " s per window in a batch of " << nb << ")" << std::endl;
+                              << " finished! (GPU " << dev0 + wp.gpu << ", " << secs / nb << " s per window in a batch of " << nb << ")" << std::endl;
                 }
             }
             if (job) sfa_job_destroy(job);

@@ -45,3 +45,18 @@ def test_world_size_mismatch_is_refused():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_for_real_on_one_gpu():
+    """the whole N = 2 path of the real bench -- child launch, two ranks with two contexts each, the timed region, max over ranks, the gather of the
+    per-window timings, rank 0's line -- with both ranks on the one GPU of this box and the exchange over gloo (SFA_BENCH_BACKEND=gloo: a rehearsal
+    switch; the line says so and is never a result).  Two processes on the card: within the box's limit."""
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--path-only"], {"SFA_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["steps"] == 1
+    assert out["config"]["frame_windows_per_gpu"] == 8
+    assert out["seconds_per_window"]["n"] == 16                         # both ranks' windows arrived
+    assert out["value"] > 0 and "gloo" in json.dumps(out)

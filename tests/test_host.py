@@ -1,5 +1,6 @@
 """Host side of the drop-in (C++): builds slowflow_amd/host and runs its CPU checks; on a GPU box also drives the
 slow_flow binary end to end over a synthetic PPM sequence and compares the .flo files with the Python binding."""
+import json
 import os
 import struct
 import subprocess
@@ -383,6 +384,36 @@ def write_pgm(path, img):           # img: (h,w) float 0..255
     with open(path, "wb") as f:
         f.write(b"P5\n%d %d\n255\n" % (w, h))
         f.write(np.clip(np.round(img), 0, 255).astype(np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+def test_driver_multi_gpu_path_rehearsed_on_one_card(host_build, tmp_path):
+    """the driver's N-GPU path (a resident, normalised sequence per GPU; `gpu_streams` workers per GPU; windows dealt out by plan_workers) cannot run on
+    this one-GPU box as written, so it is rehearsed: `gpu_oversubscribe 1` maps GPU g to device g mod devices.  Three virtual GPUs x 2 workers must
+    write exactly the files, bit for bit, that one GPU writes, and name all three in the log."""
+    from synth import texture_frame
+    w, h, jets, S = 96, 64, 7, 2
+    steps = S - 1
+    nframes = 1 + (jets + 2) * steps
+    for k in range(nframes):
+        write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), np.clip(np.round(texture_frame(w, h, k)[:, :, :w]), 0, 255))
+    body = ("file\t%s/f_%%03i.ppm\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\n"
+            "slow_flow_S\t%d\nslow_flow_layers\t2\nslow_flow_niter_alter\t2\nslow_flow_niter_outer\t3\nslow_flow_occlusion_reasoning\t1\n"
+            "slow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpu_batch\t2\n" % (tmp_path, jets, S))
+    outs = {}
+    for name, extra in (("one", "gpus\t1\ngpu_streams\t1\n"), ("three", "gpus\t3\ngpu_oversubscribe\t1\ngpu_streams\t2\n")):
+        cfg = tmp_path / (name + ".cfg")
+        cfg.write_text("output\t%s/out_%s\n" % (tmp_path, name) + body + extra)
+        r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "Done!" in r.stdout, r.stdout + r.stderr
+        outs[name] = r.stdout
+        tj = json.load(open(str(tmp_path / ("out_" + name) / "timings.json")))
+        assert len(tj) == 2 * jets
+    assert all(("GPU %d" % g) in outs["three"] for g in range(3)), outs["three"]
+    flo = sorted(f for f in os.listdir(str(tmp_path / "out_one")) if f.endswith(".flo"))
+    assert len(flo) == 2 * jets
+    for f in flo:
+        assert (tmp_path / "out_one" / f).read_bytes() == (tmp_path / "out_three" / f).read_bytes(), f
 
 
 @pytest.mark.gpu
