@@ -450,3 +450,61 @@ def test_dpsis_weight_with_statistics_is_the_pinned_weight_of_the_denormalised_i
     a = oracle.dpsis_weight(im, w, avg=avg, std=std)
     b = reflib.dpsis_weight(den, w)
     assert np.array_equal(valid(a, w), valid(b, w))
+
+
+# ---- the pyramid operators (OpenCV arithmetic, absent here: SURVEY 8c says they stay unpinned) get a SECOND, independent derivation: the documented
+#      semantics written with numpy / scipy in double precision.  Not a pin (no OpenCV output behind it) -- it guards kernel size, normalisation, border
+#      mode and the coordinate mapping against a slip in the C restatement.
+def _cv_gaussian_kernel(sigma):
+    ksize = int(np.rint(sigma * 4 * 2 + 1)) | 1                      # cv::GaussianBlur with ksize = Size(): cvRound(sigma * 8 + 1) | 1 for CV_32F
+    x = np.arange(ksize) - (ksize - 1) * 0.5
+    k = np.exp(-0.5 * x * x / (sigma * sigma))
+    return k / k.sum()
+
+
+@pytest.mark.parametrize("w,h,sigma", [(67, 45, 0.745356), (130, 98, 1.0), (64, 48, 1.4142135)])
+def test_gaussian_blur_cv_against_scipy(oracle, w, h, sigma):
+    from scipy.ndimage import correlate1d
+    rng = np.random.default_rng(w)
+    src = orc.plane(h, orc.stride_of(w))
+    src[:, :w] = rng.uniform(0, 255, (h, w)).astype(np.float32)
+    got = oracle.gaussian_blur_cv(src, w, sigma)[:, :w]
+    k = _cv_gaussian_kernel(sigma)
+    want = correlate1d(correlate1d(src[:, :w].astype(np.float64), k, axis=1, mode="nearest"), k, axis=0, mode="nearest")     # BORDER_REPLICATE
+    assert np.abs(got - want).max() < 2e-4 * 255
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(1024 // 8, 436 // 4, 921 // 8, 392 // 4), (67, 45, 60, 40), (60, 40, 67, 45), (130, 98, 117, 88)])
+def test_resize_linear_cv_against_numpy(oracle, sw, sh, dw, dh):
+    rng = np.random.default_rng(sw + dw)
+    src = orc.plane(sh, orc.stride_of(sw))
+    src[:, :sw] = rng.uniform(-3, 3, (sh, sw)).astype(np.float32)
+    got = oracle.resize_linear_cv(src, sw, dw, dh)[:, :dw]
+
+    def coords(n_dst, n_src):                                         # cv::resize INTER_LINEAR: src = (dst + .5) * (n_src / n_dst) - .5, clamped
+        f = (np.arange(n_dst) + 0.5) * (n_src / n_dst) - 0.5
+        i = np.floor(f).astype(int)
+        a = f - i
+        a = np.where(i < 0, 0.0, a); i = np.maximum(i, 0)
+        a = np.where(i >= n_src - 1, 0.0, a); i = np.minimum(i, n_src - 1)
+        return i, np.minimum(i + 1, n_src - 1), a
+    x0, x1, ax = coords(dw, sw)
+    y0, y1, ay = coords(dh, sh)
+    s = src[:, :sw].astype(np.float64)
+    top = s[y0][:, x0] * (1 - ax) + s[y0][:, x1] * ax
+    bot = s[y1][:, x0] * (1 - ax) + s[y1][:, x1] * ax
+    want = top * (1 - ay)[:, None] + bot * ay[:, None]
+    assert np.abs(got - want).max() < 2e-4                             # the coordinate is a float in cv::resize: ~1e-5 px of rounding times a slope of a few units per pixel
+    dst_fx, dwx = oracle.resize_linear_fx(src, sw, dw / sw, dh / sh)   # the Size(0,0), fx, fy form maps coordinates with 1 / f instead
+    if dwx == dw and dst_fx.shape[0] == dh:
+        assert np.abs(dst_fx[:, :dw] - want).max() < 1e-3
+
+
+def test_pyramid_sizes_are_float_floor(oracle):
+    """variational_mt.cpp:609-610: floor(w * p) with p a float, in float arithmetic, level by level"""
+    for (w, h, layers, p) in [(1024, 436, 5, 0.9), (2048, 2048, 6, 0.9), (640, 480, 8, 0.75)]:
+        want, cw, ch = [(w, h)], w, h
+        for _ in range(1, layers):
+            cw, ch = int(np.floor(np.float32(cw) * np.float32(p))), int(np.floor(np.float32(ch) * np.float32(p)))
+            want.append((cw, ch))
+        assert oracle.pyramid_sizes(w, h, layers, p)[:layers] == want[:len(oracle.pyramid_sizes(w, h, layers, p))]
