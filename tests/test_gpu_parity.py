@@ -1043,3 +1043,44 @@ print("alive")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "alive" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_boundary_rejects_bad_arguments_without_exiting(ctx):
+    """the reference exit()s or throws on bad input (image.c:19-30, variational_aux_mt.cpp:419); the C-ABI returns a negative status with a
+    message and the process lives on -- the context stays usable afterwards"""
+    L = sfa.lib()
+    C = sfa.C
+    p = sfa.default_params()
+    job = C.c_void_p()
+    for (w, h, batch) in [(1, 48, 1), (64, 4, 1), (64, 48, 0), (64, 48, 65)]:
+        assert L.sfa_job_create(ctx.h, C.byref(p), w, h, batch, C.byref(job)) == -1
+        assert b"bad arguments" in L.sfa_last_error(ctx.h)
+    assert L.sfa_job_create(None, C.byref(p), 64, 48, 1, C.byref(job)) == -1
+    bad = sfa.default_params(); bad.S = 1                                        # a window needs at least two frames each side of ... S >= 2
+    rc = L.sfa_job_create(ctx.h, C.byref(bad), 64, 48, 1, C.byref(job))
+    assert rc < 0 and L.sfa_last_error(ctx.h)
+    p.layers = 1; p.niter_alter = 1; p.niter_outer = 1
+    j = sfa.Job(ctx, p, 64, 48, 2)
+    stride = sfa.stride_of(64)
+    fr = [np.zeros((3, 48, stride), np.float32) for _ in range(3)]
+    with pytest.raises(sfa.SlowflowError):
+        j.upload(0, fr[:2])                                                          # 2 frames where S = 2 needs 3
+    with pytest.raises(sfa.SlowflowError):
+        j.upload(2, fr)                                                              # window index out of range
+    with pytest.raises(sfa.SlowflowError):
+        j.download(-1)
+    du = np.zeros((48, stride), np.float32)
+    img = sfa.Image(64, 48, stride, sfa.fptr(du))
+    nul = sfa.Image(64, 48, stride, None)                                            # a plane without data
+    args = [C.byref(img)] * 9
+    assert L.sfa_sor_coupled(ctx.h, None, *args[1:], 30, C.c_float(1.9)) < 0        # null image
+    assert L.sfa_sor_coupled(ctx.h, C.byref(nul), *args[1:], 30, C.c_float(1.9)) < 0
+    # still alive and working
+    for f in fr:
+        f[:, :, :64] = np.random.default_rng(0).uniform(0, 255, (3, 48, 64)).astype(np.float32)
+    j.upload(0, fr); j.upload(1, fr)
+    j.run()
+    wx, wy, _ = j.download(1)
+    assert np.isfinite(wx).all() and np.isfinite(wy).all()
+    j.close()
