@@ -509,6 +509,11 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
         }
     } else if (has_up && lane == 0) selfv[0] = u2f(ld_x(e_up - a.Wp));                  // x^(k0-1)(0, r0): band above, lane 63
     if (tv_lane) tv = ld_x(e_up + tv_off);
+    // selfv[0] is the one prologue load whose first use lies inside the loop and that the loop then redefines with arithmetic: left pending, the compiler
+    // guards that use with s_waitcnt vmcnt(0) in the first step of EVERY chunk (it cannot count the loads of later iterations), which drains the
+    // operand prefetch once per CH steps.  Resolve it here, once.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(selfv[0].x), "+v"(selfv[0].y));
 
     int s0 = 0;
 #ifdef SFA_BAND_TIMING
