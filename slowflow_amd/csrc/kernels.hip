@@ -1166,13 +1166,10 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, con
         if (a.zero_duv) hipLaunchKernelGGL((k_assemble_images<TY, NT, MINB, true>), grid_, dim3(NT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g);  \
         else            hipLaunchKernelGGL((k_assemble_images<TY, NT, MINB, false>), grid_, dim3(NT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g); \
     } while (0)
+    // SFA_ASSEMBLE_SHAPE=5: the taller tile (64 x 16, two pixels per thread, 209 VGPRs, one block per CU) measured slower than the default and kept for
+    // comparison; 8 x 256 threads and 16 x 1024 threads were tried in rounds 1 / 2 and dropped (the latter spills at its 128-register cap)
     switch (shape) {
-    case 1: SFA_LAUNCH_AI(8, 256, 2); break;
-    case 2: SFA_LAUNCH_AI(8, 256, 4); break;
-    case 3: SFA_LAUNCH_AI(16, 1024, 4); break;
-    case 4: SFA_LAUNCH_AI(16, 512, 4); break;
     case 5: SFA_LAUNCH_AI(16, 512, 1); break;
-    case 6: SFA_LAUNCH_AI(16, 1024, 1); break;
     default: SFA_LAUNCH_AI(8, 512, 4); break;
     }
 #undef SFA_LAUNCH_AI
