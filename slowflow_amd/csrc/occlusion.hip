@@ -72,12 +72,27 @@ __global__ void __launch_bounds__(OC_NT) k_occ_costs(OccArgs a, const float *__r
             if (wgt == 0.0f && kind == 1) continue;
             const float *pa = base + eb + (kind ? S.r1_off : S.s1_off), *pb = base + eb + (kind ? S.r2_off : S.s2_off);
             __syncthreads();
-            for (int i = threadIdx.x; i < 3 * OC_R * OC_W; i += OC_NT) {
-                const int ch = i / (OC_R * OC_W), r = (i / OC_W) % OC_R, q = i % OC_W;
-                const int gy = y0 + r, gx = clampi(x0 + q, 0, g.w - 1);              // replicated columns: fixed-offset taps (image.c:501-516)
+            // the halo-2 tile starts two columns left of a 64-aligned one: the aligned quads x0-2 .. x0+69 cover it, one 16-byte load per image and item
+            // (the scalar form issued ten loads per thread and stage); columns outside the image are replicated (fixed-offset taps, image.c:501-516)
+            constexpr int OC_Q = (OC_W + 2 + 3) / 4;
+            for (int i = threadIdx.x; i < 3 * OC_R * OC_Q; i += OC_NT) {
+                const int ch = i / (OC_R * OC_Q), r = (i / OC_Q) % OC_R, qa = i % OC_Q;
+                const int gy = y0 + r, gx = x0 - 2 + 4 * qa;
                 if (gy < 0 || gy >= g.h) continue;
-                const size_t o = ch * g.pl + (size_t)gy * g.pitch + gx;
-                sZ[ch][r * OC_W + q] = pa[o] - pb[o];                                 // Iz, variational_mt.cpp:122 / :141,144
+                const size_t ro = ch * g.pl + (size_t)gy * g.pitch;
+                float z[4];
+                if (gx >= 0 && gx + 3 < g.w) {
+                    const float4 va = *reinterpret_cast<const float4 *>(pa + ro + gx), vb = *reinterpret_cast<const float4 *>(pb + ro + gx);
+                    z[0] = va.x - vb.x; z[1] = va.y - vb.y; z[2] = va.z - vb.z; z[3] = va.w - vb.w;      // Iz, variational_mt.cpp:122 / :141,144
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const int cx = clampi(gx + e, 0, g.w - 1); z[e] = pa[ro + cx] - pb[ro + cx]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int q = 4 * qa - 2 + e;
+                    if (q >= 0 && q < OC_W) sZ[ch][r * OC_W + q] = z[e];
+                }
             }
             __syncthreads();
             if (!ok) continue;
