@@ -197,6 +197,7 @@ struct SorWorkspace {
     int NB = 0, NG = 0, RP = 0, ND = 0, G = 0, NS = 0, NCH = 0, ntasks = 0, F = 0, CHK = 0;
     long ent = 0;                 // entries per element (ND*RP)
     int band = 0, Wp = 0, EP = 0;   // band kernel: fused sweeps per wave (0 = task kernel), edge row pitch / left pad
+    int chain = 0;                  // sor_chain.hip shape id (0 = the band / task kernels); then NG = groups per band, NCH = chunks per stage, NS = barrier intervals
     long edge_job = 0;
     DevMem sa, sb, x, flags, order, edge;
     int configure(sfa_ctx *ctx, int w, int h, int K, int nb);   // (re)allocates for this shape

@@ -1,0 +1,493 @@
+// sor_chain.hip -- sor_coupled (solver.c:63-399) for FEW systems per launch (1 .. 32 frame windows): the same hyperplane pipeline as
+// sor.hip (reference raster order, IEEE == results), cut into many small workgroups so that a lone solve spreads over the chip and
+// every wave carries few instructions per step.
+//
+// Geometry (sor.hip's): skewed rows rho = r + k; a band = 64 rho = one wavefront; a STAGE = F consecutive sweeps fused in one wave;
+// at local step s the lane works on column c = s - lane - f of row r = 64 b - k0 + lane - f; operands live in diagonal-major planes.
+//
+// What is different here:
+//   * the K sweeps of a band are split into NG GROUPS of KG sweeps; a workgroup = (window, band b, group g) = NW compute waves (the
+//     group's stages) + ONE I/O wave.  Consecutive stages of a group hand the iterate over through LDS rings; consecutive groups of a
+//     band through the in-place x plane; bands through the edge rows (lane 63's iterate of every sweep), as in sor.hip.
+//   * GLOBAL TIME.  Stage st (first sweep k0) works at global time t on local step s = t - O, O = k0 - st + 1.  With that offset a
+//     stage consumes at time t exactly what its predecessor produced at time t: ring slot = t mod ring size for writer and reader, so
+//     chunk boundaries (CH steps) are the same for every stage and all LDS addresses of a chunk are lane * 8 + immediate.
+//   * LOCKSTEP BY BARRIER.  The waves of a workgroup meet at one s_barrier per chunk; compute wave w runs chunk I - LEAD - w in
+//     interval I.  No LDS progress words, no polling in the compute waves: their step is the operand refill (buffer loads), three LDS
+//     reads, the DPP shifts, the packed point updates and one or two LDS writes.
+//   * THE I/O WAVE owns everything that crosses workgroups: it polls the progress words of the three workgroups this one depends on
+//     ((b-1,g), (b-1,g-1), (b,g-1)), loads the band above's lane-63 values and the previous group's iterate AH intervals ahead
+//     (register FIFO, sc1 loads), parks them in LDS for the compute waves, stores this workgroup's lane-63 values and last iterate
+//     (sc1 write-through) and publishes ONE progress word per workgroup behind a counted s_waitcnt vmcnt (its own VMEM stream only:
+//     the compute waves' operand prefetch is never drained by a publication).
+//   * every stage starts in the zero guards (s < 0), so "self", "left weight" and the first results need no special start-up.
+//
+// Deadlock freedom: tickets are drawn in ascending 3 b + g, every dependency has a smaller ticket; only the I/O wave ever waits for
+// another workgroup, and a wait that gives up (bounded) poisons the run (error word) but still walks through every barrier.
+#include "sfa_internal.h"
+#include "sfa_device.h"
+#include "sor_device.h"
+
+#pragma clang fp contract(off)
+
+namespace sfa {
+
+struct ChainArgs {
+    const float4 *sa, *sb;
+    unsigned long long *x, *edge;
+    unsigned *gflags;              // [nb][NB][NG] intervals published; gflags[nb*NB*NG] = ticket
+    const int2 *order;             // ticket / nb -> (band, group)
+    unsigned *err;
+    long ent, edge_job;            // entries per window: operand planes / edge rows
+    unsigned long long edge_bytes, flag_bytes;
+    int W, H, K, NB, NG, RP, G, nb, Wp, EP;
+    int nch;                       // chunks per stage (even)
+    int NI;                        // barrier intervals per workgroup (multiple of AH)
+    float omega;
+};
+
+constexpr unsigned kAuxSc1 = 16;   // raw buffer builtins: aux bit 4 = sc1 (bit 0 sc0, bit 1 nt)
+
+__device__ __forceinline__ unsigned long long bload8_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxSc1);
+    return (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+}
+__device__ __forceinline__ void bstore8_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned long long v) {
+    v2u t = {(unsigned)v, (unsigned)(v >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, kAuxSc1);
+}
+__device__ __forceinline__ unsigned bload4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxSc1); }
+__device__ __forceinline__ void bstore4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, kAuxSc1); }
+
+// one barrier interval: the LDS writes of the interval are complete before any wave passes
+#define SFA_CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// shape of a workgroup: NA stages of FA sweeps, then NB_ stages of FB sweeps
+template <int FA, int NA, int FB, int NB_>
+struct ChainShape {
+    static constexpr int NW = NA + NB_, KG = NA * FA + NB_ * FB, FMAX = FA > FB ? FA : FB;
+    __host__ __device__ static constexpr int Fw(int w) { return w < NA ? FA : FB; }
+    __host__ __device__ static constexpr int kw(int w) { return w < NA ? w * FA : NA * FA + (w - NA) * FB; }   // sweeps of the group in front of wave w
+};
+
+// LDS map of a workgroup (bytes).  rings: [NW+1][2][CH][64] u64 (ring w = input of compute wave w; ring NW = output of the last one);
+// tv: per wave [2][CH][F+1] u64, the band above's lane-63 values (fi = 0: "right" of sweep 0, fi = f+1: "top" of sweep f);
+// es: per wave [2][F-1][CH] u64, lane 63's iterates of the sweeps that do not go through a ring; dummy: where lanes 0..62 write instead
+template <class S, int CH>
+struct ChainLds {
+    static constexpr int RING = 2 * CH * 64 * 8;
+    static constexpr int ring0 = 0;
+    static constexpr int tv0 = ring0 + (S::NW + 1) * RING;
+    static constexpr int TVW = 2 * CH * (S::FMAX + 1) * 8;                    // per wave
+    static constexpr int es0 = tv0 + S::NW * TVW;
+    static constexpr int ESW = 2 * (S::FMAX > 1 ? S::FMAX - 1 : 1) * CH * 8;   // per wave
+    static constexpr int dummy0 = es0 + S::NW * ESW;
+    static constexpr int DUMMY = 64 * 8 + ESW;
+    static constexpr int ticket = dummy0 + DUMMY;
+    static constexpr int total = ticket + 16;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// compute wave: stage with F fused sweeps
+// ---------------------------------------------------------------------------------------------------------------------------------
+// a * b with a = the HIGH half of the pair `hi2` broadcast (vt = SA.w, vp = SB.w).  The compiler folds low-half broadcasts into op_sel but
+// copies a high half into a fresh register first -- and schedules that copy right behind the load of the operand, which turns the
+// P-step prefetch into a stall.  One instruction, no copy:
+__device__ __forceinline__ v2f pk_mul_hi(v2f hi2, v2f b) {
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(hi2), "v"(b));
+    return r;
+}
+// The SOR point update (solver.c:337-343), the same operations in the same order as sor_device.h's sor_point: one rounding per
+// operation, no FMA.  hlz = the operand pair (hp, vp) of the PREVIOUS column: its low half is this point's left weight.
+__device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bottom, v2f left, v2f hlz, const float4 &SA, const float4 &SB, float omega) {
+    const v2f SAxy = {SA.x, SA.y}, SAzw = {SA.z, SA.w}, SBxy = {SB.x, SB.y}, SBzw = {SB.z, SB.w};
+    v2f s = __builtin_shufflevector(SBzw, SBzw, 0, 0) * right;       // hp * x_right
+    s = s + pk_mul_hi(SAzw, top);                                    // + vt * x_top
+    s = s + pk_mul_hi(SBzw, bottom);                                 // + vp * x_bottom
+    s = s + SBxy;                                                    // + b
+    const v2f B = __builtin_shufflevector(hlz, hlz, 0, 0) * left + s;
+    const v2f t2 = {SA.y * B.y, SA.z * B.y};                         // (a12 B2, a22 B2): two scalar products instead of composing the pair (a12, a22)
+    const v2f t = SAxy * __builtin_shufflevector(B, B, 0, 0) + t2;
+    return self + omega * (t - self);
+}
+
+// P0 = PD * CH steps of operand prefetch in registers for sweep 0 (first touch of the rows: Infinity Cache / HBM), P1 for the trailing
+// sweeps (the rows this CU fetched 2 f steps earlier: L2).  PD even: the ring parity of a chunk is its position in the unrolled body.
+// A slot is refilled one step AFTER its use: the next column's left weight (hp of this column) is read from it in place.
+template <int F, int CH, int PD>
+__device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char *lds, int ring_in, int ring_out, int tvb, int esb, int dummy, int job, int b,
+                                              int k0, int s_start, int lead, int lane) {
+    static_assert(PD % 2 == 0, "the chunk parity must be a compile-time constant of the body position");
+    constexpr int P0 = PD * CH, P1 = F <= 2 ? P0 : CH;
+    const int RP = a.RP;
+    const float omega = a.omega;
+    const int r0 = 64 * b - k0;
+    const long FOFF = 2L * RP + 1;
+    const long E0 = (long)(r0 + a.G) * RP + (r0 + a.G) + (long)s_start * RP - (long)(F - 1) * FOFF;   // entry of (first step, sweep F-1, lane 0)
+    const __amdgpu_buffer_rsrc_t rA = plane_rsrc(a.sa + (size_t)job * a.ent + E0, 0xffffff00ull);
+    const __amdgpu_buffer_rsrc_t rB = plane_rsrc(a.sb + (size_t)job * a.ent + E0, 0xffffff00ull);
+    unsigned vo[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) vo[f] = (unsigned)((lane + (F - 1 - f) * FOFF) * 16);
+    const unsigned st16 = (unsigned)RP * 16u;
+    unsigned so = 0;                                                  // byte offset of the step about to be computed
+
+    float4 sa0[P0], sb0[P0], sa1[F > 1 ? F - 1 : 1][P1], sb1[F > 1 ? F - 1 : 1][P1];
+#pragma unroll
+    for (int j = 0; j < P0; j++) { sa0[j] = bload16(rA, vo[0], j * st16); sb0[j] = bload16(rB, vo[0], j * st16); }
+#pragma unroll
+    for (int f = 1; f < F; f++)
+#pragma unroll
+        for (int j = 0; j < P1; j++) { sa1[f - 1][j] = bload16(rA, vo[f], j * st16); sb1[f - 1][j] = bload16(rB, vo[f], j * st16); }
+    float2 res[F], selfv[F];
+    v2f hlz[F];                                                       // (hp, vp) of the previous column; the first step sits in the zero guards
+#pragma unroll
+    for (int f = 0; f < F; f++) { res[f] = make_float2(0.f, 0.f); selfv[f] = make_float2(0.f, 0.f); hlz[f] = (v2f){0.f, 0.f}; }
+
+    const unsigned long long *rin = reinterpret_cast<const unsigned long long *>(lds + ring_in) + lane;
+    unsigned long long *rout = reinterpret_cast<unsigned long long *>(lds + ring_out) + lane;
+    const unsigned long long *tvp = reinterpret_cast<const unsigned long long *>(lds + tvb);
+    // lane 63's iterates of sweeps 0 .. F-2 go to the edge staging; the other lanes write into a dummy region (no exec masking)
+    unsigned long long *esp = reinterpret_cast<unsigned long long *>(lds + (lane == 63 ? esb : dummy + lane * 8));
+
+    int I = 0;
+    for (; I < lead; I++) SFA_CHAIN_BARRIER();
+    const int nbody = a.nch / PD;
+    for (int body = 0; body < nbody; body++) {
+#pragma unroll
+        for (int q = 0; q < PD; q++) {
+            SFA_CHAIN_BARRIER();
+            const int par = q & 1;
+            unsigned long long bot[CH], fl[CH][F + 1];
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                bot[j] = rin[(par * CH + j) * 64];
+#pragma unroll
+                for (int fi = 0; fi <= F; fi++) fl[j][fi] = tvp[(par * CH + j) * (F + 1) + fi];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const int j0 = q * CH + j, j1 = j0 % P1;             // ring slots of this step
+                const int p0 = (j0 + P0 - 1) % P0, p1 = (j1 + P1 - 1) % P1;   // ... and of the previous one
+                const float2 bottom0 = u2f(bot[j]);
+                float2 sh[F], right0;
+                { const float2 t = u2f(fl[j][0]); right0.x = lane_shr1(bottom0.x, t.x); right0.y = lane_shr1(bottom0.y, t.y); }
+#pragma unroll
+                for (int f = 0; f < F; f++) { const float2 t = u2f(fl[j][f + 1]); sh[f].x = lane_shr1(res[f].x, t.x); sh[f].y = lane_shr1(res[f].y, t.y); }
+                float2 nres[F];
+#pragma unroll
+                for (int f = 0; f < F; f++) {
+                    const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
+                    const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
+                    const float4 &SA = f == 0 ? sa0[j0] : sa1[f > 0 ? f - 1 : 0][j1];
+                    const float4 &SB = f == 0 ? sb0[j0] : sb1[f > 0 ? f - 1 : 0][j1];
+                    const v2f xn = sor_point2(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hlz[f], SA, SB, omega);
+                    nres[f] = make_float2(xn.x, xn.y);
+                    selfv[f] = right;
+                }
+#pragma unroll
+                for (int f = 0; f < F; f++) res[f] = nres[f];
+#pragma unroll
+                for (int f = 0; f + 1 < F; f++) esp[(par * (F - 1) + f) * CH + j] = f2u(res[f].x, res[f].y);
+                rout[(par * CH + j) * 64] = f2u(res[F - 1].x, res[F - 1].y);
+                // the PREVIOUS step's slots are refilled now (beyond the last step: zero guards); this step's (hp, vp) stay readable in place
+                sa0[p0] = bload16(rA, vo[0], so + (P0 - 1) * st16); sb0[p0] = bload16(rB, vo[0], so + (P0 - 1) * st16);
+#pragma unroll
+                for (int f = 1; f < F; f++) { sa1[f - 1][p1] = bload16(rA, vo[f], so + (P1 - 1) * st16); sb1[f - 1][p1] = bload16(rB, vo[f], so + (P1 - 1) * st16); }
+                hlz[0] = (v2f){sb0[j0].z, sb0[j0].w};
+#pragma unroll
+                for (int f = 1; f < F; f++) hlz[f] = (v2f){sb1[f - 1][j1].z, sb1[f - 1][j1].w};
+                so += st16;
+            }
+        }
+    }
+    I += a.nch;
+    for (; I < a.NI; I++) SFA_CHAIN_BARRIER();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// I/O wave
+// ---------------------------------------------------------------------------------------------------------------------------------
+// bounded wait for one progress word through the flags descriptor; `dead` (uniform): a wait has given up, never wait again
+__device__ __forceinline__ unsigned chain_wait(__amdgpu_buffer_rsrc_t rF, unsigned voff, unsigned soff, unsigned target, unsigned *err, bool &dead) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v = __builtin_amdgcn_readfirstlane(bload4_sc1(rF, voff, soff));
+        if (v >= target || dead) return v;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0) {
+            const unsigned e = ld_flag(err);
+            if (e || spins > kSpinLimit) {
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                return v;
+            }
+        }
+    }
+}
+
+template <class S, int CH, int AH>
+__device__ __forceinline__ void chain_io(const ChainArgs &a, unsigned char *lds, int job, int b, int g, int c_first, int c_first_prev, int lane) {
+    using L = ChainLds<S, CH>;
+    static_assert(AH % 2 == 0, "the LDS parities must be compile-time constants of the body position");
+    constexpr int NW = S::NW, LEAD = AH + 1;
+    constexpr int NTV = [] { int n = 0; for (int w = 0; w < NW; w++) n += (S::Fw(w) + 1) * CH; return n; }();      // values fetched from the band above per interval
+    constexpr int NES = [] { int n = 0; for (int w = 0; w < NW; w++) n += S::Fw(w) * CH; return n; }();            // lane-63 values stored per interval
+    constexpr int NLT = (NTV + 63) / 64, NSE = (NES + 63) / 64;
+    const int RP = a.RP, K = a.K, W = a.W, H = a.H;
+    const long FOFF = 2L * RP + 1;
+    const bool has_up = b > 0, has_prev = g > 0;
+    const int st0 = g * NW, k0g = g * S::KG;
+
+    // ---- descriptors ---------------------------------------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rE = plane_rsrc(a.edge, a.edge_bytes);
+    const __amdgpu_buffer_rsrc_t rF = plane_rsrc(a.gflags, a.flag_bytes);
+    // x plane as the first stage reads it: base = entry of (first step, sweep 0, lane 0) of stage st0
+    const int O0 = k0g - st0 + 1, s_start0 = c_first * CH - O0, r00 = 64 * b - k0g;
+    const long U00 = (long)(r00 + a.G) * RP + (r00 + a.G);
+    const __amdgpu_buffer_rsrc_t rXin = plane_rsrc(a.x + (size_t)job * a.ent + U00 + (long)s_start0 * RP, 0xffffff00ull);
+    // x plane as the last stage writes it: base = entry of (first step, sweep Fl-1, lane 0)
+    constexpr int Fl = S::Fw(NW - 1);
+    const int k0l = k0g + S::kw(NW - 1), Ol = k0l - (st0 + NW - 1) + 1, s_startl = c_first * CH - Ol, r0l = 64 * b - k0l;
+    const long U0l = (long)(r0l + a.G) * RP + (r0l + a.G);
+    const __amdgpu_buffer_rsrc_t rXout = plane_rsrc(a.x + (size_t)job * a.ent + U0l + (long)s_startl * RP - (long)(Fl - 1) * FOFF, 0xffffff00ull);
+
+    // ---- per-lane tables ------------------------------------------------------------------------------------------------------
+    // (1) values of the band above, fetched at interval I for the chunk c_first + I - w of stage w
+    unsigned tv_voff[NLT], tv_lds[NLT][2];
+    unsigned tvx_voff = kOobOffset;                       // stage 0 of the whole solve: "right" of sweep 0 for lane 0 is the INITIAL x(c + 1, r0)
+    bool tvx_lane[NLT];
+#pragma unroll
+    for (int n = 0; n < NLT; n++) {
+        const int i = n * 64 + lane;
+        int w = 0, base = 0;
+        while (w < NW - 1 && i >= base + (S::Fw(w) + 1) * CH) { base += (S::Fw(w) + 1) * CH; w++; }
+        const int Fw = S::Fw(w), rel = i - base, fi = rel / CH, j = rel % CH;
+        const bool on = i < NTV;
+        const int k0w = k0g + S::kw(w), Ow = k0w - (st0 + w) + 1;
+        const int s0 = (c_first - w) * CH - Ow;                                    // first local step of the chunk fetched at interval 0
+        const int row = k0w - 1 + fi, col = s0 + j + (fi == 0 ? 1 : -(fi - 1));
+        tvx_lane[n] = on && st0 + w == 0 && fi == 0;
+        const long off = (long)job * a.edge_job + ((long)(b - 1) * K + row) * a.Wp + a.EP + col;
+        tv_voff[n] = (on && has_up && !tvx_lane[n]) ? (unsigned)(off * 8) : kOobOffset;
+        if (tvx_lane[n]) tvx_voff = (unsigned)(((long)(s0 - s_start0 + j + 1) * RP) * 8);   // entry U00 + (s + 1) * RP relative to rXin's base
+        (void)Fw;
+#pragma unroll
+        for (int p = 0; p < 2; p++)                                                // p = parity of the WRITE interval; chunk parity = (p + w) & 1
+            tv_lds[n][p] = on ? (unsigned)(L::tv0 + w * L::TVW + ((((p + w) & 1) * CH + j) * (S::Fw(w) + 1) + fi) * 8) : (unsigned)(L::dummy0 + lane * 8);
+    }
+    // (2) lane 63's iterates, stored at interval I for the chunk c_first + I - 1 - LEAD - w of stage w
+    unsigned es_voff[NSE], es_lds[NSE][2];
+    int es_lo[NSE];
+#pragma unroll
+    for (int n = 0; n < NSE; n++) {
+        const int i = n * 64 + lane;
+        int w = 0, base = 0;
+        while (w < NW - 1 && i >= base + S::Fw(w) * CH) { base += S::Fw(w) * CH; w++; }
+        const int Fw = S::Fw(w), rel = i - base, f = rel / CH, j = rel % CH;
+        const bool on = i < NES;
+        const int k0w = k0g + S::kw(w), Ow = k0w - (st0 + w) + 1;
+        const int s0 = (c_first - 1 - LEAD - w) * CH - Ow;                         // chunk stored at interval 0 (not a real one)
+        const long off = (long)job * a.edge_job + ((long)b * K + k0w + f) * a.Wp + a.EP + (s0 + j - 63 - f);
+        es_voff[n] = on ? (unsigned)(off * 8) : kOobOffset;
+        es_lo[n] = on ? LEAD + w + 1 : 0x7fffffff;                                 // first interval with a real chunk
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int cp = (p + w) & 1;
+            es_lds[n][p] = !on ? (unsigned)(L::dummy0 + lane * 8)
+                         : f < Fw - 1 ? (unsigned)(L::es0 + w * L::ESW + ((cp * (Fw - 1) + f) * CH + j) * 8)
+                                      : (unsigned)(L::ring0 + (w + 1) * L::RING + ((cp * CH + j) * 64 + 63) * 8);
+        }
+    }
+    // (3) rows of the x plane
+    const unsigned vXin = (unsigned)(RP + lane + 1) * 8u;                          // (c, r + 1) of sweep 0: one diagonal further, one row down
+    const int rl = r0l + lane - (Fl - 1);
+    const unsigned vXout = (rl >= 0 && rl < H) ? (unsigned)lane * 8u : kOobOffset;
+    const int lanef = lane + (Fl - 1);
+    const unsigned st8 = (unsigned)RP * 8u;
+
+    // ---- progress words ---------------------------------------------------------------------------------------------------------
+    const unsigned vF0 = lane == 0 ? 0u : kOobOffset;
+    const unsigned so_mine = (unsigned)((((size_t)job * a.NB + b) * a.NG + g) * 4);
+    const unsigned so_up = so_mine - (unsigned)a.NG * 4u, so_up2 = so_up - 4u, so_prev = so_mine - 4u;
+    const unsigned vF_up = has_up ? vF0 : kOobOffset, vF_up2 = (has_up && has_prev) ? vF0 : kOobOffset, vF_prev = has_prev ? vF0 : kOobOffset;
+    // what the loads issued at interval I need (published-interval counts of the producers; see the header)
+    const int D63 = 63 / CH;
+    const int need_up0 = LEAD + 3 + D63;                                            // + I
+    const int dcf = c_first - c_first_prev;
+    const int need_up20 = 1 + D63 + dcf + LEAD + NW - 1 + 2;                        // + I   ((b-1, g-1): its last stage, chunk c_first + I + 1 + D63)
+    const int need_prev0 = dcf + LEAD + NW - 1 + 2;                                 // + I   ((b, g-1): its last stage, chunk c_first + I)
+    const unsigned cap = (unsigned)(a.nch + LEAD + NW);                              // at this count a producer has published every real chunk
+    // the progress words are polled asynchronously: a poll issued in interval I is looked at in interval I + PL, so that the I/O wave never
+    // sits on a load that is younger than PL intervals (its stores are published behind a counted wait of the same reach)
+    constexpr int PL = 2;
+    unsigned known_up = 0, known_up2 = 0, known_prev = 0, pend_up[AH], pend_up2[AH], pend_prev[AH];
+#pragma unroll
+    for (int q = 0; q < AH; q++) { pend_up[q] = 0; pend_up2[q] = 0; pend_prev[q] = 0; }
+    bool dead = false;
+
+    unsigned long long tvr[AH][NLT], tvxr[AH], xr[AH][CH];
+#pragma unroll
+    for (int q = 0; q < AH; q++) {
+        tvxr[q] = 0;
+#pragma unroll
+        for (int n = 0; n < NLT; n++) tvr[q][n] = 0;
+#pragma unroll
+        for (int j = 0; j < CH; j++) xr[q][j] = 0;
+    }
+    unsigned so_tv = 0, so_xin = 0, so_es = 0, so_xout = 0;          // advance by one chunk per interval
+    int s_out = s_startl - (1 + LEAD + NW - 1) * CH;                 // local step (last stage) of row 0 of the chunk stored at interval I
+    unsigned char *const ldsb = lds;
+    constexpr int NVM = 1 + 3 + NLT + 1 + CH + NSE + CH;            // VMEM instructions of one interval = issued between the stores of interval I-1 and the wait
+    static_assert(NVM <= 63, "vmcnt is a 6-bit counter");
+
+    for (int I0 = 0; I0 < a.NI; I0 += AH) {
+#pragma unroll
+        for (int q = 0; q < AH; q++) {
+            const int I = I0 + q;
+            const int p = q & 1;
+            SFA_CHAIN_BARRIER();
+            // ---- (a) what was fetched AH intervals ago goes to LDS: the compute waves use it in the NEXT interval ----------------
+#pragma unroll
+            for (int n = 0; n < NLT; n++) *reinterpret_cast<unsigned long long *>(ldsb + tv_lds[n][p]) = tvx_lane[n] ? tvxr[q] : tvr[q][n];   // (selected here, not when loaded: no wait on a fresh load)
+#pragma unroll
+            for (int j = 0; j < CH; j++) reinterpret_cast<unsigned long long *>(ldsb + L::ring0 + ((p * CH + j) * 64) * 8)[lane] = xr[q][j];
+            // ---- (b) what the compute waves produced in the PREVIOUS interval leaves (write-through) --------------------------------
+#pragma unroll
+            for (int n = 0; n < NSE; n++) {
+                const unsigned long long v = *reinterpret_cast<const unsigned long long *>(ldsb + es_lds[n][p]);
+                const bool act = I >= es_lo[n] && I < es_lo[n] + a.nch;
+                bstore8_sc1(rE, act ? es_voff[n] : kOobOffset, so_es, v);
+            }
+            {
+                const bool act = I >= LEAD + NW && I < LEAD + NW + a.nch;         // uniform
+                const int po = (p + NW - 1) & 1;
+                const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(ldsb + L::ring0 + NW * L::RING + (po * CH * 64) * 8) + lane;
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    const unsigned long long v = rp[j * 64];
+                    const bool ok = act && (unsigned)(s_out + j - lanef) < (unsigned)W;
+                    bstore8_sc1(rXout, ok ? vXout : kOobOffset, so_xout + (unsigned)j * st8, v);
+                }
+            }
+            // ---- (c) publish: the stores of interval I-1 are older than the NVM instructions issued since -----------------------------
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM - 1) : "memory");
+            bstore4_sc1(rF, vF0, so_mine, (unsigned)I);
+            // ---- (d) the workgroups this one depends on ---------------------------------------------------------------------------------
+            known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up[(q + AH - PL) % AH]));
+            known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2[(q + AH - PL) % AH]));
+            known_prev = max(known_prev, (unsigned)__builtin_amdgcn_readfirstlane(pend_prev[(q + AH - PL) % AH]));
+            if (!dead) {
+                const unsigned n_up = min((unsigned)(need_up0 + I), cap), n_up2 = min((unsigned)(need_up20 + I), cap), n_prev = min((unsigned)(need_prev0 + I), cap);
+                if (has_up && known_up < n_up) known_up = chain_wait(rF, vF0, so_up, n_up, a.err, dead);
+                if (has_up && has_prev && known_up2 < n_up2) known_up2 = chain_wait(rF, vF0, so_up2, n_up2, a.err, dead);
+                if (has_prev && known_prev < n_prev) known_prev = chain_wait(rF, vF0, so_prev, n_prev, a.err, dead);
+            }
+            pend_up[q] = bload4_sc1(rF, vF_up, so_up);
+            pend_up2[q] = bload4_sc1(rF, vF_up2, so_up2);
+            pend_prev[q] = bload4_sc1(rF, vF_prev, so_prev);
+            // ---- (e) fetch for the chunk the compute waves run in interval I + AH + 1 -----------------------------------------------------
+#pragma unroll
+            for (int n = 0; n < NLT; n++) tvr[q][n] = bload8_sc1(rE, tv_voff[n], so_tv);
+            tvxr[q] = bload8_sc1(rXin, tvx_voff, so_xin);
+#pragma unroll
+            for (int j = 0; j < CH; j++) xr[q][j] = bload8_sc1(rXin, vXin, so_xin + (unsigned)j * st8);
+            so_tv += CH * 8u; so_es += CH * 8u; so_xin += CH * st8; s_out += CH;
+            if (I >= LEAD + NW) so_xout += CH * st8;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bstore4_sc1(rF, vF0, so_mine, 0x7fffffffu);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int FA, int NA, int FB, int NB_, int CH, int PD, int AH>
+__global__ void __launch_bounds__((NA + NB_ + 1) * 64) k_sor_chain(ChainArgs a) {
+    using S = ChainShape<FA, NA, FB, NB_>;
+    using L = ChainLds<S, CH>;
+    constexpr int NW = S::NW, LEAD = AH + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned *s_ticket = reinterpret_cast<unsigned *>(smem + L::ticket);
+    if (threadIdx.x == 0) *s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * a.NG, 1u);
+    // the rings and staging areas are read before they are first written (start-up intervals): zeros, not garbage
+    for (int i = threadIdx.x; i < L::ticket / 8; i += (NW + 1) * 64) reinterpret_cast<unsigned long long *>(smem)[i] = 0ull;
+    __syncthreads();
+    const unsigned t = __builtin_amdgcn_readfirstlane(*s_ticket);
+    if (t >= (unsigned)(a.nb * a.NB * a.NG)) return;
+    const int job = t % a.nb;
+    const int2 bg = a.order[t / a.nb];
+    const int b = __builtin_amdgcn_readfirstlane(bg.x), g = __builtin_amdgcn_readfirstlane(bg.y);
+    // first chunk of the group (even): every stage of the group starts at a local step <= -1
+    const int c_first = ((g * (S::KG - NW)) / CH) & ~1;
+    const int c_first_prev = g > 0 ? (((g - 1) * (S::KG - NW)) / CH) & ~1 : 0;
+    if (wave == NW) { chain_io<S, CH, AH>(a, smem, job, b, g, c_first, c_first_prev, lane); return; }
+    const int st = g * NW + wave, k0 = g * S::KG + S::kw(wave), O = k0 - st + 1;
+    const int s_start = c_first * CH - O;
+    const int ring_in = L::ring0 + wave * L::RING, ring_out = ring_in + L::RING;
+    const int tvb = L::tv0 + wave * L::TVW, esb = L::es0 + wave * L::ESW;
+    if (wave < NA) chain_compute<FA, CH, PD>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + wave, lane);
+    else           chain_compute<FB, CH, PD>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int kChainCH = 4, kChainAH = 4;
+
+struct ChainShapeInfo { int id, FA, NA, FB, NB_, PD; };
+static const ChainShapeInfo kChainShapes[] = {
+    {1, 1, 3, 1, 0, 4},      // 3 stages of 1 sweep            KG = 3
+    {2, 2, 3, 2, 0, 2},      // 3 stages of 2                  KG = 6
+    {3, 3, 5, 3, 0, 2},      // 5 stages of 3                  KG = 15
+    {5, 2, 5, 2, 0, 2},      // 5 stages of 2                  KG = 10
+    {6, 1, 5, 1, 0, 4},      // 5 stages of 1                  KG = 5
+    {8, 3, 2, 3, 0, 2},      // 2 stages of 3                  KG = 6
+};
+
+bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
+    for (const ChainShapeInfo &s : kChainShapes)
+        if (s.id == id) {
+            const int kg = s.NA * s.FA + s.NB_ * s.FB;
+            if (K % kg != 0) return false;
+            *KG = kg; *NW = s.NA + s.NB_; *FMAX = std::max(s.FA, s.NB_ ? s.FB : s.FA);
+            return true;
+        }
+    return false;
+}
+int chain_ch() { return kChainCH; }
+int chain_ah() { return kChainAH; }
+
+template <int FA, int NA, int FB, int NB_, int PD>
+static void chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
+    using S = ChainShape<FA, NA, FB, NB_>;
+    using L = ChainLds<S, kChainCH>;
+    hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH>), dim3(nwg), dim3((S::NW + 1) * 64), L::total, c->stream, a);
+}
+
+int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float omega) {
+    ChainArgs a;
+    a.sa = (const float4 *)ws.sa.p; a.sb = (const float4 *)ws.sb.p; a.x = (unsigned long long *)ws.x.p; a.edge = (unsigned long long *)ws.edge.p;
+    a.gflags = (unsigned *)ws.flags.p; a.order = (const int2 *)ws.order.p; a.err = c->d_err;
+    a.ent = ws.ent; a.edge_job = ws.edge_job; a.edge_bytes = (unsigned long long)g.nb * ws.edge_job * 8ull;
+    a.flag_bytes = ((unsigned long long)g.nb * ws.ntasks + 16) * 4ull;
+    a.W = g.w; a.H = g.h; a.K = K; a.NB = ws.NB; a.NG = ws.NG; a.RP = ws.RP; a.G = ws.G; a.nb = g.nb; a.Wp = ws.Wp; a.EP = ws.EP;
+    a.nch = ws.NCH; a.NI = ws.NS; a.omega = omega;
+    const int nwg = g.nb * ws.NB * ws.NG;
+    switch (ws.chain) {
+        case 1: chain_launch_shape<1, 3, 1, 0, 4>(c, a, nwg); break;
+        case 2: chain_launch_shape<2, 3, 2, 0, 2>(c, a, nwg); break;
+        case 3: chain_launch_shape<3, 5, 3, 0, 2>(c, a, nwg); break;
+        case 5: chain_launch_shape<2, 5, 2, 0, 2>(c, a, nwg); break;
+        case 6: chain_launch_shape<1, 5, 1, 0, 4>(c, a, nwg); break;
+        case 8: chain_launch_shape<3, 2, 3, 0, 2>(c, a, nwg); break;
+        default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
+    }
+    return SFA_OK;
+}
+
+}  // namespace sfa

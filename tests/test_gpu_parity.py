@@ -253,7 +253,11 @@ def test_sor_full_size_and_batch(ctx, oracle):
 SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH": "8"}, "task_f1_ch16": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH": "16"}, "task_f2": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "2"},
                 "task_f3": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "3", "SFA_SOR_CH": "4"},
                 "band_f1": {"SFA_SOR_BAND": "1"}, "band_f2": {"SFA_SOR_BAND": "2"}, "band_f3": {"SFA_SOR_BAND": "3"},
-                "band_f5": {"SFA_SOR_BAND": "5"}, "band_f6": {"SFA_SOR_BAND": "6"}, "band_mixed_4x6_3x2": {"SFA_SOR_BAND": "43"}}
+                "band_f5": {"SFA_SOR_BAND": "5"}, "band_f6": {"SFA_SOR_BAND": "6"}, "band_mixed_4x6_3x2": {"SFA_SOR_BAND": "43"},
+                # sor_chain.hip (few windows per launch): groups of stages per workgroup + I/O wave; a shape whose sweeps per group do not divide K
+                # falls back to the kernels above
+                "chain_1x3": {"SFA_SOR_CHAIN": "1"}, "chain_2x3": {"SFA_SOR_CHAIN": "2"}, "chain_3x5": {"SFA_SOR_CHAIN": "3"}, "chain_2x5": {"SFA_SOR_CHAIN": "5"},
+                "chain_1x5": {"SFA_SOR_CHAIN": "6"}, "chain_3x2": {"SFA_SOR_CHAIN": "8"}}
 
 
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))
@@ -263,6 +267,10 @@ def test_sor_kernel_variants(ctx, oracle, monkeypatch, variant, w, h, K):
     """every solver kernel (task pipeline with 1/2/3 fused sweeps per wave, band pipeline with 1/2/3/5/6: a shape that does not divide K falls back
     to the next that does) gives the
     raster-order result bit for bit, for each element of a batch of two different systems"""
+    for k in ("SFA_SOR_BAND", "SFA_SOR_F", "SFA_SOR_CH", "SFA_SOR_CHAIN"):
+        monkeypatch.delenv(k, raising=False)
+    if not variant.startswith("chain"):
+        monkeypatch.setenv("SFA_SOR_CHAIN", "0")
     for k, v in SOR_VARIANTS[variant].items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(w + 3 * h + K)

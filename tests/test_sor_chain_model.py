@@ -1,0 +1,37 @@
+"""The few-windows solver kernel (slowflow_amd/csrc/sor_chain.hip) splits sor_coupled over workgroups that hand data over through memory
+behind progress words.  Its index arithmetic and wait thresholds are transcribed into a CPU model (tools/sim_sor_chain.py) that runs
+them under adversarial visibility and workgroup order; the model must reproduce the raster-order oracle bit for bit, and it must FAIL
+when a threshold is weakened by one interval (the thresholds are tight, the model is sensitive)."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _sim(mode, slack):
+    os.environ["SIM_MODE"], os.environ["SIM_SLACK"] = mode, str(slack)
+    spec = importlib.util.spec_from_file_location(f"sim_sor_chain_{mode}_{slack}", os.path.join(ROOT, "tools", "sim_sor_chain.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    os.environ.pop("SIM_MODE"); os.environ.pop("SIM_SLACK")
+    return m
+
+
+CASES = [(40, 70, 12, (2, 3, 2, 0), 1), (50, 130, 9, (1, 3, 1, 0), 2), (45, 100, 14, (4, 1, 3, 1), 1), (33, 150, 12, (3, 2, 3, 0), 1), (37, 200, 10, (2, 5, 2, 0), 1)]
+
+
+@pytest.mark.parametrize("mode", ["raw", "war"])
+@pytest.mark.parametrize("w,h,K,shape,nb", CASES)
+def test_chain_protocol_model_reproduces_the_oracle(mode, w, h, K, shape, nb):
+    m = _sim(mode, 0)
+    bad, _ = m.run(w, h, K, m.Shape(*shape), nb)
+    assert bad == 0
+
+
+def test_chain_protocol_thresholds_are_tight():
+    m = _sim("raw", 1)
+    bad, _ = m.run(40, 70, 12, m.Shape(2, 3, 2, 0), 1)
+    assert bad > 0
