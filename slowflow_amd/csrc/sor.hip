@@ -806,6 +806,7 @@ int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float
 // sor_chain.hip: the few-windows pipeline (groups of stages per workgroup, I/O wave)
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX);
 int chain_ch();
+int chain_flag_stride();
 int chain_ah();
 int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float omega);
 
@@ -901,7 +902,7 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
         NCH = round_up((w + 64 + KG - NW + 2 * CH + FMAX + CH - 1) / CH, 4);
         NS = round_up(NCH + LEAD + NW + 2, AH);
         ND = NS * CH + 64 * NB + G + 32;                      // diagonals: the I/O wave reads the x plane up to interval NS, the bands sit 64 rows apart
-        ntasks = NB * NG;
+        ntasks = NB * NG * chain_flag_stride();               // progress words per window (one 128-byte line per workgroup); the ticket follows the last window's
         ent = (long)ND * RP;
         EP = 256;
         Wp = round_up(EP + NS * CH + 64 + 2 * K + 64, 8);
@@ -912,12 +913,12 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
         SFA_TRY(sb.alloc(c, (size_t)nb * ent * sizeof(float4)));
         SFA_TRY(x.alloc(c, (size_t)nb * ent * sizeof(unsigned long long)));
         SFA_TRY(flags.alloc(c, ((size_t)nb * ntasks + 16) * sizeof(unsigned)));
-        SFA_TRY(order.alloc(c, (size_t)ntasks * sizeof(int2)));
+        SFA_TRY(order.alloc(c, (size_t)NB * NG * sizeof(int2)));
         SFA_HIP(c, hipMemsetAsync(sa.p, 0, (size_t)nb * ent * sizeof(float4), c->stream));
         SFA_HIP(c, hipMemsetAsync(sb.p, 0, (size_t)nb * ent * sizeof(float4), c->stream));
         SFA_HIP(c, hipMemsetAsync(x.p, 0, (size_t)nb * ent * sizeof(unsigned long long), c->stream));
         std::vector<int2> ord;                               // ticket order: ascending 3 b + g; (b-1,g), (b,g-1), (b-1,g-1) all come earlier
-        ord.reserve(ntasks);
+        ord.reserve(NB * NG);
         for (int key = 0; key <= 3 * (NB - 1) + (NG - 1); key++)
             for (int b = 0; b < NB; b++) {
                 const int g = key - 3 * b;

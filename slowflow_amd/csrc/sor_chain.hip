@@ -46,6 +46,9 @@ struct ChainArgs {
     float omega;
 };
 
+// one progress word per workgroup, each on a 128-byte line of its own: every OUT wave updates its word once per interval (atomic) and up to
+// three IN waves poll it; packed 4 bytes apart the words of a whole solve sat on three lines and every atomic queued behind all the others
+constexpr int kFlagStride = 32;      // words
 constexpr unsigned kAuxSc1 = 16;   // raw buffer builtins: aux bit 4 = sc1 (bit 0 sc0, bit 1 nt)
 
 __device__ __forceinline__ unsigned long long bload8_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -59,8 +62,52 @@ __device__ __forceinline__ void bstore8_sc1(__amdgpu_buffer_rsrc_t r, unsigned v
 __device__ __forceinline__ unsigned bload4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxSc1); }
 __device__ __forceinline__ void bstore4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, kAuxSc1); }
 
+// Everything that LEAVES a workgroup goes out as no-return buffer atomics (8-byte swaps for data, a 4-byte unsigned max for the progress word).
+// Measured on MI355X (tools/chain_timing.py, -DSFA_X_NOIO_POLL builds): ONE write-through store of 4 or 8 bytes per lane (sc1, nt or sc0 sc1)
+// per interval from any wave of a CU holds up that CU's whole load stream for ~520 cycles (the three stages' operand prefetch: 941 -> 1527-1656
+// cycles per 4-step chunk); plain stores, 16-byte sc1 stores, bypassing loads and no-return atomics cost the other waves nothing (1007-1014).
+// Rows of the iterate start at odd entries for half of the stages, so 16-byte stores do not fit them; atomics execute at the memory side
+// ("drop the line"), are counted in vmcnt in issue order like stores, and a consumer's sc1 loads behind the progress word see them.
+// The clang builtins cover only a few buffer atomics: inline asm (no result register, so nothing for the compiler's waitcnt pass to track).
+struct RsrcWords { v4u w; };
+__device__ __forceinline__ RsrcWords rsrc_words(const void *base, unsigned long long bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    RsrcWords r;
+    r.w.x = __builtin_amdgcn_readfirstlane((unsigned)p);
+    r.w.y = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xffffu;
+    r.w.z = __builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xffffff00ull ? 0xffffff00ull : bytes));
+    r.w.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void batomic_swap8(const RsrcWords &r, unsigned voff, unsigned soff, unsigned long long v) {
+#ifdef SFA_X_OUT_NOATOM   // timing experiment only
+    asm volatile("" ::"v"(v), "v"(voff), "s"(r.w), "s"(soff)); return;
+#endif
+    asm volatile("buffer_atomic_swap_x2 %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(r.w), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void batomic_umax4(const RsrcWords &r, unsigned voff, unsigned soff, unsigned v) {
+#ifdef SFA_X_OUT_NOATOM   // timing experiment only
+    asm volatile("" ::"v"(v), "v"(voff), "s"(r.w), "s"(soff)); return;
+#endif
+    asm volatile("buffer_atomic_umax %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(r.w), "s"(soff) : "memory");
+}
+
 // one barrier interval: the LDS writes of the interval are complete before any wave passes
 #define SFA_CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+#ifdef SFA_CHAIN_TIMING
+// per-phase wave cycles (s_memtime) of the first workgroups of window 0: [wg < 64][wave < 8][16 words]
+__device__ unsigned long long g_chain_timing[64 * 8 * 16];
+#define SFA_CT_STAMP(t) do { t = __builtin_readcyclecounter(); } while (0)
+// stamped barrier: time spent waiting at the barrier goes to `acc`
+#define SFA_CHAIN_BARRIER_T(acc) do { unsigned long long _t0, _t1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); _t0 = __builtin_readcyclecounter(); \
+    asm volatile("s_barrier" ::: "memory"); _t1 = __builtin_readcyclecounter(); acc += _t1 - _t0; } while (0)
+#define SFA_CHAIN_BARRIER_T2(acc, accw) do { unsigned long long _t0, _t1, _tw = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); _t0 = __builtin_readcyclecounter(); \
+    asm volatile("s_barrier" ::: "memory"); _t1 = __builtin_readcyclecounter(); acc += _t1 - _t0; accw += _t0 - _tw; } while (0)
+#else
+#define SFA_CHAIN_BARRIER_T(acc) SFA_CHAIN_BARRIER()
+#define SFA_CHAIN_BARRIER_T2(acc, accw) SFA_CHAIN_BARRIER()
+#endif
 
 // shape of a workgroup: NA stages of FA sweeps, then NB_ stages of FB sweeps
 template <int FA, int NA, int FB, int NB_>
@@ -102,6 +149,9 @@ __device__ __forceinline__ v2f pk_mul_hi(v2f hi2, v2f b) {
 // operation, no FMA.  hlz = the operand pair (hp, vp) of the PREVIOUS column: its low half is this point's left weight.
 __device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bottom, v2f left, v2f hlz, const float4 &SA, const float4 &SB, float omega) {
     const v2f SAxy = {SA.x, SA.y}, SAzw = {SA.z, SA.w}, SBxy = {SB.x, SB.y}, SBzw = {SB.z, SB.w};
+#ifdef SFA_X_NOARITH      // timing experiment only: one dependent operation instead of fifteen
+    return self + right * SAxy + top * SBxy + bottom * SAzw + left * hlz;
+#endif
     v2f s = __builtin_shufflevector(SBzw, SBzw, 0, 0) * right;       // hp * x_right
     s = s + pk_mul_hi(SAzw, top);                                    // + vt * x_top
     s = s + pk_mul_hi(SBzw, bottom);                                 // + vp * x_bottom
@@ -125,8 +175,13 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
     const int r0 = 64 * b - k0;
     const long FOFF = 2L * RP + 1;
     const long E0 = (long)(r0 + a.G) * RP + (r0 + a.G) + (long)s_start * RP - (long)(F - 1) * FOFF;   // entry of (first step, sweep F-1, lane 0)
+#ifdef SFA_X_NOLOAD       // timing experiment only: zero records, the range check drops every operand load
+    const __amdgpu_buffer_rsrc_t rA = plane_rsrc(a.sa + (size_t)job * a.ent + E0, 0);
+    const __amdgpu_buffer_rsrc_t rB = plane_rsrc(a.sb + (size_t)job * a.ent + E0, 0);
+#else
     const __amdgpu_buffer_rsrc_t rA = plane_rsrc(a.sa + (size_t)job * a.ent + E0, 0xffffff00ull);
     const __amdgpu_buffer_rsrc_t rB = plane_rsrc(a.sb + (size_t)job * a.ent + E0, 0xffffff00ull);
+#endif
     unsigned vo[F];
 #pragma unroll
     for (int f = 0; f < F; f++) vo[f] = (unsigned)((lane + (F - 1 - f) * FOFF) * 16);
@@ -152,12 +207,18 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
     unsigned long long *esp = reinterpret_cast<unsigned long long *>(lds + (lane == 63 ? esb : dummy + lane * 8));
 
     int I = 0;
-    for (; I < lead; I++) SFA_CHAIN_BARRIER();
+#ifdef SFA_CHAIN_TIMING
+    unsigned long long t_begin = __builtin_readcyclecounter(), t_lead = 0, t_bar = 0, t_first = 0, t_last = 0, t_ldsrd = 0, t_wr = 0;
+#endif
+    for (; I < lead; I++) SFA_CHAIN_BARRIER_T(t_lead);
+#ifdef SFA_CHAIN_TIMING
+    t_first = __builtin_readcyclecounter();
+#endif
     const int nbody = a.nch / PD;
     for (int body = 0; body < nbody; body++) {
 #pragma unroll
         for (int q = 0; q < PD; q++) {
-            SFA_CHAIN_BARRIER();
+            SFA_CHAIN_BARRIER_T2(t_bar, t_wr);
             const int par = q & 1;
             unsigned long long bot[CH], fl[CH][F + 1];
 #pragma unroll
@@ -166,6 +227,13 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
 #pragma unroll
                 for (int fi = 0; fi <= F; fi++) fl[j][fi] = tvp[(par * CH + j) * (F + 1) + fi];
             }
+#ifdef SFA_CHAIN_TIMING
+            {   // how long the chunk's LDS reads take (diagnosis only: the wait is forced here)
+                unsigned long long ta = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                t_ldsrd += __builtin_readcyclecounter() - ta;
+            }
+#endif
 #pragma unroll
             for (int j = 0; j < CH; j++) {
                 const int j0 = q * CH + j, j1 = j0 % P1;             // ring slots of this step
@@ -203,6 +271,14 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
         }
     }
     I += a.nch;
+#ifdef SFA_CHAIN_TIMING
+    t_last = __builtin_readcyclecounter();
+    if (job == 0 && lane == 0 && (int)blockIdx.x < 64) {
+        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+        o[0] = t_begin; o[1] = t_first; o[2] = t_last; o[3] = t_lead; o[4] = t_bar; o[5] = (unsigned long long)b; o[6] = (unsigned long long)k0; o[7] = (unsigned long long)a.nch;
+        o[8] = t_ldsrd; o[9] = t_wr; o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     for (; I < a.NI; I++) SFA_CHAIN_BARRIER();
 }
 
@@ -227,34 +303,47 @@ __device__ __forceinline__ unsigned chain_wait(__amdgpu_buffer_rsrc_t rF, unsign
     }
 }
 
-template <class S, int CH, int AH>
-__device__ __forceinline__ void chain_io(const ChainArgs &a, unsigned char *lds, int job, int b, int g, int c_first, int c_first_prev, int lane) {
+// What the two I/O waves share: where the workgroup's stages sit
+template <class S, int CH>
+struct ChainGeo {
+    int RP, K, W, H, st0, k0g;
+    long FOFF;
+    int s_start0, s_startl, r0l;
+    long U00, U0l;
+    __device__ __forceinline__ ChainGeo(const ChainArgs &a, int b, int g, int c_first) {
+        constexpr int NW = S::NW, Fl = S::Fw(NW - 1);
+        RP = a.RP; K = a.K; W = a.W; H = a.H; FOFF = 2L * RP + 1;
+        st0 = g * NW; k0g = g * S::KG;
+        const int O0 = k0g - st0 + 1, r00 = 64 * b - k0g;
+        s_start0 = c_first * CH - O0;
+        U00 = (long)(r00 + a.G) * RP + (r00 + a.G);
+        const int k0l = k0g + S::kw(NW - 1), Ol = k0l - (st0 + NW - 1) + 1;
+        s_startl = c_first * CH - Ol; r0l = 64 * b - k0l;
+        U0l = (long)(r0l + a.G) * RP + (r0l + a.G);
+        (void)Fl;
+    }
+};
+
+// ---- IN wave: progress words of the producers, the band above's lane-63 values and the previous group's iterate -> LDS ------------------
+// AH: intervals between a load and its use (register FIFO); PL: intervals between a poll and the look at its result;
+// PUBD: intervals between a store and the progress word that covers it (OUT wave) -- the consumer's thresholds are in published counts,
+// so only the producer knows PUBD.
+template <class S, int CH, int AH, int PL>
+__device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds, int job, int b, int g, int c_first, int c_first_prev, int lane) {
     using L = ChainLds<S, CH>;
-    static_assert(AH % 2 == 0, "the LDS parities must be compile-time constants of the body position");
+    static_assert(AH % 2 == 0 && PL <= AH, "the LDS parities must be compile-time constants of the body position");
     constexpr int NW = S::NW, LEAD = AH + 1;
     constexpr int NTV = [] { int n = 0; for (int w = 0; w < NW; w++) n += (S::Fw(w) + 1) * CH; return n; }();      // values fetched from the band above per interval
-    constexpr int NES = [] { int n = 0; for (int w = 0; w < NW; w++) n += S::Fw(w) * CH; return n; }();            // lane-63 values stored per interval
-    constexpr int NLT = (NTV + 63) / 64, NSE = (NES + 63) / 64;
-    const int RP = a.RP, K = a.K, W = a.W, H = a.H;
-    const long FOFF = 2L * RP + 1;
+    constexpr int NLT = (NTV + 63) / 64;
+    const ChainGeo<S, CH> G(a, b, g, c_first);
+    const int RP = G.RP, K = G.K;
     const bool has_up = b > 0, has_prev = g > 0;
-    const int st0 = g * NW, k0g = g * S::KG;
-
-    // ---- descriptors ---------------------------------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t rE = plane_rsrc(a.edge, a.edge_bytes);
     const __amdgpu_buffer_rsrc_t rF = plane_rsrc(a.gflags, a.flag_bytes);
     // x plane as the first stage reads it: base = entry of (first step, sweep 0, lane 0) of stage st0
-    const int O0 = k0g - st0 + 1, s_start0 = c_first * CH - O0, r00 = 64 * b - k0g;
-    const long U00 = (long)(r00 + a.G) * RP + (r00 + a.G);
-    const __amdgpu_buffer_rsrc_t rXin = plane_rsrc(a.x + (size_t)job * a.ent + U00 + (long)s_start0 * RP, 0xffffff00ull);
-    // x plane as the last stage writes it: base = entry of (first step, sweep Fl-1, lane 0)
-    constexpr int Fl = S::Fw(NW - 1);
-    const int k0l = k0g + S::kw(NW - 1), Ol = k0l - (st0 + NW - 1) + 1, s_startl = c_first * CH - Ol, r0l = 64 * b - k0l;
-    const long U0l = (long)(r0l + a.G) * RP + (r0l + a.G);
-    const __amdgpu_buffer_rsrc_t rXout = plane_rsrc(a.x + (size_t)job * a.ent + U0l + (long)s_startl * RP - (long)(Fl - 1) * FOFF, 0xffffff00ull);
+    const __amdgpu_buffer_rsrc_t rXin = plane_rsrc(a.x + (size_t)job * a.ent + G.U00 + (long)G.s_start0 * RP, 0xffffff00ull);
 
-    // ---- per-lane tables ------------------------------------------------------------------------------------------------------
-    // (1) values of the band above, fetched at interval I for the chunk c_first + I - w of stage w
+    // values of the band above, fetched at interval I for the chunk c_first + I - w of stage w
     unsigned tv_voff[NLT], tv_lds[NLT][2];
     unsigned tvx_voff = kOobOffset;                       // stage 0 of the whole solve: "right" of sweep 0 for lane 0 is the INITIAL x(c + 1, r0)
     bool tvx_lane[NLT];
@@ -263,21 +352,126 @@ __device__ __forceinline__ void chain_io(const ChainArgs &a, unsigned char *lds,
         const int i = n * 64 + lane;
         int w = 0, base = 0;
         while (w < NW - 1 && i >= base + (S::Fw(w) + 1) * CH) { base += (S::Fw(w) + 1) * CH; w++; }
-        const int Fw = S::Fw(w), rel = i - base, fi = rel / CH, j = rel % CH;
+        const int rel = i - base, fi = rel / CH, j = rel % CH;
         const bool on = i < NTV;
-        const int k0w = k0g + S::kw(w), Ow = k0w - (st0 + w) + 1;
+        const int k0w = G.k0g + S::kw(w), Ow = k0w - (G.st0 + w) + 1;
         const int s0 = (c_first - w) * CH - Ow;                                    // first local step of the chunk fetched at interval 0
         const int row = k0w - 1 + fi, col = s0 + j + (fi == 0 ? 1 : -(fi - 1));
-        tvx_lane[n] = on && st0 + w == 0 && fi == 0;
+        tvx_lane[n] = on && G.st0 + w == 0 && fi == 0;
         const long off = (long)job * a.edge_job + ((long)(b - 1) * K + row) * a.Wp + a.EP + col;
         tv_voff[n] = (on && has_up && !tvx_lane[n]) ? (unsigned)(off * 8) : kOobOffset;
-        if (tvx_lane[n]) tvx_voff = (unsigned)(((long)(s0 - s_start0 + j + 1) * RP) * 8);   // entry U00 + (s + 1) * RP relative to rXin's base
-        (void)Fw;
+        if (tvx_lane[n]) tvx_voff = (unsigned)(((long)(s0 - G.s_start0 + j + 1) * RP) * 8);   // entry U00 + (s + 1) * RP relative to rXin's base
 #pragma unroll
         for (int p = 0; p < 2; p++)                                                // p = parity of the WRITE interval; chunk parity = (p + w) & 1
             tv_lds[n][p] = on ? (unsigned)(L::tv0 + w * L::TVW + ((((p + w) & 1) * CH + j) * (S::Fw(w) + 1) + fi) * 8) : (unsigned)(L::dummy0 + lane * 8);
     }
-    // (2) lane 63's iterates, stored at interval I for the chunk c_first + I - 1 - LEAD - w of stage w
+#ifdef SFA_X_NOXLOAD      // timing experiment only
+    const unsigned vXin = kOobOffset;
+#else
+    const unsigned vXin = (unsigned)(RP + lane + 1) * 8u;                          // (c, r + 1) of sweep 0: one diagonal further, one row down
+#endif
+    const unsigned st8 = (unsigned)RP * 8u;
+
+    // progress words: published-interval counts of the producers (one word per workgroup)
+    const unsigned vF0 = lane == 0 ? 0u : kOobOffset;
+    const unsigned so_mine = (unsigned)((((size_t)job * a.NB + b) * a.NG + g) * 4 * kFlagStride);
+    const unsigned so_up = so_mine - (unsigned)a.NG * 4u * kFlagStride, so_up2 = so_up - 4u * kFlagStride, so_prev = so_mine - 4u * kFlagStride;
+    const unsigned vF_up = has_up ? vF0 : kOobOffset, vF_up2 = (has_up && has_prev) ? vF0 : kOobOffset, vF_prev = has_prev ? vF0 : kOobOffset;
+    // what the loads issued at interval I need (see the header; a producer's stage w computes chunk c in its interval c - c_first + LEAD + w,
+    // the OUT wave stores it one interval later, and a published count v says: the stores of all intervals < v are complete)
+    const int D63 = 63 / CH;
+    const int need_up0 = LEAD + 3 + D63;                                            // + I
+    const int dcf = c_first - c_first_prev;
+    const int need_up20 = 1 + D63 + dcf + LEAD + NW - 1 + 2;                        // + I   ((b-1, g-1): its last stage, chunk c_first + I + 1 + D63)
+    const int need_prev0 = dcf + LEAD + NW - 1 + 2;                                 // + I   ((b, g-1): its last stage, chunk c_first + I)
+    const unsigned cap = (unsigned)(a.nch + LEAD + NW);                              // at this count a producer has published every real chunk
+    unsigned known_up = 0, known_up2 = 0, known_prev = 0, pend_up[AH], pend_up2[AH], pend_prev[AH];
+    bool dead = false;
+    unsigned long long tvr[AH][NLT], tvxr[AH], xr[AH][CH];
+#pragma unroll
+    for (int q = 0; q < AH; q++) {
+        tvxr[q] = 0; pend_up[q] = 0; pend_up2[q] = 0; pend_prev[q] = 0;
+#pragma unroll
+        for (int n = 0; n < NLT; n++) tvr[q][n] = 0;
+#pragma unroll
+        for (int j = 0; j < CH; j++) xr[q][j] = 0;
+    }
+    unsigned so_tv = 0, so_xin = 0;                                  // advance by one chunk per interval
+    unsigned char *const ldsb = lds;
+#ifdef SFA_CHAIN_TIMING
+    unsigned long long t_begin = __builtin_readcyclecounter(), t_bar = 0, t_slow = 0, n_slow = 0, t0, t1;
+#endif
+    for (int I0 = 0; I0 < a.NI; I0 += AH) {
+#pragma unroll
+        for (int q = 0; q < AH; q++) {
+            const int I = I0 + q;
+            const int p = q & 1;
+            SFA_CHAIN_BARRIER_T(t_bar);
+            // ---- what was fetched AH intervals ago goes to LDS: the compute waves use it in the NEXT interval --------------------------
+#pragma unroll
+            for (int n = 0; n < NLT; n++) *reinterpret_cast<unsigned long long *>(ldsb + tv_lds[n][p]) = tvx_lane[n] ? tvxr[q] : tvr[q][n];
+#pragma unroll
+            for (int j = 0; j < CH; j++) reinterpret_cast<unsigned long long *>(ldsb + L::ring0 + ((p * CH + j) * 64) * 8)[lane] = xr[q][j];
+            // ---- the workgroups this one depends on: polls issued PL intervals ago -------------------------------------------------------
+            known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up[(q + AH - PL) % AH]));
+            known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2[(q + AH - PL) % AH]));
+            known_prev = max(known_prev, (unsigned)__builtin_amdgcn_readfirstlane(pend_prev[(q + AH - PL) % AH]));
+            if (!dead) {
+                const unsigned n_up = min((unsigned)(need_up0 + I), cap), n_up2 = min((unsigned)(need_up20 + I), cap), n_prev = min((unsigned)(need_prev0 + I), cap);
+                const bool w1 = has_up && known_up < n_up, w2 = has_up && has_prev && known_up2 < n_up2, w3 = has_prev && known_prev < n_prev;
+                if (w1 || w2 || w3) {
+#ifdef SFA_CHAIN_TIMING
+                    SFA_CT_STAMP(t0); n_slow++;
+#endif
+                    if (w1) known_up = chain_wait(rF, vF0, so_up, n_up, a.err, dead);
+                    if (w2) known_up2 = chain_wait(rF, vF0, so_up2, n_up2, a.err, dead);
+                    if (w3) known_prev = chain_wait(rF, vF0, so_prev, n_prev, a.err, dead);
+#ifdef SFA_CHAIN_TIMING
+                    SFA_CT_STAMP(t1); t_slow += t1 - t0;
+#endif
+                }
+            }
+#ifndef SFA_X_IN_NOLOADS   // (timing experiment: no loads at all)
+            pend_up[q] = bload4_sc1(rF, vF_up, so_up);
+            pend_up2[q] = bload4_sc1(rF, vF_up2, so_up2);
+            pend_prev[q] = bload4_sc1(rF, vF_prev, so_prev);
+            // ---- fetch for the chunk the compute waves run in interval I + AH + 1 ---------------------------------------------------------
+#pragma unroll
+            for (int n = 0; n < NLT; n++) tvr[q][n] = bload8_sc1(rE, tv_voff[n], so_tv);
+            tvxr[q] = bload8_sc1(rXin, tvx_voff, so_xin);
+#pragma unroll
+            for (int j = 0; j < CH; j++) xr[q][j] = bload8_sc1(rXin, vXin, so_xin + (unsigned)j * st8);
+#endif
+            so_tv += CH * 8u; so_xin += CH * st8;
+        }
+    }
+#ifdef SFA_CHAIN_TIMING
+    if (job == 0 && lane == 0 && (int)blockIdx.x < 64) {
+        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+        o[0] = t_begin; o[1] = __builtin_readcyclecounter(); o[2] = t_bar; o[6] = t_slow; o[8] = n_slow;
+        o[9] = (unsigned long long)b; o[10] = (unsigned long long)g; o[11] = (unsigned long long)a.NI; o[12] = 0x10ull;
+        o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
+}
+
+// ---- OUT wave: lane 63's iterates and the group's last iterate leave (sc1 write-through); the workgroup's progress word follows PUBD
+// intervals later behind a counted wait.  Nothing but stores is ever in this wave's memory queue, so the count is exact and short.
+template <class S, int CH, int AH, int PUBD>
+__device__ __forceinline__ void chain_out(const ChainArgs &a, unsigned char *lds, int job, int b, int g, int c_first, int lane) {
+    using L = ChainLds<S, CH>;
+    constexpr int NW = S::NW, LEAD = AH + 1, Fl = S::Fw(NW - 1);
+    constexpr int NES = [] { int n = 0; for (int w = 0; w < NW; w++) n += S::Fw(w) * CH; return n; }();            // lane-63 values stored per interval
+    constexpr int NSE = (NES + 63) / 64;
+    constexpr int T = NSE + CH + 1;                                  // VMEM instructions of one interval
+    static_assert(PUBD * T <= 63, "vmcnt is a 6-bit counter");
+    const ChainGeo<S, CH> G(a, b, g, c_first);
+    const int RP = G.RP, K = G.K, W = G.W, H = G.H;
+    const RsrcWords rE = rsrc_words(a.edge, a.edge_bytes);
+    const RsrcWords rF = rsrc_words(a.gflags, a.flag_bytes);
+    // x plane as the last stage writes it: base = entry of (first step, sweep Fl-1, lane 0)
+    const RsrcWords rXout = rsrc_words(a.x + (size_t)job * a.ent + G.U0l + (long)G.s_startl * RP - (long)(Fl - 1) * G.FOFF, 0xffffff00ull);
+    // lane 63's iterates, stored at interval I for the chunk c_first + I - 1 - LEAD - w of stage w
     unsigned es_voff[NSE], es_lds[NSE][2];
     int es_lo[NSE];
 #pragma unroll
@@ -287,7 +481,7 @@ __device__ __forceinline__ void chain_io(const ChainArgs &a, unsigned char *lds,
         while (w < NW - 1 && i >= base + S::Fw(w) * CH) { base += S::Fw(w) * CH; w++; }
         const int Fw = S::Fw(w), rel = i - base, f = rel / CH, j = rel % CH;
         const bool on = i < NES;
-        const int k0w = k0g + S::kw(w), Ow = k0w - (st0 + w) + 1;
+        const int k0w = G.k0g + S::kw(w), Ow = k0w - (G.st0 + w) + 1;
         const int s0 = (c_first - 1 - LEAD - w) * CH - Ow;                         // chunk stored at interval 0 (not a real one)
         const long off = (long)job * a.edge_job + ((long)b * K + k0w + f) * a.Wp + a.EP + (s0 + j - 63 - f);
         es_voff[n] = on ? (unsigned)(off * 8) : kOobOffset;
@@ -300,112 +494,92 @@ __device__ __forceinline__ void chain_io(const ChainArgs &a, unsigned char *lds,
                                       : (unsigned)(L::ring0 + (w + 1) * L::RING + ((cp * CH + j) * 64 + 63) * 8);
         }
     }
-    // (3) rows of the x plane
-    const unsigned vXin = (unsigned)(RP + lane + 1) * 8u;                          // (c, r + 1) of sweep 0: one diagonal further, one row down
-    const int rl = r0l + lane - (Fl - 1);
+    const int rl = G.r0l + lane - (Fl - 1);
+#ifdef SFA_X_NOXSTORE     // timing experiment only
+    const unsigned vXout = kOobOffset; (void)rl;
+#else
     const unsigned vXout = (rl >= 0 && rl < H) ? (unsigned)lane * 8u : kOobOffset;
+#endif
     const int lanef = lane + (Fl - 1);
     const unsigned st8 = (unsigned)RP * 8u;
-
-    // ---- progress words ---------------------------------------------------------------------------------------------------------
     const unsigned vF0 = lane == 0 ? 0u : kOobOffset;
-    const unsigned so_mine = (unsigned)((((size_t)job * a.NB + b) * a.NG + g) * 4);
-    const unsigned so_up = so_mine - (unsigned)a.NG * 4u, so_up2 = so_up - 4u, so_prev = so_mine - 4u;
-    const unsigned vF_up = has_up ? vF0 : kOobOffset, vF_up2 = (has_up && has_prev) ? vF0 : kOobOffset, vF_prev = has_prev ? vF0 : kOobOffset;
-    // what the loads issued at interval I need (published-interval counts of the producers; see the header)
-    const int D63 = 63 / CH;
-    const int need_up0 = LEAD + 3 + D63;                                            // + I
-    const int dcf = c_first - c_first_prev;
-    const int need_up20 = 1 + D63 + dcf + LEAD + NW - 1 + 2;                        // + I   ((b-1, g-1): its last stage, chunk c_first + I + 1 + D63)
-    const int need_prev0 = dcf + LEAD + NW - 1 + 2;                                 // + I   ((b, g-1): its last stage, chunk c_first + I)
-    const unsigned cap = (unsigned)(a.nch + LEAD + NW);                              // at this count a producer has published every real chunk
-    // the progress words are polled asynchronously: a poll issued in interval I is looked at in interval I + PL, so that the I/O wave never
-    // sits on a load that is younger than PL intervals (its stores are published behind a counted wait of the same reach)
-    constexpr int PL = 2;
-    unsigned known_up = 0, known_up2 = 0, known_prev = 0, pend_up[AH], pend_up2[AH], pend_prev[AH];
-#pragma unroll
-    for (int q = 0; q < AH; q++) { pend_up[q] = 0; pend_up2[q] = 0; pend_prev[q] = 0; }
-    bool dead = false;
-
-    unsigned long long tvr[AH][NLT], tvxr[AH], xr[AH][CH];
-#pragma unroll
-    for (int q = 0; q < AH; q++) {
-        tvxr[q] = 0;
-#pragma unroll
-        for (int n = 0; n < NLT; n++) tvr[q][n] = 0;
-#pragma unroll
-        for (int j = 0; j < CH; j++) xr[q][j] = 0;
-    }
-    unsigned so_tv = 0, so_xin = 0, so_es = 0, so_xout = 0;          // advance by one chunk per interval
-    int s_out = s_startl - (1 + LEAD + NW - 1) * CH;                 // local step (last stage) of row 0 of the chunk stored at interval I
+    const unsigned so_mine = (unsigned)((((size_t)job * a.NB + b) * a.NG + g) * 4 * kFlagStride);
+    unsigned so_es = 0, so_xout = 0;
+    int s_out = G.s_startl - (LEAD + NW) * CH;                       // local step (last stage) of row 0 of the chunk stored at interval I
     unsigned char *const ldsb = lds;
-    constexpr int NVM = 1 + 3 + NLT + 1 + CH + NSE + CH;            // VMEM instructions of one interval = issued between the stores of interval I-1 and the wait
-    static_assert(NVM <= 63, "vmcnt is a 6-bit counter");
-
-    for (int I0 = 0; I0 < a.NI; I0 += AH) {
+#ifdef SFA_CHAIN_TIMING
+    unsigned long long t_begin = __builtin_readcyclecounter(), t_bar = 0, t_pub = 0, t0, t1;
+#endif
+    for (int I0 = 0; I0 < a.NI; I0 += 2) {
 #pragma unroll
-        for (int q = 0; q < AH; q++) {
+        for (int q = 0; q < 2; q++) {
             const int I = I0 + q;
             const int p = q & 1;
-            SFA_CHAIN_BARRIER();
-            // ---- (a) what was fetched AH intervals ago goes to LDS: the compute waves use it in the NEXT interval ----------------
-#pragma unroll
-            for (int n = 0; n < NLT; n++) *reinterpret_cast<unsigned long long *>(ldsb + tv_lds[n][p]) = tvx_lane[n] ? tvxr[q] : tvr[q][n];   // (selected here, not when loaded: no wait on a fresh load)
-#pragma unroll
-            for (int j = 0; j < CH; j++) reinterpret_cast<unsigned long long *>(ldsb + L::ring0 + ((p * CH + j) * 64) * 8)[lane] = xr[q][j];
-            // ---- (b) what the compute waves produced in the PREVIOUS interval leaves (write-through) --------------------------------
+            SFA_CHAIN_BARRIER_T(t_bar);
+            // ---- what the compute waves produced in the PREVIOUS interval leaves ------------------------------------------------------------
 #pragma unroll
             for (int n = 0; n < NSE; n++) {
+#ifdef SFA_X_OUT_NOLDS    // timing experiment only
+                const unsigned long long v = (unsigned long long)I + es_lds[n][p];
+#else
                 const unsigned long long v = *reinterpret_cast<const unsigned long long *>(ldsb + es_lds[n][p]);
+#endif
                 const bool act = I >= es_lo[n] && I < es_lo[n] + a.nch;
-                bstore8_sc1(rE, act ? es_voff[n] : kOobOffset, so_es, v);
+                batomic_swap8(rE, act ? es_voff[n] : kOobOffset, so_es, v);
             }
             {
                 const bool act = I >= LEAD + NW && I < LEAD + NW + a.nch;         // uniform
+                // every lane's column inside the image (uniform): the steady state needs no per-row column test
+                const bool mid = s_out - 63 - (Fl - 1) >= 0 && s_out + CH - 1 < W;
                 const int po = (p + NW - 1) & 1;
+#ifdef SFA_X_OUT_NOLDS    // timing experiment only: some global array instead (never dereferenced with the atomics off... here: the dummy region)
+                const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(ldsb + L::dummy0) + (lane & 1) + po * 0;
+#else
                 const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(ldsb + L::ring0 + NW * L::RING + (po * CH * 64) * 8) + lane;
+#endif
+                if (mid) {
+                    const unsigned vo = act ? vXout : kOobOffset;
 #pragma unroll
-                for (int j = 0; j < CH; j++) {
-                    const unsigned long long v = rp[j * 64];
-                    const bool ok = act && (unsigned)(s_out + j - lanef) < (unsigned)W;
-                    bstore8_sc1(rXout, ok ? vXout : kOobOffset, so_xout + (unsigned)j * st8, v);
+                    for (int j = 0; j < CH; j++) batomic_swap8(rXout, vo, so_xout + (unsigned)j * st8, rp[j * 64]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CH; j++) {
+                        const bool ok = act && (unsigned)(s_out + j - lanef) < (unsigned)W;
+                        batomic_swap8(rXout, ok ? vXout : kOobOffset, so_xout + (unsigned)j * st8, rp[j * 64]);
+                    }
                 }
             }
-            // ---- (c) publish: the stores of interval I-1 are older than the NVM instructions issued since -----------------------------
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM - 1) : "memory");
-            bstore4_sc1(rF, vF0, so_mine, (unsigned)I);
-            // ---- (d) the workgroups this one depends on ---------------------------------------------------------------------------------
-            known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up[(q + AH - PL) % AH]));
-            known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2[(q + AH - PL) % AH]));
-            known_prev = max(known_prev, (unsigned)__builtin_amdgcn_readfirstlane(pend_prev[(q + AH - PL) % AH]));
-            if (!dead) {
-                const unsigned n_up = min((unsigned)(need_up0 + I), cap), n_up2 = min((unsigned)(need_up20 + I), cap), n_prev = min((unsigned)(need_prev0 + I), cap);
-                if (has_up && known_up < n_up) known_up = chain_wait(rF, vF0, so_up, n_up, a.err, dead);
-                if (has_up && has_prev && known_up2 < n_up2) known_up2 = chain_wait(rF, vF0, so_up2, n_up2, a.err, dead);
-                if (has_prev && known_prev < n_prev) known_prev = chain_wait(rF, vF0, so_prev, n_prev, a.err, dead);
-            }
-            pend_up[q] = bload4_sc1(rF, vF_up, so_up);
-            pend_up2[q] = bload4_sc1(rF, vF_up2, so_up2);
-            pend_prev[q] = bload4_sc1(rF, vF_prev, so_prev);
-            // ---- (e) fetch for the chunk the compute waves run in interval I + AH + 1 -----------------------------------------------------
-#pragma unroll
-            for (int n = 0; n < NLT; n++) tvr[q][n] = bload8_sc1(rE, tv_voff[n], so_tv);
-            tvxr[q] = bload8_sc1(rXin, tvx_voff, so_xin);
-#pragma unroll
-            for (int j = 0; j < CH; j++) xr[q][j] = bload8_sc1(rXin, vXin, so_xin + (unsigned)j * st8);
-            so_tv += CH * 8u; so_es += CH * 8u; so_xin += CH * st8; s_out += CH;
+            // ---- publish: the stores of interval I - PUBD are older than the PUBD * T instructions issued since ------------------------------
+#ifdef SFA_CHAIN_TIMING
+            SFA_CT_STAMP(t0);
+#endif
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PUBD * T - 1) : "memory");
+#ifdef SFA_CHAIN_TIMING
+            SFA_CT_STAMP(t1); t_pub += t1 - t0;
+#endif
+            batomic_umax4(rF, vF0, so_mine, (unsigned)max(I - PUBD + 1, 0));
+            so_es += CH * 8u; s_out += CH;
             if (I >= LEAD + NW) so_xout += CH * st8;
         }
     }
+#ifdef SFA_CHAIN_TIMING
+    if (job == 0 && lane == 0 && (int)blockIdx.x < 64) {
+        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+        o[0] = t_begin; o[1] = __builtin_readcyclecounter(); o[2] = t_bar; o[4] = t_pub;
+        o[9] = (unsigned long long)b; o[10] = (unsigned long long)g; o[11] = (unsigned long long)a.NI; o[12] = 0x20ull;
+        o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bstore4_sc1(rF, vF0, so_mine, 0x7fffffffu);
+    batomic_umax4(rF, vF0, so_mine, 0x7fffffffu);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int FA, int NA, int FB, int NB_, int CH, int PD, int AH>
-__global__ void __launch_bounds__((NA + NB_ + 1) * 64) k_sor_chain(ChainArgs a) {
+// waves of a workgroup: 0 = IN, 1 .. NW = the stages, NW + 1 = OUT (with NW = 3 the two I/O waves share SIMD 0, the stages have a SIMD each)
+template <int FA, int NA, int FB, int NB_, int CH, int PD, int AH, int PL, int PUBD>
+__global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) {
     using S = ChainShape<FA, NA, FB, NB_>;
     using L = ChainLds<S, CH>;
     constexpr int NW = S::NW, LEAD = AH + 1;
@@ -413,9 +587,9 @@ __global__ void __launch_bounds__((NA + NB_ + 1) * 64) k_sor_chain(ChainArgs a) 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned *s_ticket = reinterpret_cast<unsigned *>(smem + L::ticket);
-    if (threadIdx.x == 0) *s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * a.NG, 1u);
+    if (threadIdx.x == 0) *s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * a.NG * kFlagStride, 1u);
     // the rings and staging areas are read before they are first written (start-up intervals): zeros, not garbage
-    for (int i = threadIdx.x; i < L::ticket / 8; i += (NW + 1) * 64) reinterpret_cast<unsigned long long *>(smem)[i] = 0ull;
+    for (int i = threadIdx.x; i < L::ticket / 8; i += (NW + 2) * 64) reinterpret_cast<unsigned long long *>(smem)[i] = 0ull;
     __syncthreads();
     const unsigned t = __builtin_amdgcn_readfirstlane(*s_ticket);
     if (t >= (unsigned)(a.nb * a.NB * a.NG)) return;
@@ -425,19 +599,113 @@ __global__ void __launch_bounds__((NA + NB_ + 1) * 64) k_sor_chain(ChainArgs a) 
     // first chunk of the group (even): every stage of the group starts at a local step <= -1
     const int c_first = ((g * (S::KG - NW)) / CH) & ~1;
     const int c_first_prev = g > 0 ? (((g - 1) * (S::KG - NW)) / CH) & ~1 : 0;
-    if (wave == NW) { chain_io<S, CH, AH>(a, smem, job, b, g, c_first, c_first_prev, lane); return; }
-    const int st = g * NW + wave, k0 = g * S::KG + S::kw(wave), O = k0 - st + 1;
+#ifdef SFA_X_NOIO         // timing experiment only: the I/O waves just walk through the barriers (nothing crosses workgroups: wrong results, compute speed)
+#ifdef SFA_X_NOIO_POLL    // ... except that wave 0 issues ONE real bypassing load (or store) per interval: does a slow access of another wave delay this CU's operand stream?
+    if (wave == 0) {
+        const __amdgpu_buffer_rsrc_t rF = plane_rsrc(a.gflags, a.flag_bytes);
+        const unsigned so = (unsigned)((((size_t)job * a.NB + b) * a.NG + g) * 4);
+        unsigned acc = 0, pend[4] = {0, 0, 0, 0};
+        for (int I = 0; I < a.NI; I += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                SFA_CHAIN_BARRIER();
+                acc += pend[(q + 1) % 4];                    // a load issued three intervals ago
+#if SFA_X_NOIO_POLL == 1
+                pend[q] = bload4_sc1(rF, lane == 0 ? 0u : kOobOffset, so);
+#elif SFA_X_NOIO_POLL == 2
+                pend[q] = __builtin_amdgcn_raw_buffer_load_b32(rF, lane == 0 ? 0u : kOobOffset, so, 0);      // plain (L1/L2 hit)
+#elif SFA_X_NOIO_POLL == 3
+                bstore4_sc1(rF, lane == 0 ? 0u : kOobOffset, so, (unsigned)I);
+#elif SFA_X_NOIO_POLL == 4
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)I, rF, lane == 0 ? 0u : kOobOffset, so, 0);       // plain
+#elif SFA_X_NOIO_POLL == 5
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)I, rF, lane == 0 ? 0u : kOobOffset, so, 2);       // nt
+#elif SFA_X_NOIO_POLL == 6
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)I, rF, lane == 0 ? 0u : kOobOffset, so, 17);      // sc0 sc1
+#elif SFA_X_NOIO_POLL == 7
+                if (lane == 0) __hip_atomic_fetch_add(a.gflags + so / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no-return atomic
+#elif SFA_X_NOIO_POLL == 8
+                { const __amdgpu_buffer_rsrc_t rX8 = plane_rsrc(a.x + (size_t)job * a.ent, 0xffffff00ull); bstore8_sc1(rX8, lane * 8u, (unsigned)(I & 7) * 512u, 0ull); }   // a whole row, write-through
+#elif SFA_X_NOIO_POLL == 10
+                {   // four rows as no-return 8-byte atomic swaps + one atomic add
+                    unsigned long long *xp = a.x + (size_t)job * a.ent + (size_t)blockIdx.x * 4096 + lane;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) __hip_atomic_exchange(xp + j * 64, (unsigned long long)I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_fetch_add(a.gflags + so / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#elif SFA_X_NOIO_POLL == 11 || SFA_X_NOIO_POLL == 12
+                {   // four plain rows, then an agent-scope release (L2 write-back) every interval (11) / every fourth (12), then the flag
+                    const __amdgpu_buffer_rsrc_t rX8 = plane_rsrc(a.x + (size_t)job * a.ent + (size_t)blockIdx.x * 4096, 0xffffff00ull); v2u z = {(unsigned)I, 0u};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) __builtin_amdgcn_raw_buffer_store_b64(z, rX8, lane * 8u, (unsigned)(j * 512), 0);
+                    if (SFA_X_NOIO_POLL == 11 || q == 3) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_fetch_add(a.gflags + so / 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#elif SFA_X_NOIO_POLL == 13
+                {   // two 1-KB write-through stores
+                    const __amdgpu_buffer_rsrc_t rX8 = plane_rsrc(a.x + (size_t)job * a.ent + (size_t)blockIdx.x * 4096, 0xffffff00ull); v4u z = {(unsigned)I, 0u, 0u, 0u};
+                    __builtin_amdgcn_raw_buffer_store_b128(z, rX8, lane * 16u, 0, 16); __builtin_amdgcn_raw_buffer_store_b128(z, rX8, lane * 16u, 1024, 16);
+                }
+#elif SFA_X_NOIO_POLL == 14
+                {   // four rows as RETURNING swaps (result consumed three intervals later) + one atomic add
+                    unsigned long long *xp = a.x + (size_t)job * a.ent + (size_t)blockIdx.x * 4096 + lane;
+                    unsigned long long r = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) r ^= __hip_atomic_exchange(xp + j * 64, (unsigned long long)I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pend[q] = (unsigned)r;
+                }
+#elif SFA_X_NOIO_POLL == 15
+                {   // four rows of 8-byte bypassing LOADS
+                    const __amdgpu_buffer_rsrc_t rX8 = plane_rsrc(a.x + (size_t)job * a.ent + (size_t)blockIdx.x * 4096, 0xffffff00ull);
+                    unsigned long long r = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) r ^= bload8_sc1(rX8, lane * 8u, (unsigned)(j * 512 + (I & 15) * 2048));
+                    pend[q] = (unsigned)r;
+                }
+#elif SFA_X_NOIO_POLL == 16
+                {   // four rows as 8-byte atomic swaps + the edge values (12 lanes) as swaps + an atomic max as flag: the OUT wave's traffic
+                    unsigned long long *xp = a.x + (size_t)job * a.ent + (size_t)blockIdx.x * 4096 + lane;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) __hip_atomic_exchange(xp + j * 64, (unsigned long long)I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane < 12) __hip_atomic_exchange(a.edge + (size_t)blockIdx.x * 64 + lane, (unsigned long long)I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_max(a.gflags + so / 4, (unsigned)I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#elif SFA_X_NOIO_POLL == 9
+                { const __amdgpu_buffer_rsrc_t rX8 = plane_rsrc(a.x + (size_t)job * a.ent, 0xffffff00ull); v2u z = {0u, 0u}; __builtin_amdgcn_raw_buffer_store_b64(z, rX8, lane * 8u, (unsigned)(I & 7) * 512u, 0); }   // a whole row, plain
+#endif
+            }
+        }
+        if (acc == 0x12345678u) bstore4_sc1(rF, 0u, so, acc);
+        return;
+    }
+#endif
+    if (wave == 0 || wave == NW + 1) { for (int I = 0; I < a.NI; I++) SFA_CHAIN_BARRIER(); return; }
+#endif
+#ifdef SFA_X_IN_IDLE
+    if (wave == 0) { for (int I = 0; I < a.NI; I++) SFA_CHAIN_BARRIER(); return; }
+#endif
+#ifdef SFA_X_OUT_IDLE
+    if (wave == NW + 1) { for (int I = 0; I < a.NI; I++) SFA_CHAIN_BARRIER(); return; }
+#endif
+    if (wave == 0) { chain_in<S, CH, AH, PL>(a, smem, job, b, g, c_first, c_first_prev, lane); return; }
+    if (wave == NW + 1) { chain_out<S, CH, AH, PUBD>(a, smem, job, b, g, c_first, lane); return; }
+    const int w = wave - 1;
+    const int st = g * NW + w, k0 = g * S::KG + S::kw(w), O = k0 - st + 1;
     const int s_start = c_first * CH - O;
-    const int ring_in = L::ring0 + wave * L::RING, ring_out = ring_in + L::RING;
-    const int tvb = L::tv0 + wave * L::TVW, esb = L::es0 + wave * L::ESW;
-    if (wave < NA) chain_compute<FA, CH, PD>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + wave, lane);
-    else           chain_compute<FB, CH, PD>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + wave, lane);
+    const int ring_in = L::ring0 + w * L::RING, ring_out = ring_in + L::RING;
+    const int tvb = L::tv0 + w * L::TVW, esb = L::es0 + w * L::ESW;
+    if (w < NA) chain_compute<FA, CH, PD>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
+    else        chain_compute<FB, CH, PD>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int kChainCH = 4, kChainAH = 4;
+constexpr int kChainCH = 4, kChainAH = 4, kChainPL = 3, kChainPUBD = 3;
 
 struct ChainShapeInfo { int id, FA, NA, FB, NB_, PD; };
 static const ChainShapeInfo kChainShapes[] = {
@@ -460,13 +728,21 @@ bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
     return false;
 }
 int chain_ch() { return kChainCH; }
+int chain_flag_stride() { return kFlagStride; }
 int chain_ah() { return kChainAH; }
 
 template <int FA, int NA, int FB, int NB_, int PD>
 static void chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
     using S = ChainShape<FA, NA, FB, NB_>;
     using L = ChainLds<S, kChainCH>;
-    hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH>), dim3(nwg), dim3((S::NW + 1) * 64), L::total, c->stream, a);
+    size_t lds = L::total;
+    if (const char *e = getenv("SFA_CHAIN_LDS")) lds = std::max(lds, (size_t)atoi(e));      // experiment: a larger request limits the workgroups per CU
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>), dim3(nwg), dim3((S::NW + 2) * 64), lds, c->stream, a);
 }
 
 int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float omega) {
@@ -491,3 +767,7 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
 }
 
 }  // namespace sfa
+
+#ifdef SFA_CHAIN_TIMING
+extern "C" int sfa_debug_chain_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sfa::g_chain_timing), sizeof(unsigned long long) * 64 * 8 * 16); }
+#endif

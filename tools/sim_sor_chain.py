@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 f32 = np.float32
-CH, AH = 4, 4
+CH, AH, PUBD = 4, 4, 3
 LEAD = AH + 1
 OOB = None
 # visibility model: "raw" = stores land as late, loads sample as early as the protocol allows (read-after-write hazards);
@@ -263,14 +263,15 @@ class WG:
             ent = self.Xout_base + self.so_xout + j * RP + lane
             for l in np.nonzero(ok)[0]:
                 new.append(("x", ent[l], v[l]))
-        # (c) publish: S(I-1) is complete
+        # (c) publish (OUT wave): the stores of interval I - PUBD are complete
         if MODE == "war":
             for kind, addr, v in new: (ws.edge if kind == "edge" else ws.x[self.job])[addr] = v
             new = []
-        for kind, addr, v in self.pending_stores:
-            (ws.edge if kind == "edge" else ws.x[self.job])[addr] = v
-        self.pending_stores = new
-        ws.flags[self.flag_idx] = I
+        self.pending_stores.append(new)
+        if len(self.pending_stores) > PUBD:
+            for kind, addr, v in self.pending_stores.pop(0):
+                (ws.edge if kind == "edge" else ws.x[self.job])[addr] = v
+        ws.flags[self.flag_idx] = max(I - PUBD + 1, 0)
 
     def io_interval_back(self):
         """(e): the loads of interval I, issued once the waits are satisfied"""
@@ -313,8 +314,9 @@ class WG:
         self._front_done = False
         self.I += 1
         if self.I == ws.NS:
-            for kind, addr, v in self.pending_stores:
-                (ws.edge if kind == "edge" else ws.x[self.job])[addr] = v
+            for st in self.pending_stores:
+                for kind, addr, v in st:
+                    (ws.edge if kind == "edge" else ws.x[self.job])[addr] = v
             ws.flags[self.flag_idx] = 0x7fffffff
             self.done = True
         return True
