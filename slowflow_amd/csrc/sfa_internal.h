@@ -195,6 +195,7 @@ struct SorWorkspace {
     sfa_ctx *ctx = nullptr;
     int w = 0, h = 0, K = 0, nb = 0;
     int NB = 0, NG = 0, RP = 0, ND = 0, G = 0, NS = 0, NCH = 0, ntasks = 0, F = 0, CHK = 0;
+    int nwords = 0;               // progress words per window (one per task, each on a 128-byte line of its own)
     long ent = 0;                 // entries per element (ND*RP)
     int band = 0, Wp = 0, EP = 0;   // band kernel: fused sweeps per wave (0 = task kernel), edge row pitch / left pad
     int chain = 0;                  // sor_chain.hip shape id (0 = the band / task kernels); then NG = groups per band, NCH = chunks per stage, NS = barrier intervals

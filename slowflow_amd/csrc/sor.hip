@@ -39,6 +39,11 @@ namespace sfa {
 #define SFA_PUBLISH_VMCNT (2 * CH - 1)
 #endif
 
+#ifndef SFA_PROGRESS_STRIDE
+#define SFA_PROGRESS_STRIDE 32
+#endif
+constexpr int kProgressStride = SFA_PROGRESS_STRIDE;      // words between two progress words of the task / band kernels
+
 struct SorArgs {
     const float4 *sa;               // (inv11, inv12, inv22, vt)
     const float4 *sb;               // (b1, b2, hp, vp)
@@ -48,6 +53,7 @@ struct SorArgs {
     unsigned *err;
     long ent;                       // entries per batch element
     int W, H, K, NB, NG, RP, G, NS, NCH, ntasks, nb;
+    int nwords;                     // progress words per window (padded)
     float omega;
 };
 
@@ -158,17 +164,19 @@ template <int F, int CH>
 __global__ void __launch_bounds__(64) k_sor_solve(SorArgs a) {
     const int lane = threadIdx.x;
     unsigned t = 0;
-    if (lane == 0) t = atomicAdd(a.flags + (size_t)a.nb * a.ntasks, 1u);
+    if (lane == 0) t = atomicAdd(a.flags + (size_t)a.nb * a.nwords, 1u);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= (unsigned)(a.nb * a.ntasks)) return;
     const int job = t % a.nb, idx = t / a.nb;
     const int2 bg = a.order[idx];
     const int b = __builtin_amdgcn_readfirstlane(bg.x), g = __builtin_amdgcn_readfirstlane(bg.y);
     const int k0 = g * F;
-    unsigned *jflags = a.flags + (size_t)job * a.ntasks;
-    unsigned *myflag = jflags + g * a.NB + b;
-    const unsigned *f_prev = jflags + (g - 1) * a.NB + b;     // (b, g-1), valid if g > 0
-    const unsigned *f_up = jflags + g * a.NB + (b - 1);       // (b-1, g), valid if b > 0
+    // one progress word per 128-byte line (kProgressStride words apart): packed, the words of a solve share a few lines and every publication
+    // queues behind the others (sor_chain.hip measured that)
+    unsigned *jflags = a.flags + (size_t)job * a.nwords;
+    unsigned *myflag = jflags + (size_t)(g * a.NB + b) * kProgressStride;
+    const unsigned *f_prev = jflags + (size_t)((g - 1) * a.NB + b) * kProgressStride;     // (b, g-1), valid if g > 0
+    const unsigned *f_up = jflags + (size_t)(g * a.NB + (b - 1)) * kProgressStride;       // (b-1, g), valid if b > 0
     const int NCH = a.NCH, RP = a.RP;
     const int r0 = 64 * b - k0;
     const long FOFF = 2L * RP + 1;
@@ -342,9 +350,9 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     const unsigned so8_last = __builtin_amdgcn_readfirstlane((unsigned)((U0 - (long)(F - 1) * FOFF) * 8));
     unsigned long long *e_mine = a.edge + (size_t)job * a.edge_job + ((size_t)b * a.K + k0) * a.Wp + a.EP;
     const unsigned long long *e_up = a.edge + (size_t)job * a.edge_job + ((size_t)(b - 1) * a.K + k0) * a.Wp + a.EP;
-    unsigned *gmine = a.gflags + ((size_t)job * a.NB + b) * a.NW + wave;
-    const unsigned *g_up = a.gflags + ((size_t)job * a.NB + (b - 1)) * a.NW + wave;      // (b-1, w)
-    const unsigned *g_up2 = g_up - 1;                                                    // (b-1, w-1)
+    unsigned *gmine = a.gflags + (((size_t)job * a.NB + b) * a.NW + wave) * kProgressStride;
+    const unsigned *g_up = a.gflags + (((size_t)job * a.NB + (b - 1)) * a.NW + wave) * kProgressStride;      // (b-1, w)
+    const unsigned *g_up2 = g_up - kProgressStride;                                                           // (b-1, w-1)
 #ifdef SFA_X_NOBAND       // timing experiment only: bands do not wait for each other
     const bool has_up = false, publishes = false;
 #else
@@ -589,7 +597,7 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     unsigned &s_ticket = lprog[NW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * NW, 1u);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * NW * kProgressStride, 1u);
     if (threadIdx.x < NW) lprog[threadIdx.x] = 0;
     __syncthreads();
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
@@ -618,7 +626,7 @@ __global__ void __launch_bounds__((NA + NB_) * 64) k_sor_band_mixed(BandArgs a) 
     unsigned &s_ticket = lprog[NW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * NW, 1u);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * NW * kProgressStride, 1u);
     if (threadIdx.x < NW) lprog[threadIdx.x] = 0;
     __syncthreads();
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
@@ -816,9 +824,10 @@ static int chain_choice(int K, int nb, int NBands) {
     if (const char *e = getenv("SFA_SOR_CHAIN")) id = atoi(e);
     else if (getenv("SFA_SOR_BAND") || getenv("SFA_SOR_F")) id = 0;          // an explicit choice of the other kernels
     else {
-        // default: by the number of workgroups the launch can spread over the 256 CUs
+        // default: by the number of bands in the launch (measured at 1024x436, K = 30, 8 bands per window; us per launch, chain shape 1 / 2 / band kernel):
+        // 1 window 268 / 379 / 581 (task kernel), 4: 376 / 394 / 1025, 8: 611 / 605 / 1250, 16: 1076 / 946 / 1310, 32: 2150 / 1590 / 1372
         const int bands = nb * NBands;
-        id = bands <= 24 ? 1 : bands <= 64 ? 2 : bands <= 128 ? 3 : 0;
+        id = bands <= 48 ? 1 : bands <= 160 ? 2 : 0;
     }
     int KG, NW, FMAX;
     if (id > 0 && !chain_shape(id, K, &KG, &NW, &FMAX)) id = 0;
@@ -902,7 +911,8 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
         NCH = round_up((w + 64 + KG - NW + 2 * CH + FMAX + CH - 1) / CH, 4);
         NS = round_up(NCH + LEAD + NW + 2, AH);
         ND = NS * CH + 64 * NB + G + 32;                      // diagonals: the I/O wave reads the x plane up to interval NS, the bands sit 64 rows apart
-        ntasks = NB * NG * chain_flag_stride();               // progress words per window (one 128-byte line per workgroup); the ticket follows the last window's
+        ntasks = NB * NG;                                     // workgroups per window
+        nwords = ntasks * chain_flag_stride();                // progress words per window (one 128-byte line per workgroup); the ticket follows the last window's
         ent = (long)ND * RP;
         EP = 256;
         Wp = round_up(EP + NS * CH + 64 + 2 * K + 64, 8);
@@ -912,7 +922,7 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
         SFA_TRY(sa.alloc(c, (size_t)nb * ent * sizeof(float4)));
         SFA_TRY(sb.alloc(c, (size_t)nb * ent * sizeof(float4)));
         SFA_TRY(x.alloc(c, (size_t)nb * ent * sizeof(unsigned long long)));
-        SFA_TRY(flags.alloc(c, ((size_t)nb * ntasks + 16) * sizeof(unsigned)));
+        SFA_TRY(flags.alloc(c, ((size_t)nb * nwords + 16) * sizeof(unsigned)));
         SFA_TRY(order.alloc(c, (size_t)NB * NG * sizeof(int2)));
         SFA_HIP(c, hipMemsetAsync(sa.p, 0, (size_t)nb * ent * sizeof(float4), c->stream));
         SFA_HIP(c, hipMemsetAsync(sb.p, 0, (size_t)nb * ent * sizeof(float4), c->stream));
@@ -936,6 +946,7 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     if (band) NS = NCH * CHK;                                   // the band kernel runs whole macro chunks
     ND = w + 64 * NB + 2 * CHK + F + 2 * G + 8;
     ntasks = NB * NG;                                           // band kernel: NG = NW waves per band workgroup
+    nwords = ntasks * kProgressStride;
     ent = (long)ND * RP;
     if (band) {
         EP = 72;                                                    // columns s-63-f >= -66 of the unconditional lane-63 stores
@@ -947,7 +958,7 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
     SFA_TRY(sa.alloc(c, (size_t)nb * ent * sizeof(float4)));
     SFA_TRY(sb.alloc(c, (size_t)nb * ent * sizeof(float4)));
     SFA_TRY(x.alloc(c, (size_t)nb * ent * sizeof(unsigned long long)));
-    SFA_TRY(flags.alloc(c, ((size_t)nb * ntasks + 16) * sizeof(unsigned)));
+    SFA_TRY(flags.alloc(c, ((size_t)nb * nwords + 16) * sizeof(unsigned)));
     SFA_TRY(order.alloc(c, (size_t)ntasks * sizeof(int2)));
     // guards (entries outside the image) must read as zero and are never written afterwards
     SFA_HIP(c, hipMemsetAsync(sa.p, 0, (size_t)nb * ent * sizeof(float4), c->stream));
@@ -970,7 +981,7 @@ int sor_operand_target(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, SorOpe
     if (g.w < 2 || g.h < 2 || K < 1) return set_error(c, SFA_ERR_ARG, "sor_operand_target: system too small for the pipelined solver");
     SFA_TRY(ws.configure(c, g.w, g.h, K, g.nb));
     out->sa = (float4 *)ws.sa.p; out->sb = (float4 *)ws.sb.p; out->x = (unsigned long long *)ws.x.p; out->flags = (unsigned *)ws.flags.p;
-    out->ent = ws.ent; out->RP = ws.RP; out->G = ws.G; out->ntasks = ws.ntasks; out->nb = g.nb;
+    out->ent = ws.ent; out->RP = ws.RP; out->G = ws.G; out->ntasks = ws.nwords; out->nb = g.nb;      // (the producer of the operands resets that many progress words per window)
     return SFA_OK;
 }
 
@@ -987,7 +998,7 @@ int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, fl
     p.sa = (float4 *)ws.sa.p; p.sb = (float4 *)ws.sb.p; p.x = (unsigned long long *)ws.x.p; p.flags = (unsigned *)ws.flags.p;
     p.du = du; p.dv = dv; p.b1 = b1; p.b2 = b2; p.sh = sh; p.sv = sv; p.a11 = a11; p.a12 = a12; p.a22 = a22;
     p.ent = ws.ent; p.es = g.es; p.W = g.w; p.H = g.h; p.RP = ws.RP; p.ND = ws.ND; p.G = ws.G; p.pitch = g.pitch;
-    p.ntasks = ws.ntasks; p.nb = g.nb; p.inv_out = inv_out ? 1 : 0;
+    p.ntasks = ws.nwords; p.nb = g.nb; p.inv_out = inv_out ? 1 : 0;
     hipLaunchKernelGGL(k_sor_prepare, dim3((g.w + PT_C - 1) / PT_C, (g.h + PT_R - 1) / PT_R, g.nb), dim3(256), 0, c->stream, p);
     return sor_launch_solve(c, ws, g, du, dv, K, omega);
 }
@@ -1002,7 +1013,7 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
     SorArgs a;
     a.sa = p.sa; a.sb = p.sb; a.x = p.x; a.flags = p.flags; a.order = (const int2 *)ws.order.p; a.err = c->d_err;
     a.ent = ws.ent; a.W = g.w; a.H = g.h; a.K = K; a.NB = ws.NB; a.NG = ws.NG; a.RP = ws.RP; a.G = ws.G; a.NS = ws.NS; a.NCH = ws.NCH;
-    a.ntasks = ws.ntasks; a.nb = g.nb; a.omega = omega;
+    a.ntasks = ws.ntasks; a.nwords = ws.nwords; a.nb = g.nb; a.omega = omega;
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
     if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
     if (ws.chain) {

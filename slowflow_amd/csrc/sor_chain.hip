@@ -333,6 +333,10 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
     using L = ChainLds<S, CH>;
     static_assert(AH % 2 == 0 && PL <= AH, "the LDS parities must be compile-time constants of the body position");
     constexpr int NW = S::NW, LEAD = AH + 1;
+#ifndef SFA_CHAIN_HYST
+#define SFA_CHAIN_HYST 2
+#endif
+    constexpr unsigned HYST = SFA_CHAIN_HYST;
     constexpr int NTV = [] { int n = 0; for (int w = 0; w < NW; w++) n += (S::Fw(w) + 1) * CH; return n; }();      // values fetched from the band above per interval
     constexpr int NLT = (NTV + 63) / 64;
     const ChainGeo<S, CH> G(a, b, g, c_first);
@@ -423,9 +427,11 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
 #ifdef SFA_CHAIN_TIMING
                     SFA_CT_STAMP(t0); n_slow++;
 #endif
-                    if (w1) known_up = chain_wait(rF, vF0, so_up, n_up, a.err, dead);
-                    if (w2) known_up2 = chain_wait(rF, vF0, so_up2, n_up2, a.err, dead);
-                    if (w3) known_prev = chain_wait(rF, vF0, so_prev, n_prev, a.err, dead);
+                    // a blocking wait means this workgroup has caught up with a producer: fall HYST intervals further back, so that the next
+                    // intervals are covered by the asynchronous polls again instead of paying a synchronous round trip each
+                    if (w1) known_up = chain_wait(rF, vF0, so_up, min(n_up + HYST, cap), a.err, dead);
+                    if (w2) known_up2 = chain_wait(rF, vF0, so_up2, min(n_up2 + HYST, cap), a.err, dead);
+                    if (w3) known_prev = chain_wait(rF, vF0, so_prev, min(n_prev + HYST, cap), a.err, dead);
 #ifdef SFA_CHAIN_TIMING
                     SFA_CT_STAMP(t1); t_slow += t1 - t0;
 #endif
@@ -705,7 +711,16 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int kChainCH = 4, kChainAH = 4, kChainPL = 3, kChainPUBD = 3;
+#ifndef SFA_CHAIN_AH
+#define SFA_CHAIN_AH 2
+#endif
+#ifndef SFA_CHAIN_PL
+#define SFA_CHAIN_PL 2
+#endif
+#ifndef SFA_CHAIN_PUBD
+#define SFA_CHAIN_PUBD 2
+#endif
+constexpr int kChainCH = 4, kChainAH = SFA_CHAIN_AH, kChainPL = SFA_CHAIN_PL, kChainPUBD = SFA_CHAIN_PUBD;
 
 struct ChainShapeInfo { int id, FA, NA, FB, NB_, PD; };
 static const ChainShapeInfo kChainShapes[] = {
@@ -750,7 +765,7 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
     a.sa = (const float4 *)ws.sa.p; a.sb = (const float4 *)ws.sb.p; a.x = (unsigned long long *)ws.x.p; a.edge = (unsigned long long *)ws.edge.p;
     a.gflags = (unsigned *)ws.flags.p; a.order = (const int2 *)ws.order.p; a.err = c->d_err;
     a.ent = ws.ent; a.edge_job = ws.edge_job; a.edge_bytes = (unsigned long long)g.nb * ws.edge_job * 8ull;
-    a.flag_bytes = ((unsigned long long)g.nb * ws.ntasks + 16) * 4ull;
+    a.flag_bytes = ((unsigned long long)g.nb * ws.nwords + 16) * 4ull;
     a.W = g.w; a.H = g.h; a.K = K; a.NB = ws.NB; a.NG = ws.NG; a.RP = ws.RP; a.G = ws.G; a.nb = g.nb; a.Wp = ws.Wp; a.EP = ws.EP;
     a.nch = ws.NCH; a.NI = ws.NS; a.omega = omega;
     const int nwg = g.nb * ws.NB * ws.NG;

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 f32 = np.float32
-CH, AH, PUBD = 4, 4, 3
+CH, AH, PUBD = 4, 2, 2
 LEAD = AH + 1
 OOB = None
 # visibility model: "raw" = stores land as late, loads sample as early as the protocol allows (read-after-write hazards);
