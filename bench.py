@@ -33,6 +33,21 @@ import slowflow_amd as sfa  # noqa: E402
 
 W, H, LAYERS, OUTER, INNER, SWEEPS, S = 1024, 436, 5, 5, 1, 30, 2
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+CLOCK_GHZ = 2.4              # peak engine clock the issue-rate and latency-floor figures are quoted at
+
+
+def assemble_valu_per_pixel_term():
+    """VALU instructions one pixel spends per data term in k_assemble_images, from the SQ counter pass of the newest profile round that has it
+    (profiles/<tag>_sq.json: SQ_INSTS_VALU of the kernel x 64 lanes / pixels / terms)"""
+    for tag in ("r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
+                v = json.load(f).get("assemble_valu_inst_per_pixel_term")
+            if v:
+                return float(v), "profiles/%s_sq.json" % tag
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def synth_window(seed, w=W, h=H, n=3):
@@ -145,6 +160,49 @@ def cpu_baseline(budget_s=12.0):
                                      "sample": f"{cores} worker processes, each solving {W}x{H} x {SWEEPS} sweeps back to back for 4 s"}
     except Exception as e:                                        # a reported extra, never a reason to lose the bench line
         out["sor_only_all_cores"] = {"error": str(e)[:200]}
+    # the WHOLE PATH on every core, one frame window per worker process at a time -- the node-level figure SURVEY.md 8(d)(ii) asks for
+    # ("OMP over jets with threads = physical cores", slow_flow.cpp:706): each worker refines distinct windows of the bench configuration
+    # with the oracle port for about 8 s
+    try:
+        import subprocess, sys as _sys
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(cores, 64))
+        code = ("import sys,time,os; sys.path.insert(0,%r); sys.path.insert(0,%r)\n"
+                "os.environ['OMP_NUM_THREADS']='1'\n"
+                "import numpy as np, oracle as orc, bench\n"
+                "o = orc.Oracle(); p = o.default_params()\n"
+                "p.S = bench.S; p.layers = bench.LAYERS; p.niter_alter = 1; p.niter_outer = bench.OUTER; p.niter_inner = bench.INNER; p.niter_solver = bench.SWEEPS\n"
+                "p.thres_outer = 0; p.thres_inner = 0; p.occlusion_reasoning = 0; p.hbit = 0; p.rho[0] = 1; p.omega[0] = 0\n"
+                "seed = int(sys.argv[1]); n = 0; t = 0.0\n"
+                "while t < 8.0 and n < 4:\n"
+                "    fr = []\n"
+                "    for f in bench.synth_window(7000 + 10 * seed + n):\n"
+                "        a = orc.aligned_zeros(f.shape); a[...] = f; fr.append(a)\n"
+                "    _, _, af, sf = o.normalize(fr, bench.W)\n"
+                "    for k in range(3): p.norm_avg[k] = af[k]; p.norm_std[k] = sf[k]\n"
+                "    wx, wy = orc.plane(bench.H, orc.stride_of(bench.W)), orc.plane(bench.H, orc.stride_of(bench.W))\n"
+                "    t0 = time.perf_counter(); o.variational(p, wx, wy, fr, bench.W); t += time.perf_counter() - t0; n += 1\n"
+                "print(n, t)\n") % (ROOT, os.path.join(ROOT, "tests"))
+        env = dict(os.environ); env["OMP_NUM_THREADS"] = "1"; env["HIP_VISIBLE_DEVICES"] = ""          # the workers never touch the GPU
+        t_wall = time.perf_counter()
+        procs = [subprocess.Popen([_sys.executable, "-c", code, str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(cores)]
+        nwin, rate = 0, 0.0
+        per_window = sum(w_ * h_ for w_, h_ in zip(ws, hs)) * OUTER * INNER * SWEEPS / 1e6
+        for pr in procs:
+            so, _ = pr.communicate(timeout=300)
+            kk, tt = so.split()
+            nwin += int(kk); rate += int(kk) * per_window / float(tt)
+        t_wall = time.perf_counter() - t_wall
+        model = ""
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            pass
+        out["all_cores"] = {"value": round(rate, 1), "unit": "Mpix*solver-iters/s", "cores": cores, "kind": "port", "cpu": model,
+                            "sample": f"{cores} worker processes, {nwin} frame windows of the bench configuration through the whole path in all "
+                                      f"({t_wall:.1f} s wall including start-up; rate = sum over workers of windows / their own refinement time)"}
+    except Exception as e:
+        out["all_cores"] = {"error": str(e)[:200]}
     return out
 
 
@@ -165,18 +223,21 @@ def hbm_triad_gbs(torch):
     return 3.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def measured_traffic(batch):
+def measured_traffic(batch, kernel=None):
     """HBM-side bytes per SOR launch from the PMC passes of profiles/collect.sh (FETCH_SIZE x2 on gfx950 for wide
     reads + WRITE_SIZE, separate passes; MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process,
     so the committed measurement of the same command is reported, and only when it was taken at this batch size.
     Returns (bytes per launch, source, valu_busy) -- valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (SIMDs x kernel cycles) of the SOR kernel
     when the SQ pass of the same round is there (profiles/<tag>_sq.json), else None."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", tag + "_traffic.json")
         try:
             with open(path) as f:
                 t = json.load(f)
             if int(t["batch"]) != int(batch):
+                continue
+            # a counter file taken from another kernel (shape) says nothing about this run: refuse it
+            if kernel is not None and t.get("kernel") and not (t["kernel"].split("<")[0] in kernel and t["kernel"].split("(")[0].strip() in kernel):
                 continue
             valu = None
             try:
@@ -242,6 +303,74 @@ def cfg_schedule_sample(ctx, B=16):
     return {"windows": B, "streams": 1, "seconds_per_window": round(sec / B, 5),
             "schedule": "sfa_params_default: %d alternations x %d outer x %d inner x %d sweeps, thresholds %g / %g, occlusion reasoning %d, %d levels" % (
                 p.niter_alter, p.niter_outer, p.niter_inner, p.niter_solver, p.thres_outer, p.thres_inner, p.occlusion_reasoning, p.layers)}
+
+
+def config4_strong(ctxs, dev, world, rank, dist, xdev, total_windows=128):
+    """BASELINE config 4 as north_star states it: a FIXED set of 128 frame windows (64 jets x 2 directions, slow_flow.cpp:706) under the cfg's
+    schedule (cfgs/slow_flow.cfg: S = 3, 5 levels, 10 alternations x 10 outer x 30 sweeps, occlusion reasoning, break thresholds 1e-5), partitioned
+    over the ranks (shard.partition: contiguous blocks, no data-path collective) -- STRONG scaling: 128 windows on one GPU, 16 per GPU on eight.
+    Wall time = max over ranks of one resident refinement of the rank's share (each rank's windows in len(ctxs) lockstep groups)."""
+    import threading
+    from slowflow_amd import shard
+    lo, hi = shard.partition(total_windows, world, rank)
+    nloc = hi - lo
+    S_ = len(ctxs)
+    p = sfa.default_params()
+    p.S = 3; p.layers = LAYERS; p.hbit = 0
+    p.rho[0] = 1; p.rho[1] = 1; p.omega[0] = 0; p.omega[1] = 2
+    base = [synth_window(300 + b, n=5) for b in range(4)]
+    avg, std = ctxs[0].normalize([f for w_ in base for f in w_], W)
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    groups = [(nloc * g // S_, nloc * (g + 1) // S_) for g in range(S_)]
+    jobs = [sfa.Job(c, p, W, H, max(1, b1 - b0)) if b1 > b0 else None for c, (b0, b1) in zip(ctxs, groups)]
+    for job, (b0, b1) in zip(jobs, groups):
+        for b in range(b1 - b0):
+            job.upload(b, base[(lo + b0 + b) % len(base)])
+
+    def run_all():
+        def work(g):
+            if jobs[g] is not None:
+                jobs[g].run(); ctxs[g].sync()
+        th = [threading.Thread(target=work, args=(g,)) for g in range(S_)]
+        for t in th: t.start()
+        for t in th: t.join()
+    run_all()                                         # warm-up (workspaces, first-touch)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run_all()
+    sec = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    sec_max = shard.max_over_ranks(dist, sec, device=xdev)
+    for job in jobs:
+        if job is not None:
+            job.close()
+    return {"windows_total": total_windows, "windows_this_rank": nloc, "groups_per_rank": S_, "n_gpus": world, "seconds": round(sec_max, 4),
+            "windows_per_second": round(total_windows / sec_max, 2), "scaling": "strong",
+            "schedule": "cfgs/slow_flow.cfg: S=3 (5 frames), %d levels, %d alternations x %d outer x %d inner x %d sweeps, thresholds %g / %g, occlusion reasoning %d" % (
+                p.layers, p.niter_alter, p.niter_outer, p.niter_inner, p.niter_solver, p.thres_outer, p.thres_inner, p.occlusion_reasoning)}
+
+
+def sor_launch(ctx, B, rank, reps=20):
+    """one batch size of the metric's own kernel: (launches, ms, algorithmic bytes, kernel shape)"""
+    from synth import sor_system
+    sb = sfa.SorBatch(ctx, W, H, B)
+    rng = np.random.default_rng(7 + rank)
+    systems = [sor_system(rng, W, H) for _ in range(min(B, 4))]
+    for b in range(B):
+        s = systems[b % len(systems)]
+        sb.upload(b, *[np.ascontiguousarray(s[k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb.run(SWEEPS, 1.9); ctx.sync()
+    ctx.profile_enable(True)
+    for _ in range(reps):
+        sb.run(SWEEPS, 1.9)
+    n, ms, by = ctx.profile_read()
+    kernel = ctx.profile_read_kernels()[3]
+    ctx.profile_enable(False)
+    sb.close()
+    return n, ms, by, kernel
 
 
 def sor_only(ctx, B, rank):
@@ -340,6 +469,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path-only", action="store_true", help="skip the SOR-only section (used for the PMC passes: every SOR dispatch then belongs to the path)")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU rehearsal of the multi-rank launch and exchange (gloo); prints a selftest line, never a result")
+    ap.add_argument("--no-strong", action="store_true", help="skip the config-4 strong-scaling section (128 windows in total under the cfg schedule)")
     args = ap.parse_args()
 
     # N > 1 and nobody started the ranks: do it here, as a child process, before torch / HIP are touched
@@ -423,9 +553,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     n_sor, sor_ms, sor_bytes = 0, 0.0, 0.0
+    n_asm, asm_ms, asm_px, sor_kernel = 0, 0.0, 0.0, ""
     for c in ctxs:
         n_, ms_, by_ = c.profile_read()
         n_sor += n_; sor_ms += ms_; sor_bytes += by_
+        na_, ma_, pa_, sor_kernel = c.profile_read_kernels()
+        n_asm += na_; asm_ms += ma_; asm_px += pa_
         c.profile_enable(False)
     from slowflow_amd import shard
     if dist is not None:
@@ -437,13 +570,21 @@ def main():
 
     # SOR-only: the metric's own kernel at 1024x436, same batch, HIP events on the launch stream
     n1 = ms1 = by1 = n2 = ms2 = by2 = 0
+    sor16 = None
     if not args.path_only:
         n1, ms1, by1, n2, ms2, by2 = sor_only(ctx, BL, rank)
+        sor16 = sor_launch(ctx, 16, rank)            # what one GPU of an 8-GPU node gets of config 4's 128 windows
+    strong = None
+    if not args.no_strong and not args.path_only:
+        try:
+            strong = config4_strong(ctxs, dev, world, rank, dist, xdev)
+        except Exception as e:                        # a reported extra
+            strong = {"error": str(e)[:200]}
     if rank == 0:
         total = mpix_iters * args.steps * world
         value = total / elapsed_max
         achieved = sor_bytes / (sor_ms * 1e-3) / 1e9 if sor_ms > 0 else 0.0
-        traffic, traffic_src, valu_busy = measured_traffic(BL)
+        traffic, traffic_src, valu_busy = measured_traffic(BL, sor_kernel)
         avg_launch_s = sor_ms / max(n_sor, 1) * 1e-3
         # what one launch must move at least: every operand entry read once (SA 16 B + SB 16 B + x 8 B), x written once (8 B)
         compulsory = 48.0 * (sor_bytes / (44.0 * SWEEPS + 12.0)) / max(n_sor, 1)
@@ -455,30 +596,59 @@ def main():
                                    "symmetric window, modified-L1 penalties, thresholds off",
                        "frame_windows_per_gpu": B, "streams": S, "windows_per_launch": BL, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
                        "parallelism": f"frame-window data parallel x{world}" + ("" if backend == "nccl" or world == 1 else f" (REHEARSAL over {backend}: ranks share {ndev} GPU(s))")},
-            "roofline": {"bound": "hbm", "kernel": "k_sor_band_mixed<4,6,3,2,4,12,16> (batched lockstep solves: 8 pipeline stages of 4,4,4,4,4,4,3,3 fused sweeps per 64-row band; single solves: k_sor_solve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # What bounds the solver: NOT bandwidth.  A kernel that fuses all K sweeps of a band re-reads nothing, so the 8(d) byte model
+            # (44 K + 12 bytes per pixel: every sweep re-reads its operands) gives frac > 1; the launch is as long as the dependency chain of the
+            # reference's raster order: W + H + 2K hyperplane steps at the finest level, each a chain of ~14 dependent packed operations + one DPP
+            # shift (~150 cycles, tools/ubench/valu_rates.hip), plus what the hand-overs between workgroups add.  `frac` stays the 8(d) figure;
+            # the physical picture is in hbm_physical / traffic_over_compulsory, the latency picture in the sor_1024x436_* entries.
+            "roofline": {"bound": "dependency-latency", "kernel": sor_kernel + " (the shape the library picked for %d windows per launch; single solves and small batches: k_sor_chain)" % BL,
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
                          "algorithmic_bytes_per_launch": round(sor_bytes / max(n_sor, 1)),
                          "traffic_source": traffic_src,
-                         # the physical picture beside the algorithmic one: counter bytes / launch time against the HBM peak, the bytes a launch cannot avoid,
-                         # and how busy the vector ALUs are (PMC of the same round) -- the kernel fuses K sweeps, so neither HBM nor VALU issue is its roof:
-                         # it is bound by the latency chain of the K-stage pipeline
                          "hbm_physical": (round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_s > 0 else None),
                          "compulsory_bytes_per_launch": round(compulsory),
                          "traffic_over_compulsory": (round(traffic / compulsory, 2) if traffic and compulsory > 0 else None),
                          "valu_issue_frac": valu_busy,
-                         "note": "over the timed region (launches of all streams; with streams > 1 a launch shares the GPU with the other groups' kernels, so its duration is longer than alone): sum of (44*K+12)*w*h*batch ALGORITHMIC bytes of every SOR launch (all 5 levels) / sum of HIP-event durations; the kernel fuses all K sweeps of a 64-row band in one workgroup (x stays in registers/LDS), so its real HBM traffic is far below the algorithmic bytes and frac can exceed 1",
+                         "steps_critical_level0": W + H + 2 * SWEEPS,
+                         "alu_latency_floor_us_per_step": round(150.0 / CLOCK_GHZ / 1e3, 4),
+                         "note": "over the timed region (launches of all streams; with streams > 1 a launch shares the GPU with the other groups' kernels, so its duration is longer than alone): sum of (44*K+12)*w*h*batch ALGORITHMIC bytes of every SOR launch (all 5 levels) / sum of HIP-event durations",
                          },
             "sor_share_of_step": round(sor_ms / S / (elapsed * 1e3), 4),
             "seconds_per_window": {"mean": round(float(window_seconds.mean()), 6), "max": round(float(window_seconds.max()), 6), "n": int(window_seconds.size)},
         }
+        def sor_entry(batch, n, ms, by, kernel=None):
+            steps = W + H + 2 * SWEEPS
+            e = {"batch": batch, "avg_launch_ms": round(ms / n, 4), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
+                 "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "mpix_iters_per_s": round(W * H * SWEEPS * batch * n / 1e6 / (ms * 1e-3), 1),
+                 "us_per_solve": round(ms / n * 1e3 / batch, 1),
+                 # the launch against the length of the dependency chain: microseconds per hyperplane step, and how many times the ALU-latency floor that is
+                 "us_per_critical_step": round(ms / n * 1e3 / steps, 4),
+                 "x_alu_latency_floor": round(ms / n * 1e3 / steps / (150.0 / CLOCK_GHZ / 1e3), 2)}
+            if kernel:
+                e["kernel"] = kernel
+            return e
         if n1:
-            out["roofline"]["sor_1024x436_batch"] = {"batch": BL, "avg_launch_ms": round(ms1 / n1, 4), "achieved": round(by1 / (ms1 * 1e-3) / 1e9, 1),
-                                                     "frac": round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                     "mpix_iters_per_s": round(W * H * SWEEPS * BL * n1 / 1e6 / (ms1 * 1e-3), 1)}
-            out["roofline"]["sor_1024x436_single"] = {"batch": 1, "avg_launch_ms": round(ms2 / n2, 4), "achieved": round(by2 / (ms2 * 1e-3) / 1e9, 1),
-                                                      "frac": round(by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                      "mpix_iters_per_s": round(W * H * SWEEPS * n2 / 1e6 / (ms2 * 1e-3), 1)}
+            out["roofline"]["sor_1024x436_batch"] = sor_entry(BL, n1, ms1, by1)
+            out["roofline"]["sor_1024x436_single"] = sor_entry(1, n2, ms2, by2)
+        if sor16:
+            out["roofline"]["sor_1024x436_batch16"] = sor_entry(16, sor16[0], sor16[1], sor16[2], sor16[3])
+        # second kernel of the step: the data-term assembly (about 40 % of it).  VALU bound: wave instructions issued per second against the chip's
+        # issue rate (256 CUs x 4 SIMDs, one wave instruction per 4 cycles).  Instructions per pixel and term from the SQ counter pass of the same
+        # kernel (profiles/), duration live from HIP events around every launch of the timed region.
+        if n_asm:
+            ipt, ipt_src = assemble_valu_per_pixel_term()
+            peak_issue = 256 * 4 * CLOCK_GHZ * 1e9 / 4.0
+            ach = (ipt * asm_px / 64.0) / (asm_ms * 1e-3) if ipt else None
+            out["roofline_assemble"] = {"kernel": "k_assemble_images<8,512,4>", "bound": "valu", "launches": n_asm, "avg_launch_ms": round(asm_ms / n_asm, 4),
+                                        "pixel_terms_per_launch": round(asm_px / n_asm), "valu_instructions_per_pixel_term": ipt, "source": ipt_src,
+                                        "achieved": (round(ach / 1e9, 2) if ach else None), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s",
+                                        "frac": (round(ach / peak_issue, 4) if ach else None),
+                                        "share_of_step": round(asm_ms / S / (elapsed * 1e3), 4)}
+        if strong is not None:
+            out["config4_strong"] = strong
         try:
             lat, sor1, rb = one_window_latency(ctx)
             out["latency_one_window_ms"] = round(lat, 3)

@@ -226,6 +226,9 @@ int  sfa_sor_batch_download(sfa_sor_batch *sb, int b, float *du, float *dv, int 
  * While enabled every SOR solve kernel launch is bracketed by an event pair on the launch stream. */
 int  sfa_profile_enable(sfa_ctx *ctx, int on);
 int  sfa_profile_read(sfa_ctx *ctx, int *n_sor_launches, double *sor_ms_total, double *sor_bytes_total);
+/* the same for the data-term assembly kernel (pixels x data terms of the bracketed launches), and the name of the solver kernel shape the last
+ * solve was launched with (so that a measurement can be matched to the kernel it was taken from) */
+int  sfa_profile_read_kernels(sfa_ctx *ctx, int *n_assembly_launches, double *assembly_ms_total, double *assembly_pixel_terms, char *sor_kernel, int sor_kernel_len);
 /* wall bracket on the stream: start/stop an event pair around arbitrary enqueued work */
 int  sfa_timer_start(sfa_ctx *ctx);
 int  sfa_timer_stop(sfa_ctx *ctx, float *ms);

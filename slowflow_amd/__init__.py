@@ -70,7 +70,7 @@ EXPORTS = [
     "sfa_sequence_create", "sfa_sequence_destroy", "sfa_sequence_upload", "sfa_sequence_download", "sfa_sequence_normalize",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_upload_resident", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
-    "sfa_profile_enable", "sfa_profile_read", "sfa_timer_start", "sfa_timer_stop",
+    "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
 ]
 
 _lib = None
@@ -290,6 +290,13 @@ class Context:
         n, ms, by = C.c_int(), C.c_double(), C.c_double()
         self._ck(lib().sfa_profile_read(self.h, C.byref(n), C.byref(ms), C.byref(by)), "sfa_profile_read")
         return n.value, ms.value, by.value
+
+    def profile_read_kernels(self):
+        """(assembly launches, their ms, their pixels x terms, name of the solver kernel shape last launched); call BEFORE profile_enable(False)"""
+        n, ms, px = C.c_int(), C.c_double(), C.c_double()
+        name = C.create_string_buffer(160)
+        self._ck(lib().sfa_profile_read_kernels(self.h, C.byref(n), C.byref(ms), C.byref(px), name, 160), "sfa_profile_read_kernels")
+        return n.value, ms.value, px.value, name.value.decode()
 
     def timer_start(self):
         self._ck(lib().sfa_timer_start(self.h), "sfa_timer_start")

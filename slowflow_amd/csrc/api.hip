@@ -432,6 +432,7 @@ void sfa_ctx_destroy(sfa_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto e : c->ev) (void)hipEventDestroy(e);
+    for (auto e : c->ev2) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->d_red) (void)hipFree(c->d_red);
@@ -478,10 +479,31 @@ int sfa_profile_enable(sfa_ctx *c, int on) {
     c->profile = on != 0;
     c->ev_used = 0;
     c->sor_bytes = 0;
+    c->ev2_used = 0;
+    c->asm_pixel_terms = 0;
     if (on && c->ev.empty()) {
         c->ev.resize(4096);
         for (auto &e : c->ev) SFA_HIP(c, hipEventCreate(&e));
+        c->ev2.resize(4096);
+        for (auto &e : c->ev2) SFA_HIP(c, hipEventCreate(&e));
     }
+    return SFA_OK;
+}
+int sfa_profile_read_kernels(sfa_ctx *c, int *n_asm, double *asm_ms_total, double *asm_pixel_terms, char *sor_kernel, int sor_kernel_len) {
+    if (!c) return SFA_ERR_ARG;
+    SFA_HIP(c, hipStreamSynchronize(c->stream));
+    double tot = 0;
+    for (size_t i = 0; i + 1 < c->ev2_used; i += 2) {
+        float ms = 0;
+        SFA_HIP(c, hipEventElapsedTime(&ms, c->ev2[i], c->ev2[i + 1]));
+        tot += ms;
+    }
+    if (n_asm) *n_asm = (int)(c->ev2_used / 2);
+    if (asm_ms_total) *asm_ms_total = tot;
+    if (asm_pixel_terms) *asm_pixel_terms = c->asm_pixel_terms;
+    if (sor_kernel && sor_kernel_len > 0) snprintf(sor_kernel, (size_t)sor_kernel_len, "%s", c->sor_kernel);
+    c->ev2_used = 0;
+    c->asm_pixel_terms = 0;
     return SFA_OK;
 }
 int sfa_profile_read(sfa_ctx *c, int *n, double *ms_total, double *bytes_total) {

@@ -1160,6 +1160,8 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
 void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
     static const int shape = getenv("SFA_ASSEMBLE_SHAPE") ? atoi(getenv("SFA_ASSEMBLE_SHAPE")) : 0;
+    const bool prof = c->profile && c->ev2_used + 2 <= c->ev2.size();
+    if (prof) (void)hipEventRecord(c->ev2[c->ev2_used], c->stream);
 #define SFA_LAUNCH_AI(TY, NT, MINB)                                                                                                                       \
     do {                                                                                                                                                \
         const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + TY - 1) / TY, g.nb);                                                                          \
@@ -1173,6 +1175,11 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, con
     default: SFA_LAUNCH_AI(8, 512, 4); break;
     }
 #undef SFA_LAUNCH_AI
+    if (prof) {
+        (void)hipEventRecord(c->ev2[c->ev2_used + 1], c->stream);
+        c->ev2_used += 2;
+        c->asm_pixel_terms += (double)g.w * g.h * g.nb * a.n;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

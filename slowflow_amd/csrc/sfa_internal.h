@@ -36,6 +36,10 @@ struct sfa_ctx {
     std::vector<hipEvent_t> ev;   // pairs
     size_t ev_used = 0;
     double sor_bytes = 0;         // algorithmic bytes of the bracketed launches
+    std::vector<hipEvent_t> ev2;  // pairs around the data-term assembly kernel (k_assemble_images)
+    size_t ev2_used = 0;
+    double asm_pixel_terms = 0;   // pixels x data terms of the bracketed assembly launches
+    char sor_kernel[160] = {0};   // the solver kernel (shape) of the last solve launched
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // default-ctx bookkeeping
     int cu_count = 256;

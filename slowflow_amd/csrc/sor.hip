@@ -1016,6 +1016,10 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
     a.ntasks = ws.ntasks; a.nwords = ws.nwords; a.nb = g.nb; a.omega = omega;
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
     if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+    if (ws.chain) snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_chain shape %d (%d groups of stages per band)", ws.chain, ws.NG);
+    else if (ws.band == 43) snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_band_mixed<4,6,3,2,4,12,16>");
+    else if (ws.band) snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_band<%d>", ws.F);
+    else snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_solve<%d,%d>", ws.F, ws.CHK);
     if (ws.chain) {
         SFA_TRY(sor_chain_launch(c, ws, g, K, omega));
     } else if (ws.band) {
