@@ -535,24 +535,14 @@ __device__ __forceinline__ void chain_out(const ChainArgs &a, unsigned char *lds
             }
             {
                 const bool act = I >= LEAD + NW && I < LEAD + NW + a.nch;         // uniform
-                // every lane's column inside the image (uniform): the steady state needs no per-row column test
-                const bool mid = s_out - 63 - (Fl - 1) >= 0 && s_out + CH - 1 < W;
                 const int po = (p + NW - 1) & 1;
-#ifdef SFA_X_OUT_NOLDS    // timing experiment only: some global array instead (never dereferenced with the atomics off... here: the dummy region)
-                const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(ldsb + L::dummy0) + (lane & 1) + po * 0;
-#else
                 const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(ldsb + L::ring0 + NW * L::RING + (po * CH * 64) * 8) + lane;
-#endif
-                if (mid) {
-                    const unsigned vo = act ? vXout : kOobOffset;
+                // straight-line on purpose (no fast path for the steady state): the counted wait below relies on exactly T memory instructions per
+                // interval, and tools/check_publish_vmcnt.py counts them on the ISA
 #pragma unroll
-                    for (int j = 0; j < CH; j++) batomic_swap8(rXout, vo, so_xout + (unsigned)j * st8, rp[j * 64]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < CH; j++) {
-                        const bool ok = act && (unsigned)(s_out + j - lanef) < (unsigned)W;
-                        batomic_swap8(rXout, ok ? vXout : kOobOffset, so_xout + (unsigned)j * st8, rp[j * 64]);
-                    }
+                for (int j = 0; j < CH; j++) {
+                    const bool ok = act && (unsigned)(s_out + j - lanef) < (unsigned)W;
+                    batomic_swap8(rXout, ok ? vXout : kOobOffset, so_xout + (unsigned)j * st8, rp[j * 64]);
                 }
             }
             // ---- publish: the stores of interval I - PUBD are older than the PUBD * T instructions issued since ------------------------------
