@@ -934,7 +934,10 @@ int sfa_sequence_upload(sfa_sequence *q, int f, const float *frame3, int stride)
     CHECK_ARGS(q && f >= 0 && f < q->n && frame3 && stride >= q->w, "bad arguments");
     SFA_HIP(ctx, hipSetDevice(ctx->device));
     for (int k = 0; k < 3; k++) SFA_TRY(upload_plane(ctx, q->frame(f) + k * q->pl, q->pitch, frame3 + (size_t)k * stride * q->h, stride, q->w, q->h));
-    return SFA_OK;                                           // asynchronous on the context's stream; sfa_ctx_sync / any later call orders behind it
+    // the copies read pageable host memory of the caller: wait for them, so that the buffer may be freed or reused on return (like sfa_job_upload;
+    // the driver calls this from its decode threads, where the wait hides behind the decoding of the next frame)
+    SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFA_OK;
 }
 int sfa_sequence_download(sfa_sequence *q, int f, float *frame3, int stride) {
     sfa_ctx *ctx = q ? q->ctx : nullptr;

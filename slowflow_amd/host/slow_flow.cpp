@@ -164,6 +164,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     // ---- read the image sequence (:447-592, without OpenCV: PNG, binary PPM / PGM / PFM): decoded, demosaiced and cropped by the
     //      io pool, one frame per task ----------------------------------------------------------------------------------------------
     std::vector<color_image_t *> seq(frames, nullptr), seq_back(frames, nullptr);
+    std::vector<int> seq_maxval(frames, 255);            // 255 / 65535 per frame: the 8-bit copy EpicFlow's saliency works on divides 16-bit samples by 255 (:472-474, :578)
     std::vector<string> names(frames);
     for (unsigned f = start_f; f < end_f; f++) {
         if (!sintel) names[f] = fmt1(sequence_path + format, (int)start - ref * skip + (int)f * skip);
@@ -208,6 +209,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                     img = part;
                 }
                 seq[f] = img;
+                seq_maxval[f] = maxval;
             });
         pool.wait_all();
     }
@@ -283,6 +285,8 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     const bool oversubscribe = params.parameter<bool>("gpu_oversubscribe", "0");
     if (params.exists("gpus")) ngpu = std::max(1, oversubscribe ? std::min(16, params.parameter<int>("gpus")) : std::min(ngpu, params.parameter<int>("gpus")));
     const int dev0 = params.parameter<int>("gpu_device", "0");
+    if (!oversubscribe) ngpu = std::max(1, std::min(ngpu, ndev - dev0));             // devices dev0 .. ndev-1 exist; asking for more would only fail after all frames are decoded
+    if (!oversubscribe && dev0 >= ndev) { std::cerr << "gpu_device " << dev0 << " does not exist (" << ndev << " device(s))" << std::endl; return 4; }
     auto device_of = [&](int g) { return oversubscribe ? (dev0 + g) % ndev : dev0 + g; };
     const int n_loaded = (int)(end_f - start_f);
     std::vector<sfa_ctx *> seq_ctx(ngpu, nullptr);
@@ -422,7 +426,20 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                         if (!read_matches((wd.backward ? matches_file(b, a) : matches_file(a, b)).c_str(), mt) ||
                             !read_edges((wd.backward ? edges_file(b) : edges_file(a)).c_str(), width, height, ed)) rc = SFA_ERR_ARG;
                         else {
-                            color_image_t *lab = rgb_to_lab(un_ref);
+                            // the reference hands epic() un_seq: the frame after img.convertTo(CV_8U, norm), i.e. rounded to nearest and saturated to 0..255,
+                            // 16-bit samples scaled by 1/255 first (slow_flow.cpp:472-474, :578-586) -- not the float frame the refinement reads
+                            const int fi = wd.backward ? f + 2 * ref : f + ref;
+                            color_image_t *un8 = color_image_new(un_ref->width, un_ref->height);
+                            {
+                                const float norm = seq_maxval[fi] > 255 ? 1.0f / 255 : 1.0f;
+                                const size_t n3 = (size_t)3 * un_ref->stride * un_ref->height;
+                                for (size_t i = 0; i < n3; i++) {
+                                    const float v = nearbyintf(un_ref->c1[i] * norm);              // cvRound: to nearest, ties to even
+                                    un8->c1[i] = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);       // saturate_cast<uchar>
+                                }
+                            }
+                            color_image_t *lab = rgb_to_lab(un8);
+                            color_image_delete(un8);
                             iwx = image_new(width, height); iwy = image_new(width, height);
                             image_erase(iwx); image_erase(iwy);
                             const int er = epic(ctx, iwx, iwy, lab, mt, ed, &ep);
@@ -480,7 +497,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                     const Window &wd = todo[mine[b0 + e]];
                     const int f = wd.jet * steps;
                     std::cout << (wd.backward ? "Backward" : "Forward") << " flow from frame " << start + f * skip << " to " << start + f * skip + steps * skip
-                              << " finished! (GPU " << dev0 + wp.gpu << ", " << secs / nb << " s per window in a batch of " << nb << ")" << std::endl;
+                              << " finished! (GPU " << device << ", " << secs / nb << " s per window in a batch of " << nb << ")" << std::endl;
                 }
             }
             if (job) sfa_job_destroy(job);

@@ -144,6 +144,9 @@ bool tiff_read(const char *filename, png_image &out) {
     for (uint32_t b : bits) if (b != bps) return false;
     if (bps != 8 && bps != 16) return false;
     if (photometric > 2) return false;                             // 0 WhiteIsZero, 1 BlackIsZero, 2 RGB
+    // grey images have one sample and a grey interpretation, colour images three (a fourth -- ExtraSamples, e.g. alpha -- is dropped) and RGB: anything
+    // else (three samples called grey, one sample called RGB) would decode to a plausible-looking wrong image
+    if (!((spp == 1 && photometric <= 1) || (spp >= 3 && photometric == 2))) return false;
     const bool deflate = compression == 8 || compression == 32946;
     if (compression != 1 && compression != 5 && compression != 32773 && !deflate) return false;
     if (predictor != 1 && !(predictor == 2 && (compression == 5 || deflate))) return false;
@@ -200,7 +203,9 @@ bool tiff_read(const char *filename, png_image &out) {
 
 bool tiff_write(const char *filename, const png_image &img) {
     if (img.width <= 0 || img.height <= 0 || (img.channels != 1 && img.channels != 3) || (img.depth != 8 && img.depth != 16)) return false;
-    const uint32_t nbytes = (uint32_t)((size_t)img.width * img.height * img.channels * (img.depth / 8));
+    const uint64_t nbytes64 = (uint64_t)img.width * img.height * img.channels * (img.depth / 8);
+    if (nbytes64 > 0xfff00000ull) return false;                    // classic TIFF has 32-bit offsets: the strip and the directory behind it must fit
+    const uint32_t nbytes = (uint32_t)nbytes64;
     std::vector<unsigned char> d;
     auto p16 = [&](uint32_t v) { d.push_back((unsigned char)(v & 255)); d.push_back((unsigned char)(v >> 8)); };
     auto p32 = [&](uint32_t v) { p16(v & 0xffff); p16(v >> 16); };

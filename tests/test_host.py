@@ -731,8 +731,17 @@ def test_driver_adaptive_frame_rates_and_alternation_outputs(host_build, tmp_pat
     assert set(np.unique(rows[:, 1:])) <= {0, 255}
 
 
+def write_ppm16(path, img):        # img: (3,h,w) float 0..65535, big-endian samples as the PNM format has them
+    h, w = img.shape[1:]
+    data = np.clip(np.round(img), 0, 65535).astype(">u2").transpose(1, 2, 0).tobytes()
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n65535\n" % (w, h))
+        f.write(data)
+
+
 @pytest.mark.gpu
-def test_driver_deep_matching_initialisation(host_build, tmp_path):
+@pytest.mark.parametrize("bits", [8, 16])
+def test_driver_deep_matching_initialisation(host_build, tmp_path, bits):
     """deep_matching 1 (slow_flow.cpp:744-863, 960-1004): with match and edge files at the reference's locations (<output>tmp/matches_<a>_<b>.dat, edges_<n>.dat) the
     driver initialises every window with EpicFlow's interpolation and refines from there: the .flo equals the binding run from the same initial flow (epic through
     tests/host/epic_tool.cpp, divided by steps), and a large motion that the zero-initialised refinement cannot reach at one level is recovered."""
@@ -743,8 +752,12 @@ def test_driver_deep_matching_initialisation(host_build, tmp_path):
     nframes = 1 + (jets + 2) * steps
     DX, DY = 9.0, -6.0                                               # large motion: out of reach for a single-level variational refinement from zero
     frames = [np.clip(np.round(texture_frame(w, h, k, dx=DX, dy=DY)[:, :, :w]), 0, 255) for k in range(nframes)]
+    if bits == 16:
+        # 16-bit input: samples 0..65535 that are NOT multiples of 255, so the 8-bit copy EpicFlow's saliency works on
+        # (img.convertTo(CV_8U, 1/255): slow_flow.cpp:472-474, :578) differs from both the frame and frame / 255
+        frames = [np.clip(np.round(f * 255.0 + 100.0 * np.sin(0.37 * np.arange(w))[None, None, :] + 60.0), 0, 65535).astype(np.float32) for f in frames]
     for k, f in enumerate(frames):
-        write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), f)
+        (write_ppm16 if bits == 16 else write_ppm)(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), f)
     out = tmp_path / "out"
     (out / "tmp").mkdir(parents=True)
     rng = np.random.default_rng(0)
@@ -756,9 +769,9 @@ def test_driver_deep_matching_initialisation(host_build, tmp_path):
     for n in (10, 11):
         (0.05 + 0.02 * rng.uniform(0, 1, (h, w))).astype(np.float32).tofile(str(out / "tmp" / ("edges_%d.dat" % n)))
     cfg = tmp_path / "run.cfg"
-    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t1\ndm_scale\t1.0\nverbose\t00001\n"
+    cfg.write_text(("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t" + ("1" if bits == 16 else "0") + "\nraw\t0\nscale\t1.0\ndeep_matching\t1\ndm_scale\t1.0\nverbose\t00001\n"
                    "slow_flow_S\t%d\nslow_flow_layers\t1\nslow_flow_niter_alter\t1\nslow_flow_niter_outer\t5\nslow_flow_occlusion_reasoning\t0\n"
-                   "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\n" % (tmp_path, tmp_path, jets, S))
+                   "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\n") % (tmp_path, tmp_path, jets, S))
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     u, v = read_flo(str(out / "f_010.flo"))
@@ -777,7 +790,8 @@ def test_driver_deep_matching_initialisation(host_build, tmp_path):
     # the forward window through the binding from the same initial flow
     exe = _link_host_test(tmp_path, ["epic_tool.cpp"], "epic_tool")
     st = sfa.stride_of(w)
-    rgb = np.zeros((3, h, st), np.float32); rgb[:, :, :w] = frames[1]
+    rgb = np.zeros((3, h, st), np.float32)
+    rgb[:, :, :w] = frames[1] if bits == 8 else np.clip(np.rint(frames[1] * np.float32(1.0 / 255)), 0, 255)      # un_seq: the 8-bit copy
     rgb.tofile(str(tmp_path / "epic_rgb.bin"))
     import shutil
     shutil.copy(str(out / "tmp" / "matches_10_11.dat"), str(tmp_path / "epic_matches.txt"))
@@ -793,7 +807,7 @@ def test_driver_deep_matching_initialisation(host_build, tmp_path):
         fr.append(a)
     avg, std = ctx.normalize(fr, w)
     p = sfa.default_params()
-    p.S = S; p.layers = 1; p.niter_alter = 1; p.niter_outer = 5; p.occlusion_reasoning = 0; p.thres_outer = 0; p.thres_inner = 0; p.hbit = 0; p.smoothing = 1
+    p.S = S; p.layers = 1; p.niter_alter = 1; p.niter_outer = 5; p.occlusion_reasoning = 0; p.thres_outer = 0; p.thres_inner = 0; p.hbit = 1 if bits == 16 else 0; p.smoothing = 1
     p.rho[0] = 1; p.omega[0] = 0
     for k in range(3):
         p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
