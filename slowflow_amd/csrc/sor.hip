@@ -268,6 +268,25 @@ struct BandArgs {
     float omega;
 };
 
+// What a band hands to the band below -- lane 63's iterates and the progress word -- leaves as write-through (sc1) stores.  sor_chain.hip found that ONE
+// small sc1 store per 4-step interval from any wave holds up its CU's load stream (~520 cycles) and moved to no-return atomics; here a wave publishes twice
+// per 12-step macro chunk and the same change measured nothing (1024x436x30, batches 8 / 16 / 32 / 64: 1255 / 1311 / 1372 / 2044 us with atomics against
+// 1251 / 1300 / 1362 / 2038 with the stores), so the form the hand-off rules are documented for stays.  -DSFA_BAND_ATOMICS: the comparison build.
+__device__ __forceinline__ void publish_x(unsigned long long *p, unsigned long long v) {
+#ifdef SFA_BAND_ATOMICS
+    (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    st_x(p, v);
+#endif
+}
+__device__ __forceinline__ void publish_word(unsigned *p, unsigned v) {
+#ifdef SFA_BAND_ATOMICS
+    (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 __device__ __forceinline__ bool wait_lds_ge(unsigned *p, unsigned target, unsigned *err) {
     unsigned spins = 0;
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) {
@@ -553,14 +572,14 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
                 // edge store of the previous macro chunk and this wait in every role of every shape
                 if (CH >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(gmine, (unsigned)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) publish_word(gmine, (unsigned)m);
             }
         }
         // lane 63's iterates of this macro chunk: sweep f, steps s0-MC .. s0-1 are MC consecutive columns of edge row f, one
         // 64-byte piece per sweep in a single store (instead of F stores per step)
         if (publishes && lane < F * MC) {
             const int fi = lane / MC, j = lane % MC;
-            st_x(e_mine + (long)fi * a.Wp + (s0 - MC - 63 - fi + j), estage[fi][j]);
+            publish_x(e_mine + (long)fi * a.Wp + (s0 - MC - 63 - fi + j), estage[fi][j]);
         }
         if (has_up && !last && !pre) {
             SFA_T0();
@@ -573,7 +592,7 @@ __device__ __forceinline__ void band_wave(const BandArgs &a, unsigned long long 
     }
     if (publishes) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(gmine, (unsigned)NMC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) publish_word(gmine, (unsigned)NMC);
     }
 #ifdef SFA_BAND_TIMING
     if (job == 0 && lane == 0 && b < 16 && wave < 16) {

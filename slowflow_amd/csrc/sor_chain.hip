@@ -165,11 +165,12 @@ __device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bott
 // P0 = PD * CH steps of operand prefetch in registers for sweep 0 (first touch of the rows: Infinity Cache / HBM), P1 for the trailing
 // sweeps (the rows this CU fetched 2 f steps earlier: L2).  PD even: the ring parity of a chunk is its position in the unrolled body.
 // A slot is refilled one step AFTER its use: the next column's left weight (hp of this column) is read from it in place.
-template <int F, int CH, int PD>
+template <int F, int CH, int PD, bool SHORT = false>
 __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char *lds, int ring_in, int ring_out, int tvb, int esb, int dummy, int job, int b,
                                               int k0, int s_start, int lead, int lane) {
     static_assert(PD % 2 == 0, "the chunk parity must be a compile-time constant of the body position");
-    constexpr int P0 = PD * CH, P1 = F <= 2 ? P0 : CH;
+    // ring lengths divide the body (PD * CH steps): wide stages (F >= 4: a whole band's sweeps in one workgroup, large batches, slow steps) keep one chunk
+    constexpr int P0 = (F >= 4 || SHORT) ? CH : PD * CH, P1 = (F <= 2 && !SHORT) ? P0 : CH;
     const int RP = a.RP;
     const float omega = a.omega;
     const int r0 = 64 * b - k0;
@@ -220,12 +221,17 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
         for (int q = 0; q < PD; q++) {
             SFA_CHAIN_BARRIER_T2(t_bar, t_wr);
             const int par = q & 1;
+            // narrow stages read the chunk's LDS inputs at its top (one exposed LDS latency per chunk); wide ones (F >= 4: several waves per SIMD hide
+            // it) step by step, which keeps (CH - 1) * (F + 2) register pairs free
+            constexpr bool JIT = F >= 4;
             unsigned long long bot[CH], fl[CH][F + 1];
+            if (!JIT) {
 #pragma unroll
-            for (int j = 0; j < CH; j++) {
-                bot[j] = rin[(par * CH + j) * 64];
+                for (int j = 0; j < CH; j++) {
+                    bot[j] = rin[(par * CH + j) * 64];
 #pragma unroll
-                for (int fi = 0; fi <= F; fi++) fl[j][fi] = tvp[(par * CH + j) * (F + 1) + fi];
+                    for (int fi = 0; fi <= F; fi++) fl[j][fi] = tvp[(par * CH + j) * (F + 1) + fi];
+                }
             }
 #ifdef SFA_CHAIN_TIMING
             {   // how long the chunk's LDS reads take (diagnosis only: the wait is forced here)
@@ -236,8 +242,14 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
 #endif
 #pragma unroll
             for (int j = 0; j < CH; j++) {
-                const int j0 = q * CH + j, j1 = j0 % P1;             // ring slots of this step
+                const int j0 = (q * CH + j) % P0, j1 = (q * CH + j) % P1;   // ring slots of this step
                 const int p0 = (j0 + P0 - 1) % P0, p1 = (j1 + P1 - 1) % P1;   // ... and of the previous one
+                if (JIT) {
+                    bot[j] = rin[(par * CH + j) * 64];
+#pragma unroll
+                    for (int fi = 0; fi <= F; fi++) fl[j][fi] = tvp[(par * CH + j) * (F + 1) + fi];
+                    asm volatile("" ::: "memory");             // the reads of the next step stay behind this step's arithmetic
+                }
                 const float2 bottom0 = u2f(bot[j]);
                 float2 sh[F], right0;
                 { const float2 t = u2f(fl[j][0]); right0.x = lane_shr1(bottom0.x, t.x); right0.y = lane_shr1(bottom0.y, t.y); }
@@ -694,8 +706,9 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
     const int s_start = c_first * CH - O;
     const int ring_in = L::ring0 + w * L::RING, ring_out = ring_in + L::RING;
     const int tvb = L::tv0 + w * L::TVW, esb = L::es0 + w * L::ESW;
-    if (w < NA) chain_compute<FA, CH, PD>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
-    else        chain_compute<FB, CH, PD>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
+    constexpr bool SHORT = NW >= 8;                  // many waves per workgroup: fewer registers each
+    if (w < NA) chain_compute<FA, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
+    else        chain_compute<FB, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -720,6 +733,8 @@ static const ChainShapeInfo kChainShapes[] = {
     {5, 2, 5, 2, 0, 2},      // 5 stages of 2                  KG = 10
     {6, 1, 5, 1, 0, 4},      // 5 stages of 1                  KG = 5
     {8, 3, 2, 3, 0, 2},      // 2 stages of 3                  KG = 6
+    {9, 5, 6, 5, 0, 2},      // 6 stages of 5                  KG = 30: a whole band per workgroup (large batches)
+    {10, 3, 10, 3, 0, 2},    // 10 stages of 3                 KG = 30
 };
 
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
@@ -766,6 +781,8 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
         case 5: chain_launch_shape<2, 5, 2, 0, 2>(c, a, nwg); break;
         case 6: chain_launch_shape<1, 5, 1, 0, 4>(c, a, nwg); break;
         case 8: chain_launch_shape<3, 2, 3, 0, 2>(c, a, nwg); break;
+        case 9: chain_launch_shape<5, 6, 5, 0, 2>(c, a, nwg); break;
+        case 10: chain_launch_shape<3, 10, 3, 0, 2>(c, a, nwg); break;
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }
     return SFA_OK;

@@ -257,7 +257,7 @@ SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH":
                 # sor_chain.hip (few windows per launch): groups of stages per workgroup + I/O wave; a shape whose sweeps per group do not divide K
                 # falls back to the kernels above
                 "chain_1x3": {"SFA_SOR_CHAIN": "1"}, "chain_2x3": {"SFA_SOR_CHAIN": "2"}, "chain_3x5": {"SFA_SOR_CHAIN": "3"}, "chain_2x5": {"SFA_SOR_CHAIN": "5"},
-                "chain_1x5": {"SFA_SOR_CHAIN": "6"}, "chain_3x2": {"SFA_SOR_CHAIN": "8"}}
+                "chain_1x5": {"SFA_SOR_CHAIN": "6"}, "chain_3x2": {"SFA_SOR_CHAIN": "8"}, "chain_5x6": {"SFA_SOR_CHAIN": "9"}, "chain_3x10": {"SFA_SOR_CHAIN": "10"}}
 
 
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))
