@@ -212,6 +212,7 @@ int  sfa_job_download_occlusions(sfa_job *job, int b, float *occ, int stride);
 int  sfa_job_keep_alternation_occlusions(sfa_job *job, int on);
 int  sfa_job_download_alternation_occlusions(sfa_job *job, int b, int alter, float *occ, int stride);
 double sfa_job_mpix_iters(const sfa_job *job);       /* sum over the job's SOR solves of w*h*K / 1e6, per run */
+double sfa_job_device_bytes(const sfa_job *job);     /* device memory the job holds right now (arena + solver workspaces shaped so far) */
 
 /* SOR-only resident batch: `batch` independent systems of one size */
 typedef struct sfa_sor_batch sfa_sor_batch;

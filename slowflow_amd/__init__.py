@@ -68,7 +68,7 @@ EXPORTS = [
     "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
     "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_resize_linear_fx", "sfa_gaussian_presmooth", "sfa_pyramid_sizes",
     "sfa_sequence_create", "sfa_sequence_destroy", "sfa_sequence_upload", "sfa_sequence_download", "sfa_sequence_normalize",
-    "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_upload_resident", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters",
+    "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_upload_resident", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters", "sfa_job_device_bytes",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
     "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
 ]
@@ -88,6 +88,8 @@ def lib():
         L.sfa_last_error.argtypes = [C.c_void_p]
         L.sfa_job_mpix_iters.restype = C.c_double
         L.sfa_job_mpix_iters.argtypes = [C.c_void_p]
+        L.sfa_job_device_bytes.restype = C.c_double
+        L.sfa_job_device_bytes.argtypes = [C.c_void_p]
         for name in ("sfa_ctx_destroy", "sfa_job_destroy", "sfa_sor_batch_destroy", "sfa_sequence_destroy"):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [C.c_void_p]
@@ -356,6 +358,9 @@ class Job:
 
     def mpix_iters(self):
         return lib().sfa_job_mpix_iters(self.h_)
+
+    def device_bytes(self):
+        return lib().sfa_job_device_bytes(self.h_)
 
     def close(self):
         if self.h_:

@@ -64,12 +64,17 @@ static PenaltyDev pen(const sfa_penalty &p) { return PenaltyDev{p.id, p.eps, p.t
 
 // ---------------------------------------------------------------------------------------------------
 // Level: device-resident state of `nb` frame windows at one pyramid level.
-// Element arena layout (floats, per batch element), PL = pitch*h:
-//   planes : wx wy uu vv du dv odu odv sh sv a11 a12 a22 b1 b2 occ dpsis   (17 PL)
-//   masks  : 2*ref PL
-//   warped : [slot][w_s|w_sp1] (3 PL each); a factor-0 warp is the frame itself and is not materialised
-//   stacks : [slot][succ|toref][24 PL] -- only in the unfused form (SFA_UNFUSED=1, kept to cross-check the fused kernel)
-//   frames : F x 3 PL
+// Element arena (floats, per window; the same element stride for every plane of every level), PL = pitch*h of the level:
+//   PERSISTENT part, one per level (the pyramid is built before the coarse-to-fine loop and the flow travels from level to level):
+//     wx wy (2 PL), frames F x 3 PL
+//   TRANSIENT part, ONE for all levels (only one level is refined at a time), sized for the finest level:
+//     planes : uu vv du dv odu odv sh sv a11 a12 a22 b1 b2 occ dpsis   (15 PL)
+//     masks  : 2*ref PL
+//     warped : [slot][w_s|w_sp1] (3 PL each); a factor-0 warp is the frame itself and is not materialised
+//     stacks : [slot][succ|toref][24 PL] -- only in the unfused form (SFA_UNFUSED=1, kept to cross-check the fused kernel)
+//     tmp    : two colour images for the pyramid / presmoothing: they are dead before the first warp, so they LIE ON the warped images (6 PL <= 12 ref PL)
+// Offsets handed to kernels (Term, WarpJob, OccSlot) are relative to `base` (the transient part) and may point into the persistent part.
+// Round 3, arena + solver workspaces: 0.43 -> 0.30 GB per 1024x436 window (S = 2, 5 levels), 4 -> 1.63 GB per 2048x2048 window (6 levels).
 // ---------------------------------------------------------------------------------------------------
 enum { P_WX = 0, P_WY, P_UU, P_VV, P_DU, P_DV, P_ODU, P_ODV, P_SH, P_SV, P_A11, P_A12, P_A22, P_B1, P_B2, P_OCC, P_DPSIS, P_COUNT };
 
@@ -77,26 +82,27 @@ struct Level {
     int w = 0, h = 0, pitch = 0, lstride = 0, ref = 0, F = 0, nb = 0;
     bool fused = true;
     long pl = 0, es = 0;
-    long off_masks = 0, off_warp = 0, off_stacks = 0, off_frames = 0, off_tmp = 0;
-    float *base = nullptr;    // element 0
-    float *plane(int i) const { return base + (long)i * pl; }
+    long off_masks = 0, off_warp = 0, off_stacks = 0, off_tmp = 0;
+    float *base = nullptr;    // transient part, element 0
+    float *pbase = nullptr;   // this level's persistent part, element 0
+    float *plane(int i) const { return i < 2 ? pbase + (long)i * pl : base + (long)(i - 2) * pl; }
     float *mask(int s) const { return base + off_masks + (long)s * pl; }
     float *stack(int s, int toref) const { return base + off_stacks + ((long)s * 2 + toref) * 24 * pl; }
     float *warp(int s, int sp1) const { return base + off_warp + ((long)s * 2 + sp1) * 3 * pl; }
-    float *frame(int f) const { return base + off_frames + (long)f * 3 * pl; }
+    float *frame(int f) const { return pbase + 2 * pl + (long)f * 3 * pl; }
+    float *tmp() const { return base + off_tmp; }
     Geo geo(unsigned long long active = ~0ull) const { return Geo{w, h, pitch, pl, es, nb, active}; }
-    static long elem_floats(int pitch, int h, int ref, bool fused) {
-        const long pl = (long)pitch * h;
-        return pl * (P_COUNT + 2 * ref + 2L * ref * 6 + (fused ? 0 : 2L * ref * 2 * 24) + (2L * ref + 1) * 3 + 6 /* tmp colour images for the pyramid */);
+    static long persistent_floats(int pitch, int h, int ref) { return (long)pitch * h * (2 + (2L * ref + 1) * 3); }
+    static long transient_floats(int pitch, int h, int ref, bool fused) {
+        return (long)pitch * h * ((P_COUNT - 2) + 2 * ref + 2L * ref * 6 + (fused ? 0 : 2L * ref * 2 * 24));
     }
-    void layout(float *b, int w_, int h_, int lstride_, int ref_, int nb_, long es_, bool fused_) {
-        base = b; w = w_; h = h_; pitch = dev_pitch(w_); lstride = lstride_; ref = ref_; F = 2 * ref_ + 1; nb = nb_; es = es_; fused = fused_;
+    void layout(float *transient, float *persistent, int w_, int h_, int lstride_, int ref_, int nb_, long es_, bool fused_) {
+        base = transient; pbase = persistent; w = w_; h = h_; pitch = dev_pitch(w_); lstride = lstride_; ref = ref_; F = 2 * ref_ + 1; nb = nb_; es = es_; fused = fused_;
         pl = (long)pitch * h;
-        off_masks = (long)P_COUNT * pl;
+        off_masks = (long)(P_COUNT - 2) * pl;
         off_warp = off_masks + 2L * ref * pl;
         off_stacks = off_warp + 2L * ref * 6 * pl;
-        off_frames = off_stacks + (fused ? 0 : 2L * ref * 2 * 24 * pl);
-        off_tmp = off_frames + (long)F * 3 * pl;
+        off_tmp = off_warp;                                  // 6 PL inside the 12 ref PL of the warped images (ref >= 1)
     }
 };
 
@@ -374,7 +380,9 @@ struct sfa_job {
     int w = 0, h = 0, nb = 0, ref = 0, F = 0, L = 0;
     int ws[64], hs[64];
     long es = 0;                       // floats per element (all levels)
-    std::vector<long> level_off;       // offset of each level's arena inside the element
+    std::vector<long> level_off;       // offset of each level's PERSISTENT part inside the element
+    long trans_off = 0;                // offset of the transient part (shared by all levels)
+    bool share_sor = false;            // large frames: one solver workspace for all levels (re-shaped per level), not one per level
     DevMem arena;                      // nb * es floats
     DevMem init_flow;                  // nb x 2 planes at level-0 pitch: the uploaded initial flow
     DevMem chw;                        // nb x 3 planes (level-0 pitch) or empty
@@ -386,7 +394,7 @@ struct sfa_job {
     double mpix_iters = 0;
     Level level(int l) const {
         Level Lv;
-        Lv.layout(arena.f() + level_off[l], ws[l], hs[l], l == 0 ? host_stride0 : host_stride(ws[l]), ref, nb, es, fused);
+        Lv.layout(arena.f() + trans_off, arena.f() + level_off[l], ws[l], hs[l], l == 0 ? host_stride0 : host_stride(ws[l]), ref, nb, es, fused);
         return Lv;
     }
     int host_stride0 = 0;
@@ -997,9 +1005,14 @@ int sfa_job_create(sfa_ctx *ctx, const sfa_params *p, int w, int h, int batch, s
     long off = 0;
     for (int l = 0; l < j->L; l++) {
         j->level_off[l] = off;
-        off += Level::elem_floats(dev_pitch(j->ws[l]), j->hs[l], j->ref, j->fused);
+        off += Level::persistent_floats(dev_pitch(j->ws[l]), j->hs[l], j->ref);
     }
+    j->trans_off = off;
+    off += Level::transient_floats(dev_pitch(j->ws[0]), j->hs[0], j->ref, j->fused);     // level 0 is the largest
     j->es = off;
+    // the solver workspaces (40 bytes per entry of the diagonal-major planes) of all levels together are 3.5 x the finest one's: from 2 Mpx on, one
+    // workspace is re-shaped level by level (a few memsets per level against hundreds of ms of refinement); below that every level keeps its own
+    j->share_sor = (double)w * h >= 2.0e6 || getenv("SFA_SHARE_SOR");
     j->host_stride0 = host_stride(w);
     SFA_TRY(j->arena.alloc(ctx, (size_t)batch * j->es * sizeof(float)));
     SFA_HIP(ctx, hipMemsetAsync(j->arena.p, 0, (size_t)batch * j->es * sizeof(float), ctx->stream));
@@ -1021,6 +1034,12 @@ void sfa_job_destroy(sfa_job *j) {
     delete j;
 }
 double sfa_job_mpix_iters(const sfa_job *j) { return j ? j->mpix_iters : 0; }
+double sfa_job_device_bytes(const sfa_job *j) {
+    if (!j) return 0;
+    double b = (double)j->arena.bytes + j->init_flow.bytes + j->chw.bytes + j->cut_scratch.bytes + j->occ_log.bytes;
+    for (const auto &w : j->sor) b += (double)w->sa.bytes + w->sb.bytes + w->x.bytes + w->flags.bytes + w->order.bytes + w->edge.bytes;
+    return b;
+}
 
 static int job_set_channel_weights(sfa_job *j, int b, int stride, const float *const chw[3]) {
     sfa_ctx *ctx = j->ctx;
@@ -1110,7 +1129,7 @@ int sfa_job_run(sfa_job *j) {
     if (p.presmooth_sigma > 0 && (j->presmoothed & all) != all) {                     // :590-597
         // the smoothed frames replace the uploaded ones, once per upload: a job may be run again (warm-up + timed runs, a second pass
         // over the same windows) and must then start from the same images
-        float *tmp = L0.base + L0.off_tmp;
+        float *tmp = L0.tmp();
         for (int f = 0; f < F; f++) {
             launch_presmooth(ctx, L0.geo(all), tmp + 3 * L0.pl, tmp, L0.frame(f), 3, p.presmooth_sigma);
             launch_copy_planes(ctx, L0.geo(all & ~j->presmoothed), L0.frame(f), tmp + 3 * L0.pl, 3, L0.es, L0.es);
@@ -1119,7 +1138,7 @@ int sfa_job_run(sfa_job *j) {
     }
     for (int l = 1; l < L; l++) {
         Level Lp = j->level(l - 1), Lc = j->level(l);
-        float *tmp = Lp.base + Lp.off_tmp;
+        float *tmp = Lp.tmp();
         // all F frames (3 F consecutive planes per window) in one pass: :607 + :611 fused
         if (!getenv("SFA_PYRAMID_UNFUSED") &&
             launch_pyr_down(ctx, Lc.frame(0), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Lp.frame(0), Lp.w, Lp.h, Lp.pitch, Lp.pl, Lp.es, 3 * F, nb, taps, radius))
@@ -1151,7 +1170,7 @@ int sfa_job_run(sfa_job *j) {
             launch_resize(ctx, Lc.plane(P_WX), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WX), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fx);   // :711,716
             launch_resize(ctx, Lc.plane(P_WY), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WY), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fy);
         }
-        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[l], j->cut_scratch, j->change.data(), l == 0 && j->keep_alt_occ ? j->occ_log.f() : nullptr));   // :761
+        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[j->share_sor ? 0 : l], j->cut_scratch, j->change.data(), l == 0 && j->keep_alt_occ ? j->occ_log.f() : nullptr));   // :761
     }
     SFA_HIP(ctx, hipGetLastError());
     return SFA_OK;

@@ -497,7 +497,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                     const Window &wd = todo[mine[b0 + e]];
                     const int f = wd.jet * steps;
                     std::cout << (wd.backward ? "Backward" : "Forward") << " flow from frame " << start + f * skip << " to " << start + f * skip + steps * skip
-                              << " finished! (GPU " << device << ", " << secs / nb << " s per window in a batch of " << nb << ")" << std::endl;
+                              << " finished! (GPU " << wp.gpu << " = device " << device << ", " << secs / nb << " s per window in a batch of " << nb << ")" << std::endl;
                 }
             }
             if (job) sfa_job_destroy(job);

@@ -583,6 +583,66 @@ def test_config5_pyramid_6_levels_fused_equals_unfused(ctx, oracle, monkeypatch)
     assert abs(np.median(valid(out[1][0], w)) - 2.0) < 0.2 and abs(np.median(valid(out[1][1], w)) - 1.0) < 0.2   # the sequence moves by (2,1) px / frame
 
 
+def test_config5_batch_32_fits_in_1_65_gb_per_window(ctx, oracle):
+    """arena diet: one level is live at a time, so the work planes of all levels share one region and, for large frames, so do the
+    solver workspaces.  2048x2048, 6 levels, Lorentzian: a lockstep batch of 32 windows costs <= 1.65 GB per window (round 2: ~4 GB, so config 5
+    could not reach the batch sizes the throughput needs), and every window of the batch ends with the bits of the same window refined alone."""
+    w = h = 2048
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=22)
+    lor = (2, 0.05, 0.5)
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=1, layers=6, robust_color=lor, robust_grad=lor, robust_reg=lor)
+    fr = [c_(f) for f in frames]
+    out = {}
+    for nb in (1, 32):
+        job = sfa.Job(ctx, ps, w, h, nb)
+        for b in range(nb):
+            job.upload(b, fr)
+        job.run(); ctx.sync()
+        if nb == 32:
+            per_window = job.device_bytes() / nb
+            assert per_window <= 1.65e9, per_window
+        out[nb] = [job.download(b)[:2] for b in sorted({0, nb - 1})]
+        job.close()
+    for wx, wy in out[32]:
+        assert np.array_equal(valid(wx, w), valid(out[1][0][0], w)) and np.array_equal(valid(wy, w), valid(out[1][0][1], w))
+    assert abs(np.median(valid(out[1][0][0], w)) - 2.0) < 0.3
+
+
+@pytest.mark.parametrize("w,h,layers", [(256, 200, 4), (130, 98, 3)])
+def test_shared_solver_workspace_is_the_per_level_one(ctx, oracle, monkeypatch, w, h, layers):
+    """large frames re-shape ONE solver workspace level by level instead of keeping one per level; forced on a small size (SFA_SHARE_SOR) it must not change a bit,
+    (the memory figure of a bench window is test_bench_window_memory's)"""
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=31)
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=2, layers=layers)
+    out = []
+    for share in (False, True):
+        if share:
+            monkeypatch.setenv("SFA_SHARE_SOR", "1")
+        else:
+            monkeypatch.delenv("SFA_SHARE_SOR", raising=False)
+        wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
+        for _ in range(2):                                   # twice: the second run re-shapes a workspace that already holds another level's data
+            wx[...] = 0; wy[...] = 0
+            ctx.variational(ps, wx, wy, [c_(f) for f in frames], w, None)
+        out.append((wx.copy(), wy.copy()))
+    assert np.array_equal(valid(out[0][0], w), valid(out[1][0], w)) and np.array_equal(valid(out[0][1], w), valid(out[1][1], w))
+
+
+def test_bench_window_memory(ctx, oracle):
+    """a 1024x436 window of the bench configuration (S = 2, 5 levels) holds <= 0.32 GB of device memory (round 2: 0.43): 0.12 GB of arena, the rest
+    the five per-level solver workspaces (at this size they are not shared: re-zeroing them per level would cost 3-4 % of the step)"""
+    import bench
+    p = bench.bench_params()
+    job = sfa.Job(ctx, p, bench.W, bench.H, 8)
+    win = bench.synth_window(3)
+    for b in range(8):
+        job.upload(b, win)
+    job.run(); ctx.sync()
+    per_window = job.device_bytes() / 8
+    job.close()
+    assert per_window <= 0.32e9, per_window
+
+
 def test_config3_shape_2560x1440_cfg_terms(ctx, oracle, monkeypatch):
     """config 3 stand-in: 2560x1440, cfgs/slow_flow.cfg terms (S=3, rho 1/1, omega 0/2, modified L1), 5 levels:
     fused == materialised bit for bit at full size, and the known (2,1) px/frame translation is recovered"""
