@@ -18,6 +18,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -161,10 +162,75 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         }
     }
 
-    // ---- read the image sequence (:447-592, without OpenCV: PNG, binary PPM / PGM / PFM): decoded, demosaiced and cropped by the
-    //      io pool, one frame per task ----------------------------------------------------------------------------------------------
     std::vector<color_image_t *> seq(frames, nullptr), seq_back(frames, nullptr);
     std::vector<int> seq_maxval(frames, 255);            // 255 / 65535 per frame: the 8-bit copy EpicFlow's saliency works on divides 16-bit samples by 255 (:472-474, :578)
+    // ---- the GPUs (chosen before anything is read, so that the HIP runtime starts up -- 0.35 s for the first context of a process -- beside the decoding) ----
+    const int ndev = sfa_device_count();
+    int ngpu = ndev;
+    if (ngpu <= 0) { std::cerr << "no HIP device: slowflow_amd has no CPU fallback" << std::endl; return 4; }
+    // gpu_oversubscribe 1: `gpus` may exceed the devices of the box, GPU g then runs on device g mod devices -- the multi-GPU code path (one resident
+    // sequence, one set of workers and one statistics slot per GPU) rehearsed on fewer cards than it is written for; never a way to get speed
+    const bool oversubscribe = params.parameter<bool>("gpu_oversubscribe", "0");
+    if (params.exists("gpus")) ngpu = std::max(1, oversubscribe ? std::min(16, params.parameter<int>("gpus")) : std::min(ngpu, params.parameter<int>("gpus")));
+    const int dev0 = params.parameter<int>("gpu_device", "0");
+    if (!oversubscribe) ngpu = std::max(1, std::min(ngpu, ndev - dev0));             // devices dev0 .. ndev-1 exist; asking for more would only fail after all frames are decoded
+    if (!oversubscribe && dev0 >= ndev) { std::cerr << "gpu_device " << dev0 << " does not exist (" << ndev << " device(s))" << std::endl; return 4; }
+    auto device_of = [&](int g) { return oversubscribe ? (dev0 + g) % ndev : dev0 + g; };
+    const int n_loaded = (int)(end_f - start_f);
+    std::vector<sfa_ctx *> seq_ctx(ngpu, nullptr);
+    std::vector<sfa_sequence *> seq_dev(ngpu, nullptr);
+    std::vector<double> stat_avg(3 * ngpu, 0.0), stat_std(3 * ngpu, 0.0);
+    std::vector<string> seq_err(ngpu);
+    // The frames go to the GPUs once and are normalised there (:673; sfa_sequence = normalize() on resident frames: same kernels, same statistics as the
+    // host-plane normalize() of variational_mt.h).  Every GPU holds the loaded frames -- 133 frames of 1024x436 are 0.7 GB -- so no GPU waits for another;
+    // the statistics are those of GPU 0 (identical on all: same data, same deterministic kernels).  One thread per GPU: it creates the context while the
+    // io pool decodes, then uploads every frame the moment its decode task has finished (`ready`), and normalises when the last one is there.
+    std::mutex ready_mu;
+    std::condition_variable ready_cv;
+    std::vector<char> frame_ready(frames, 0);
+    bool ingest_abort = false, size_known = false;
+    int width = 0, height = 0;
+    const bool upload_while_decoding = !(((!params.exists("raw") || params.parameter<float>("raw_weight", "1.0") == 1.0f)) && scale != 1);   // a rescaled sequence exists only after all frames are in
+    std::vector<std::thread> up;
+    for (int g = 0; g < ngpu; g++)
+        up.emplace_back([&, g] {
+            int rc = sfa_ctx_create(device_of(g), &seq_ctx[g]);
+            {
+                std::unique_lock<std::mutex> l(ready_mu);
+                ready_cv.wait(l, [&] { return size_known || ingest_abort; });
+                if (ingest_abort) return;
+            }
+            if (rc == SFA_OK) rc = sfa_sequence_create(seq_ctx[g], width, height, n_loaded, &seq_dev[g]);
+            for (int f = 0; f < n_loaded && rc == SFA_OK; f++) {
+                {
+                    std::unique_lock<std::mutex> l(ready_mu);
+                    ready_cv.wait(l, [&] { return frame_ready[start_f + f] || ingest_abort; });
+                    if (ingest_abort) return;
+                }
+                rc = sfa_sequence_upload(seq_dev[g], f, seq[start_f + f]->c1, seq[start_f + f]->stride);
+            }
+            if (rc == SFA_OK) rc = sfa_sequence_normalize(seq_dev[g], 0, n_loaded, &stat_avg[3 * g], &stat_std[3 * g]);
+            if (rc != SFA_OK) seq_err[g] = seq_ctx[g] ? sfa_last_error(seq_ctx[g]) : sfa_last_error(nullptr);
+        });
+    auto release_sequences = [&] {
+        for (int g = 0; g < ngpu; g++) {
+            if (seq_dev[g]) sfa_sequence_destroy(seq_dev[g]);
+            if (seq_ctx[g]) sfa_ctx_destroy(seq_ctx[g]);
+        }
+    };
+    auto abort_ingest = [&] {
+        { std::lock_guard<std::mutex> l(ready_mu); ingest_abort = true; }
+        ready_cv.notify_all();
+        for (auto &t : up) t.join();
+        release_sequences();
+    };
+    auto frames_are = [&](unsigned f0, unsigned f1) {      // frames [f0, f1) are final: publish the size once, then the frames
+        { std::lock_guard<std::mutex> l(ready_mu); if (!size_known) { width = seq[f0]->width; height = seq[f0]->height; size_known = true; } for (unsigned f = f0; f < f1; f++) frame_ready[f] = 1; }
+        ready_cv.notify_all();
+    };
+
+    // ---- read the image sequence (:447-592, without OpenCV: PNG, binary PPM / PGM / PFM): decoded, demosaiced and cropped by the
+    //      io pool, one frame per task ----------------------------------------------------------------------------------------------
     std::vector<string> names(frames);
     for (unsigned f = start_f; f < end_f; f++) {
         if (!sintel) names[f] = fmt1(sequence_path + format, (int)start - ref * skip + (int)f * skip);
@@ -210,24 +276,26 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                 }
                 seq[f] = img;
                 seq_maxval[f] = maxval;
+                if (upload_while_decoding) frames_are(f, f + 1);
             });
         pool.wait_all();
     }
-    if (!load_error.empty()) { std::cerr << load_error << std::endl; return 3; }
+    if (!load_error.empty()) { std::cerr << load_error << std::endl; abort_ingest(); return 3; }
     const double decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (preprocess && scale != 1) {                                                  // blur + resize against aliasing (:550-553), on the GPU
         sfa_ctx *ingest_ctx = nullptr;
-        if (sfa_ctx_create(params.parameter<int>("gpu_device", "0"), &ingest_ctx) != SFA_OK) { std::cerr << sfa_last_error(nullptr) << std::endl; return 4; }
+        if (sfa_ctx_create(params.parameter<int>("gpu_device", "0"), &ingest_ctx) != SFA_OK) { std::cerr << sfa_last_error(nullptr) << std::endl; abort_ingest(); return 4; }
         for (unsigned f = start_f; f < end_f; f++) {
             color_image_t *small = color_image_rescale(ingest_ctx, seq[f], scale);
-            if (!small) { std::cerr << "rescaling failed: " << sfa_last_error(ingest_ctx) << std::endl; sfa_ctx_destroy(ingest_ctx); return 4; }
+            if (!small) { std::cerr << "rescaling failed: " << sfa_last_error(ingest_ctx) << std::endl; sfa_ctx_destroy(ingest_ctx); abort_ingest(); return 4; }
             color_image_delete(seq[f]);
             seq[f] = small;
         }
         sfa_ctx_destroy(ingest_ctx);
     }
+    if (!upload_while_decoding) frames_are(start_f, end_f);
     for (unsigned f = start_f; f < end_f; f++) seq_back[frames - 1 - f] = seq[f];    // :590-591
-    const int width = seq[start_f]->width, height = seq[start_f]->height;
+    if (seq[start_f]->width != width || seq[start_f]->height != height) { std::cerr << "frames of different sizes" << std::endl; abort_ingest(); return 3; }
     color_image_t *channel_weights = color_image_new(width, height);                 // :597-598 (all ones without raw weighting)
     for (size_t i = 0; i < (size_t)3 * channel_weights->stride * height; i++) channel_weights->c1[i] = 1.0f;
     if (raw) rawWeighting(channel_weights, red_loc.size() > 0 ? red_loc[0] : 0, red_loc.size() > 1 ? red_loc[1] : 0, params.parameter<float>("raw_weight", "1.0"));   // :599-600
@@ -253,7 +321,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                 for (int c = 0; c < 2; c++) {
                     const int x0 = params.center.x - params.extent.x / 2, y0 = params.center.y - params.extent.y / 2;
                     const int cw = 2 * (params.extent.x / 2), chh = 2 * (params.extent.y / 2);
-                    if (x0 < 0 || y0 < 0 || x0 + cw > g[c]->width || y0 + chh > g[c]->height) { std::cerr << "center / extent do not fit the ground truth" << std::endl; return 3; }
+                    if (x0 < 0 || y0 < 0 || x0 + cw > g[c]->width || y0 + chh > g[c]->height) { std::cerr << "center / extent do not fit the ground truth" << std::endl; abort_ingest(); return 3; }
                     image_t *part = image_new(cw, chh);
                     image_erase(part);
                     for (int y = 0; y < chh; y++) memcpy(part->data + (size_t)y * part->stride, g[c]->data + (size_t)(y0 + y) * g[c]->stride + x0, sizeof(float) * cw);
@@ -273,44 +341,9 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         }
     }
 
-    // ---- the frames go to the GPUs once and are normalised there (:673; sfa_sequence = normalize() on resident frames: same kernels, same statistics
-    //      as the host-plane normalize() of variational_mt.h).  Every GPU holds the loaded frames -- 133 frames of 1024x436 are 0.7 GB -- so no GPU
-    //      waits for another; the statistics are those of GPU 0 (identical on all: same data, same deterministic kernels). --------------------------
+    // ---- the GPU threads started above have been uploading beside the decoding; what is left of the ingest is the normalisation ------------------
     const auto t_norm = std::chrono::steady_clock::now();
-    const int ndev = sfa_device_count();
-    int ngpu = ndev;
-    if (ngpu <= 0) { std::cerr << "no HIP device: slowflow_amd has no CPU fallback" << std::endl; return 4; }
-    // gpu_oversubscribe 1: `gpus` may exceed the devices of the box, GPU g then runs on device g mod devices -- the multi-GPU code path (one resident
-    // sequence, one set of workers and one statistics slot per GPU) rehearsed on fewer cards than it is written for; never a way to get speed
-    const bool oversubscribe = params.parameter<bool>("gpu_oversubscribe", "0");
-    if (params.exists("gpus")) ngpu = std::max(1, oversubscribe ? std::min(16, params.parameter<int>("gpus")) : std::min(ngpu, params.parameter<int>("gpus")));
-    const int dev0 = params.parameter<int>("gpu_device", "0");
-    if (!oversubscribe) ngpu = std::max(1, std::min(ngpu, ndev - dev0));             // devices dev0 .. ndev-1 exist; asking for more would only fail after all frames are decoded
-    if (!oversubscribe && dev0 >= ndev) { std::cerr << "gpu_device " << dev0 << " does not exist (" << ndev << " device(s))" << std::endl; return 4; }
-    auto device_of = [&](int g) { return oversubscribe ? (dev0 + g) % ndev : dev0 + g; };
-    const int n_loaded = (int)(end_f - start_f);
-    std::vector<sfa_ctx *> seq_ctx(ngpu, nullptr);
-    std::vector<sfa_sequence *> seq_dev(ngpu, nullptr);
-    std::vector<double> stat_avg(3 * ngpu, 0.0), stat_std(3 * ngpu, 0.0);
-    std::vector<string> seq_err(ngpu);
-    {
-        std::vector<std::thread> up;
-        for (int g = 0; g < ngpu; g++)
-            up.emplace_back([&, g] {
-                int rc = sfa_ctx_create(device_of(g), &seq_ctx[g]);
-                if (rc == SFA_OK) rc = sfa_sequence_create(seq_ctx[g], width, height, n_loaded, &seq_dev[g]);
-                for (int f = 0; f < n_loaded && rc == SFA_OK; f++) rc = sfa_sequence_upload(seq_dev[g], f, seq[start_f + f]->c1, seq[start_f + f]->stride);
-                if (rc == SFA_OK) rc = sfa_sequence_normalize(seq_dev[g], 0, n_loaded, &stat_avg[3 * g], &stat_std[3 * g]);
-                if (rc != SFA_OK) seq_err[g] = sfa_last_error(seq_ctx[g]);
-            });
-        for (auto &t : up) t.join();
-    }
-    auto release_sequences = [&] {
-        for (int g = 0; g < ngpu; g++) {
-            if (seq_dev[g]) sfa_sequence_destroy(seq_dev[g]);
-            if (seq_ctx[g]) sfa_ctx_destroy(seq_ctx[g]);
-        }
-    };
+    for (auto &t : up) t.join();                                                     // the GPU threads uploaded every frame as it was decoded; here they finish normalising
     for (int g = 0; g < ngpu; g++)
         if (!seq_err[g].empty()) { std::cerr << "GPU " << device_of(g) << ": " << seq_err[g] << std::endl; release_sequences(); return 4; }
     publish_normalization(params, &stat_avg[0], &stat_std[0]);                       // the slow_flow_img_norm_* parameters (variational_mt.cpp:71-84)
