@@ -237,7 +237,9 @@ def measured_traffic(batch, kernel=None):
             if int(t["batch"]) != int(batch):
                 continue
             # a counter file taken from another kernel (shape) says nothing about this run: refuse it
-            if kernel is not None and t.get("kernel") and not (t["kernel"].split("<")[0] in kernel and t["kernel"].split("(")[0].strip() in kernel):
+            def norm(k):
+                return k.replace("void ", "").replace("sfa::", "").replace(" ", "").split("(")[0]
+            if kernel is not None and t.get("kernel") and norm(t["kernel"]) != norm(kernel):
                 continue
             valu = None
             try:

@@ -5,10 +5,10 @@
 # own run with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2; --pmc is never combined with the trace domains).
 # Afterwards, in the container:  python profiles/summarize.py <tag> <windows per launch = batch / streams>   (writes profiles/<tag>_*.{csv,json})
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 BATCH=${2:-128}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats -o bench -f csv -- python3 bench.py --batch $BATCH --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_stats.json 2> gpurun_out/${TAG}_stats.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats -o bench -f csv -- python3 bench.py --batch $BATCH --steps 5 --warmup 1 --no-cpu-baseline --no-strong > gpurun_out/${TAG}_stats.json 2> gpurun_out/${TAG}_stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_fetch.json 2> gpurun_out/${TAG}_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${TAG}_write -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_write.json 2> gpurun_out/${TAG}_write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d gpurun_out/${TAG}_sq1 -o bench -f csv -- python3 bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --path-only > gpurun_out/${TAG}_sq1.json 2> gpurun_out/${TAG}_sq1.err

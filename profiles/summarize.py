@@ -38,7 +38,7 @@ except FileNotFoundError:
 rows = list(csv.DictReader(open(find(f"{tag}_stats", "kernel_trace.csv"))))
 acc = collections.defaultdict(list)
 for r in rows:
-    if "k_sor_band" in r["Kernel_Name"] or "k_sor_solve" in r["Kernel_Name"]:
+    if "k_sor_band" in r["Kernel_Name"] or "k_sor_solve" in r["Kernel_Name"] or "k_sor_chain" in r["Kernel_Name"]:
         acc[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(os.path.join(out, f"{tag}_sor_by_level.csv"), "w") as f:
     f.write("kernel,grid_threads,dispatches,avg_us,min_us,max_us\n")
@@ -100,6 +100,15 @@ try:
     if sor_k:
         sqj["valu_busy_frac"] = sqj["kernels"][sor_k[0]]["valu_active_frac"]
         sqj["kernel"] = sor_k[0]
+    # the data-term assembly kernel: VALU instructions one pixel spends per data term = wave instructions x 64 lanes / (pixels x terms) of a launch
+    # (bench configuration: 5 levels, 2 terms, `batch` windows per launch; the mean over the launches of all levels against the mean level size)
+    asm_k = [k for k in sq if "k_assemble_images" in k and sq[k].get("SQ_INSTS_VALU")]
+    if asm_k:
+        LV = [(1024, 436), (921, 392), (828, 352), (745, 316), (670, 284)]
+        px = sum(w * h for w, h in LV) / len(LV)
+        inst = sum(sum(sq[k]["SQ_INSTS_VALU"]) for k in asm_k) / sum(len(sq[k]["SQ_INSTS_VALU"]) for k in asm_k)
+        sqj["assemble_valu_inst_per_pixel_term"] = round(inst * 64.0 / (px * batch * 2), 1)
+        sqj["assemble_note"] = "SQ_INSTS_VALU (wave instructions, mean per dispatch of both k_assemble_images instances) x 64 / (mean level pixels x %d windows x 2 terms)" % batch
     json.dump(sqj, open(os.path.join(out, f"{tag}_sq.json"), "w"), indent=1)
     print("SQ:", {k[-40:]: v for k, v in list(sqj["kernels"].items())[:4]})
 except FileNotFoundError:
