@@ -416,6 +416,7 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
     unsigned char *const ldsb = lds;
 #ifdef SFA_CHAIN_TIMING
     unsigned long long t_begin = __builtin_readcyclecounter(), t_bar = 0, t_slow = 0, n_slow = 0, t0, t1;
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every XCD
 #endif
     for (int I0 = 0; I0 < a.NI; I0 += AH) {
 #pragma unroll
@@ -466,7 +467,7 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
 #ifdef SFA_CHAIN_TIMING
     if (job == 0 && lane == 0 && (int)blockIdx.x < 64) {
         unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
-        o[0] = t_begin; o[1] = __builtin_readcyclecounter(); o[2] = t_bar; o[6] = t_slow; o[8] = n_slow;
+        o[0] = t_begin; o[1] = __builtin_readcyclecounter(); o[2] = t_bar; o[6] = t_slow; o[8] = n_slow; o[3] = rt_begin; o[4] = __builtin_amdgcn_s_memrealtime();
         o[9] = (unsigned long long)b; o[10] = (unsigned long long)g; o[11] = (unsigned long long)a.NI; o[12] = 0x10ull;
         o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }

@@ -49,3 +49,8 @@ for wg,w in sorted(ins, key=lambda t:(a[t[0],t[1],9],a[t[0],t[1],10])):
     key=(xcc,se,sh,cu); seen.setdefault(key,[]).append((int(r[9]),int(r[10])))
     print(f"  ({r[9]},{r[10]:2d}): xcc {xcc} se {se} sh {sh} cu {cu:2d} | simd {simds}")
 print("CUs holding more than one recorded workgroup:", {k:v for k,v in seen.items() if len(v)>1})
+print("timeline (s_memrealtime, 100 MHz): workgroup (band,group): start .. end in us after the first start")
+rt0=min(a[wg,w,3] for wg,w in ins)
+for wg,w in sorted(ins, key=lambda t:(a[t[0],t[1],9],a[t[0],t[1],10])):
+    r=a[wg,w]
+    print(f"  ({r[9]},{r[10]:2d}) {(r[3]-rt0)/100:8.1f} .. {(r[4]-rt0)/100:8.1f}   ({(r[4]-r[3])/100:7.1f} us, {(r[4]-r[3])/100/r[11]:.2f} us per interval)")
