@@ -44,10 +44,17 @@ def assemble_valu_per_pixel_term():
             with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
                 v = json.load(f).get("assemble_valu_inst_per_pixel_term")
             if v:
-                return float(v), "profiles/%s_sq.json" % tag
+                act = None
+                try:
+                    with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
+                        ks = json.load(f).get("kernels", {})
+                    act = max(x["valu_active_frac"] for k, x in ks.items() if "k_assemble_images" in k)
+                except (OSError, ValueError, KeyError):
+                    pass
+                return float(v), "profiles/%s_sq.json" % tag, act
         except (OSError, ValueError):
             continue
-    return None, None
+    return None, None, None
 
 
 def synth_window(seed, w=W, h=H, n=3):
@@ -250,7 +257,7 @@ def measured_traffic(batch, kernel=None):
             return t["traffic_bytes_per_launch"], "profiles/%s_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, python bench.py --path-only)" % tag, valu
         except (OSError, KeyError, ValueError):
             continue
-    return None, None, None
+    return None, None, None, None
 
 
 def one_window_latency(ctx, reps=3):
@@ -641,14 +648,18 @@ def main():
         # issue rate (256 CUs x 4 SIMDs, one wave instruction per 4 cycles).  Instructions per pixel and term from the SQ counter pass of the same
         # kernel (profiles/), duration live from HIP events around every launch of the timed region.
         if n_asm:
-            ipt, ipt_src = assemble_valu_per_pixel_term()
+            ipt, ipt_src, valu_active = assemble_valu_per_pixel_term()
             peak_issue = 256 * 4 * CLOCK_GHZ * 1e9 / 4.0
             ach = (ipt * asm_px / 64.0) / (asm_ms * 1e-3) if ipt else None
             out["roofline_assemble"] = {"kernel": "k_assemble_images<8,512,4>", "bound": "valu", "launches": n_asm, "avg_launch_ms": round(asm_ms / n_asm, 4),
                                         "pixel_terms_per_launch": round(asm_px / n_asm), "valu_instructions_per_pixel_term": ipt, "source": ipt_src,
                                         "achieved": (round(ach / 1e9, 2) if ach else None), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s",
                                         "frac": (round(ach / peak_issue, 4) if ach else None),
-                                        "share_of_step": round(asm_ms / S / (elapsed * 1e3), 4)}
+                                        # the SIMDs' own view from the same counter pass: share of their time with a VALU instruction in flight when the kernel runs
+                                        # alone (divisions, square roots and reciprocals occupy a SIMD for more than the 4 cycles the issue model charges)
+                                        "valu_active_frac_alone": valu_active,
+                                        "share_of_step": round(asm_ms / S / (elapsed * 1e3), 4),
+                                        "note": "launch durations are those inside the timed region, where the other stream's kernels share the GPU (alone: about half)"}
         if strong is not None:
             out["config4_strong"] = strong
         try:
