@@ -42,7 +42,10 @@ using std::string;
 
 static void usage() {
     printf("usage:\n    ./slow_flow [cfg] -overwrite -resume -deep_settings [settings] -threads -fr [select one specific adaptive frame rate] "
-           "-jet [select one specific high speed flow]\n\n");
+           "-jet [select one specific high speed flow]\n\n"
+           "    -deep_settings is accepted and ignored: the reference passes it to the DeepMatching binary it starts (slow_flow.cpp:180-181, :768); this build does\n"
+           "    not start DeepMatching or the MATLAB edge detector -- with deep_matching 1 it reads their outputs from <output>tmp/ (matches_<a>_<b>.dat, edges_<n>.dat).\n"
+           "    raw_demosaicing 1 (Hamilton-Adams, third-party code absent from the reference tree) is rejected; 0 (bilinear) and 2 (OpenCV's 8-bit conversion) work.\n\n");
 }
 
 static void setDefault(ParameterList &p) {        // slow_flow.cpp:64-128
