@@ -446,6 +446,7 @@ void sfa_ctx_destroy(sfa_ctx *c) {
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->rb_tmp) (void)hipFree(c->rb_tmp);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

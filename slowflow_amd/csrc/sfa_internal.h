@@ -40,6 +40,8 @@ struct sfa_ctx {
     size_t ev2_used = 0;
     double asm_pixel_terms = 0;   // pixels x data terms of the bracketed assembly launches
     char sor_kernel[160] = {0};   // the solver kernel (shape) of the last solve launched
+    void *rb_tmp = nullptr;       // labelled red-black mode: scratch (du, dv) pair the tile visits ping-pong with, grown on demand
+    size_t rb_tmp_bytes = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // default-ctx bookkeeping
     int cu_count = 256;

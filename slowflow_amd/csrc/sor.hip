@@ -807,17 +807,124 @@ __global__ void __launch_bounds__(256) k_rb_pass(float *__restrict__ du, float *
     du[o] = u + omega * (i11[o] * B1 + i12[o] * B2 - u);                                  // solver.c:115-116
     dv[o] = v + omega * (i12[o] * B1 + i22[o] * B2 - v);
 }
+// The same algorithm as the kernel north_star names: LDS tiles with stencil halos, several sweeps per tile visit.  A block owns a 64 x 16 tile and works on
+// the region around it that T sweeps can reach (halo 2 T: every colour pass consumes one ring): the (du, dv) pairs of the region sit in LDS, the seven
+// operands of every cell a thread owns (six cells of each colour) in its registers, loaded once per visit.  Colour pass p updates the cells whose four
+// neighbours are still exact (p + 1 cells away from every region edge that is not an image border), with k_rb_pass's operations in k_rb_pass's order, so a
+// halo cell gets the very bits the neighbouring block computes for it and the whole solve is bit-identical to the one-launch-per-colour form and to the CPU
+// twin.  K sweeps = ceil(K / T) launches instead of 2 K; the iterate ping-pongs between the caller's planes and a scratch pair (a visit reads its halos
+// from the previous visit's output).
+template <int T>
+__global__ void __launch_bounds__(256) k_rb_tile(const float *__restrict__ du_in, const float *__restrict__ dv_in, long es_in, int pitch_in,
+                                                 float *__restrict__ du_out, float *__restrict__ dv_out, long es_out, int pitch_out,
+                                                 const float *__restrict__ i11, const float *__restrict__ i12, const float *__restrict__ i22,
+                                                 const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ sh, const float *__restrict__ sv,
+                                                 Geo g, int nsweeps, float omega) {
+    constexpr int HAL = 2 * T, RW = 64 + 2 * HAL, RH = 16 + 2 * HAL, HALF = RW / 2, NC = HALF * RH, PER = (NC + 255) / 256;
+    __shared__ float2 xs[RH][RW + 1];
+    const int b = blockIdx.z;
+    if (!elem_active(g.active, b)) return;
+    const int tid = threadIdx.x;
+    const int x0 = (int)blockIdx.x * 64 - HAL, y0 = (int)blockIdx.y * 16 - HAL;
+    const float *dui = du_in + b * es_in, *dvi = dv_in + b * es_in;
+    for (int idx = tid; idx < RW * RH; idx += 256) {
+        const int rx = idx % RW, ry = idx / RW, gx = x0 + rx, gy = y0 + ry;
+        float2 v = make_float2(0.f, 0.f);
+        if (gx >= 0 && gx < g.w && gy >= 0 && gy < g.h) { const size_t o = (size_t)gy * pitch_in + gx; v = make_float2(dui[o], dvi[o]); }
+        xs[ry][rx] = v;
+    }
+    // the cells this thread owns, colour by colour, and their operands
+    struct Cell { float i11, i12, i22, b1, b2, hp, hl, vp, vt; };
+    Cell cell[2][PER];
+    const size_t eb = (size_t)b * g.es;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int n = j * 256 + tid, ry = n / HALF, xh = n - ry * HALF, gy = y0 + ry;
+            const int rx = 2 * xh + ((c + x0 + gy) & 1), gx = x0 + rx;
+            Cell q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (n < NC && gx >= 0 && gx < g.w && gy >= 0 && gy < g.h) {
+                const size_t o = eb + (size_t)gy * g.pitch + gx;
+                q.i11 = i11[o]; q.i12 = i12[o]; q.i22 = i22[o]; q.b1 = b1[o]; q.b2 = b2[o];
+                q.hp = sh[o]; q.hl = gx > 0 ? sh[o - 1] : 0.0f;
+                q.vp = sv[o]; q.vt = gy > 0 ? sv[o - g.pitch] : 0.0f;
+            }
+            cell[c][j] = q;
+        }
+    __syncthreads();
+    const bool open_l = x0 > 0, open_r = x0 + RW < g.w, open_t = y0 > 0, open_b = y0 + RH < g.h;      // region edges with image behind them
+    for (int p = 0; p < 2 * nsweeps; p++) {
+        const int c = p & 1;
+        const int lo_x = open_l ? p + 1 : 0, hi_x = open_r ? RW - 2 - p : RW - 1, lo_y = open_t ? p + 1 : 0, hi_y = open_b ? RH - 2 - p : RH - 1;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int n = j * 256 + tid, ry = n / HALF, xh = n - ry * HALF, gy = y0 + ry;
+            const int rx = 2 * xh + ((c + x0 + gy) & 1), gx = x0 + rx;
+            if (n >= NC || gx < 0 || gx >= g.w || gy < 0 || gy >= g.h || rx < lo_x || rx > hi_x || ry < lo_y || ry > hi_y) continue;
+            const Cell &q = c == 0 ? cell[0][j] : cell[1][j];
+            const float2 self = xs[ry][rx];
+            const float2 r = gx < g.w - 1 ? xs[ry][rx + 1] : make_float2(0.f, 0.f);
+            float s1 = q.hp * r.x, s2 = q.hp * r.y;                                                  // solver.c:108,166,221
+            if (gy > 0) { const float2 t = xs[ry - 1][rx]; s1 = s1 + q.vt * t.x; s2 = s2 + q.vt * t.y; }
+            if (gy < g.h - 1) { const float2 t = xs[ry + 1][rx]; s1 = s1 + q.vp * t.x; s2 = s2 + q.vp * t.y; }
+            s1 = s1 + q.b1;
+            s2 = s2 + q.b2;
+            float B1 = s1, B2 = s2;
+            if (gx > 0) { const float2 l = xs[ry][rx - 1]; B1 = q.hl * l.x + s1; B2 = q.hl * l.y + s2; }   // solver.c:113-114
+            xs[ry][rx] = make_float2(self.x + omega * (q.i11 * B1 + q.i12 * B2 - self.x), self.y + omega * (q.i12 * B1 + q.i22 * B2 - self.y));   // solver.c:115-116
+        }
+        __syncthreads();
+    }
+    float *duo = du_out + b * es_out, *dvo = dv_out + b * es_out;
+    for (int idx = tid; idx < 64 * 16; idx += 256) {
+        const int lx = idx & 63, ly = idx >> 6, gx = (int)blockIdx.x * 64 + lx, gy = (int)blockIdx.y * 16 + ly;
+        if (gx < g.w && gy < g.h) { const float2 v = xs[HAL + ly][HAL + lx]; const size_t o = (size_t)gy * pitch_out + gx; duo[o] = v.x; dvo[o] = v.y; }
+    }
+}
+
 int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2, const float *sh,
                const float *sv, int K, float omega) {
     if (K < 1) return SFA_OK;
     const dim3 blk(64, 4);
     hipLaunchKernelGGL(k_rb_invert, dim3((g.w + 63) / 64, (g.h + 3) / 4, g.nb), blk, 0, c->stream, a11, a12, a22, sh, sv, g);
-    const dim3 grid((g.w + 127) / 128, (g.h + 3) / 4, g.nb);
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
     if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
-    for (int k = 0; k < K; k++)
-        for (int color = 0; color < 2; color++)
-            hipLaunchKernelGGL(k_rb_pass, grid, blk, 0, c->stream, du, dv, a11, a12, a22, b1, b2, sh, sv, g, color, omega);
+    static const int mode = getenv("SFA_RB_TILE") ? atoi(getenv("SFA_RB_TILE")) : 5;      // sweeps per tile visit (3 or 5); 0: one launch per colour pass (the round-2 form)
+    if (mode == 0) {
+        const dim3 grid((g.w + 127) / 128, (g.h + 3) / 4, g.nb);
+        for (int k = 0; k < K; k++)
+            for (int color = 0; color < 2; color++)
+                hipLaunchKernelGGL(k_rb_pass, grid, blk, 0, c->stream, du, dv, a11, a12, a22, b1, b2, sh, sv, g, color, omega);
+    } else {
+        const int T = mode == 3 ? 3 : 5;
+        const long pl = (long)g.pitch * g.h;
+        const size_t need = (size_t)2 * g.nb * pl * sizeof(float);
+        if (need > c->rb_tmp_bytes) {
+            SFA_HIP(c, hipStreamSynchronize(c->stream));                                   // nobody may still be reading the old scratch
+            if (c->rb_tmp) (void)hipFree(c->rb_tmp);
+            c->rb_tmp = nullptr; c->rb_tmp_bytes = 0;
+            SFA_HIP(c, hipMalloc(&c->rb_tmp, need));
+            c->rb_tmp_bytes = need;
+        }
+        float *tu = static_cast<float *>(c->rb_tmp), *tv = tu + (size_t)g.nb * pl;
+        const dim3 grid((g.w + 63) / 64, (g.h + 15) / 16, g.nb);
+        bool in_tmp = false;                                                              // where the current iterate lives
+        for (int k = 0; k < K; k += T) {
+            const int ns = std::min(T, K - k);
+            const float *iu = in_tmp ? tu : du, *iv = in_tmp ? tv : dv;
+            float *ou = in_tmp ? du : tu, *ov = in_tmp ? dv : tv;
+            const long ei = in_tmp ? pl : g.es, eo = in_tmp ? g.es : pl;
+            if (T == 3) hipLaunchKernelGGL((k_rb_tile<3>), grid, dim3(256), 0, c->stream, iu, iv, ei, g.pitch, ou, ov, eo, g.pitch, a11, a12, a22, b1, b2, sh, sv, g, ns, omega);
+            else        hipLaunchKernelGGL((k_rb_tile<5>), grid, dim3(256), 0, c->stream, iu, iv, ei, g.pitch, ou, ov, eo, g.pitch, a11, a12, a22, b1, b2, sh, sv, g, ns, omega);
+            in_tmp = !in_tmp;
+        }
+        if (in_tmp) {                                                                     // an odd number of visits: the result comes home
+            Geo gc = g;
+            launch_copy_planes(c, gc, du, tu, 1, g.es, pl);
+            launch_copy_planes(c, gc, dv, tv, 1, g.es, pl);
+        }
+    }
     if (prof) {
         (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
         c->ev_used += 2;

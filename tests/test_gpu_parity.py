@@ -13,7 +13,8 @@ from synth import copy_sys, noise_color, noise_plane, smooth_noise_color, sor_sy
 
 pytestmark = pytest.mark.gpu
 
-G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "ref_vectors.npz"))
 TOL_UV = 1e-4          # north_star: (u,v) within 1e-4 max-abs of the CPU reference
 
 
@@ -1000,6 +1001,7 @@ def test_smoothness_full_size_exact(ctx, oracle):
 @pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (130, 98), (2, 2), (1024, 436)])
 @pytest.mark.parametrize("K", [1, 30])
 def test_red_black_solver_against_its_cpu_twin(ctx, oracle, w, h, K):
+    """the labelled mode's kernels (LDS halo tiles, 5 sweeps per tile visit) against the CPU twin, bit for bit"""
     rng = np.random.default_rng(w + h + K)
     s0 = sor_system(rng, w, h)
     s0["du"][:, :w] = rng.uniform(-.2, .2, (h, w)); s0["dv"][:, :w] = rng.uniform(-.2, .2, (h, w))
@@ -1009,6 +1011,37 @@ def test_red_black_solver_against_its_cpu_twin(ctx, oracle, w, h, K):
     ctx.sor_coupled(b["du"], b["dv"], b["a11"], b["a12"], b["a22"], b["b1"], b["b2"], b["sh"], b["sv"], w, K, 1.9, red_black=True)
     for k in ("du", "dv", "a11", "a12", "a22"):
         assert np.array_equal(valid(a[k], w), valid(b[k], w)), k
+
+
+@pytest.mark.parametrize("w,h,K", [(300, 70, 30), (131, 97, 7), (64, 16, 5), (1024, 436, 30), (65, 17, 11)])
+def test_red_black_tile_kernel_is_the_pass_kernel(ctx, oracle, w, h, K):
+    """one launch per colour pass (round 2's form, SFA_RB_TILE=0) and the tile kernel -- 3 or 5 sweeps per visit, image borders inside the halos, visits that
+    do not divide K, odd numbers of visits (the result comes home from the scratch pair) -- give the same bits.  The environment switch is read once per
+    process, so the three forms run in child processes."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import slowflow_amd as sfa
+        from synth import sor_system
+        w, h, K = %d, %d, %d
+        rng = np.random.default_rng(w + h + K)
+        s = sor_system(rng, w, h)
+        s["du"][:, :w] = rng.uniform(-.2, .2, (h, w)); s["dv"][:, :w] = rng.uniform(-.2, .2, (h, w))
+        b = {k: np.ascontiguousarray(v).copy() for k, v in s.items()}
+        ctx = sfa.Context(0)
+        ctx.sor_coupled(b["du"], b["dv"], b["a11"], b["a12"], b["a22"], b["b1"], b["b2"], b["sh"], b["sv"], w, K, 1.9, red_black=True)
+        np.save(sys.argv[1], np.stack([b["du"][:, :w], b["dv"][:, :w]]))
+    """) % (ROOT, os.path.join(ROOT, "tests"), w, h, K)
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("0", "3", "5"):
+            f = os.path.join(d, "rb_%s.npy" % mode)
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, SFA_RB_TILE=mode), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr
+            outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 def test_red_black_mode_is_labelled_and_deviates(ctx, oracle):
