@@ -257,7 +257,7 @@ def measured_traffic(batch, kernel=None):
             return t["traffic_bytes_per_launch"], "profiles/%s_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, python bench.py --path-only)" % tag, valu
         except (OSError, KeyError, ValueError):
             continue
-    return None, None, None, None
+    return None, None, None
 
 
 def one_window_latency(ctx, reps=3):

@@ -91,7 +91,7 @@ struct Level {
     float *warp(int s, int sp1) const { return base + off_warp + ((long)s * 2 + sp1) * 3 * pl; }
     float *frame(int f) const { return pbase + 2 * pl + (long)f * 3 * pl; }
     float *tmp() const { return base + off_tmp; }
-    Geo geo(unsigned long long active = ~0ull) const { return Geo{w, h, pitch, pl, es, nb, active}; }
+    Geo geo(unsigned long long active = ~0ull) const { return Geo{w, h, pitch, pl, es, nb, active, nullptr}; }
     static long persistent_floats(int pitch, int h, int ref) { return (long)pitch * h * (2 + (2L * ref + 1) * 3); }
     static long transient_floats(int pitch, int h, int ref, bool fused) {
         return (long)pitch * h * ((P_COUNT - 2) + 2 * ref + 2L * ref * 6 + (fused ? 0 : 2L * ref * 2 * 24));
@@ -112,8 +112,7 @@ struct ChannelWeights { const float *dev = nullptr; long pl = 0, es = 0; int pit
 static const float *pair_image(const Level &L, int s, int sp1) { return (s + sp1 - L.ref == 0) ? L.frame(s + sp1) : L.warp(s, sp1); }
 
 // get_derivatives (variational_mt.cpp:87-166).  Fused form: only the warps; the filters run inside the assembly kernel.
-static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, unsigned long long active, const bool need_toref[2 * SFA_MAX_REF]) {
-    const Geo g = L.geo(active);
+static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, const Geo &g, const bool need_toref[2 * SFA_MAX_REF]) {
     const int ref = L.ref;
     WarpJobs J;
     J.n = 0;
@@ -219,24 +218,39 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
 
     const bool use_thres_in = p.thres_inner > 0, use_thres_out = p.thres_outer > 0;
     double *red = c->d_red;
-    std::vector<double> last(2 * L.nb, 0.0);
     const double npx = (double)L.h * L.w;
+    // The outer break (:431-436) is taken ON THE DEVICE: k_outer_threshold clears a window's bit in *d_amask when its norms meet the threshold, and every
+    // kernel (the solver included) leaves the windows without a bit alone.  The host never waits for the iteration it has just queued: it reads the mask
+    // of kLag iterations ago (a superset -- windows only ever leave) to stop queueing once nothing iterates any more, so the GPU always has work queued
+    // and at most kLag iterations of empty launches follow the last window's break.  One blocking read per level (the norms), not one per iteration.
+    constexpr int kLag = 2, kRing = 4;
+    static const bool dbg = getenv("SFA_DEBUG_ACTIVE") != nullptr;
+    g.amask = c->d_amask;
+    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double), c->stream));
+    launch_set_mask(c, all);
 
     for (int alter = 0; alter < p.niter_alter; alter++) {
         active = all;
         g.active = active;
-        get_derivatives(c, L, p, active, need_toref);                                                       // :266
+        if (use_thres_out && alter > 0) launch_set_mask(c, all);
+        get_derivatives(c, L, p, g, need_toref);                                                            // :266
         if (alter > 0 && p.occlusion_reasoning && !p.one_direction) SFA_TRY(optimize_occlusions(c, L, p, g, cut_scratch));   // :269-272
         if (alter > 0 && p.occlusion_reasoning && occ_log)                                                  // :275-285
             launch_copy_planes(c, g, occ_log + (long)alter * L.pl, L.plane(P_OCC), 1, (long)p.niter_alter * L.pl, L.es);
         for (int outer = 0; outer < p.niter_outer; outer++) {
+            if (use_thres_out && outer >= kLag) {
+                const int slot = (outer - kLag) % kRing;
+                SFA_HIP(c, hipEventSynchronize(c->ev_mask[slot]));
+                active = *(volatile unsigned long long *)&c->h_amask[slot];
+                if (!active) break;                                                                      // :436, every window
+            }
+            if (dbg) fprintf(stderr, "level %dx%d alter %d outer %d known active %d\n", L.w, L.h, alter, outer, __builtin_popcountll(active));
             g.active = active;
-            if (outer > 0) get_derivatives(c, L, p, active, need_toref);                                    // :289-290
+            if (outer > 0) get_derivatives(c, L, p, g, need_toref);                                         // :289-290
             if (!L.fused) launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);   // :293-320
             // in the direct form the first inner iteration never touches du / dv / old du / old dv: they are zeros by construction.
-            // Windows that already met a threshold stay in the lockstep launches as passengers: every kernel but the solver skips them
-            // (Geo::active), the solver re-solves their stale operands into its own x plane, which nobody reads -- cheaper than leaving
-            // the batched path for single solves (one window costs 0.87 ms alone, a batch of 32 costs 1.5 ms).
+            // Windows that already met a threshold stay in the lockstep launches as passengers: every kernel skips them (Geo::active and
+            // Geo::amask; the solver's workgroups of a passenger return as soon as they have drawn their ticket).
             const bool red_black = p.sor_order == 1;           // labelled mode: works on the row-major planes, never on the diagonal-major operands
             const bool direct_outer = L.fused && !red_black && !getenv("SFA_NO_DIRECT_OPERANDS");
             if (!direct_outer) launch_zero_planes(c, g, L.plane(P_DU), 2);                                   // :323-324 (du, dv adjacent)
@@ -267,20 +281,9 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 } else if (red_black) {
                     SFA_TRY(sor_rb_run(c, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2),
                                        L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega));
-                } else if (in_active == all) {
+                } else {
                     SFA_TRY(sor_run(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1),
                                     L.plane(P_B2), L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega, false));   // :368
-                } else {
-                    // some elements already broke out of the inner loop: solve the remaining ones one by one
-                    for (int b = 0; b < L.nb; b++)
-                        if ((in_active >> b) & 1) {
-                            Geo g1 = gi;
-                            g1.nb = 1; g1.active = 1;
-                            const long eb = b * L.es;
-                            SFA_TRY(sor_run(c, sorws, g1, L.plane(P_DU) + eb, L.plane(P_DV) + eb, L.plane(P_A11) + eb, L.plane(P_A12) + eb,
-                                            L.plane(P_A22) + eb, L.plane(P_B1) + eb, L.plane(P_B2) + eb, L.plane(P_SH) + eb, L.plane(P_SV) + eb,
-                                            p.niter_solver, p.sor_omega, false));
-                        }
                 }
                 if (direct && inner + 1 == p.niter_inner) {
                     // last inner iteration: nothing reads its inner norms or du/dv; the flow update and the outer update run as one pass
@@ -312,21 +315,20 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 launch_update_outer(c, go, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);                      // :412-429
             }
             const bool last_iter = (alter == p.niter_alter - 1 && outer == p.niter_outer - 1);
-            if (use_thres_out || last_iter) {
-                SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-                SFA_HIP(c, hipStreamSynchronize(c->stream));
-                for (int b = 0; b < L.nb; b++)
-                    if ((active >> b) & 1) {
-                        last[2 * b] = c->h_red[2 * b] / npx;
-                        last[2 * b + 1] = c->h_red[2 * b + 1] / npx;
-                        if (use_thres_out && std::max((float)last[2 * b], (float)last[2 * b + 1]) < p.thres_outer) active &= ~(1ull << b);   // :436
-                    }
-                if (!active) break;
+            if (use_thres_out || last_iter) launch_outer_threshold(c, g, red, use_thres_out ? p.thres_outer : 0.0f);   // :431-436
+            if (use_thres_out) {
+                const int slot = outer % kRing;
+                SFA_HIP(c, hipMemcpyAsync(&c->h_amask[slot], c->d_amask, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+                SFA_HIP(c, hipEventRecord(c->ev_mask[slot], c->stream));
             }
         }
     }
+    // the norms of every window's last outer iteration
+    SFA_HIP(c, hipMemcpyAsync(c->h_red, c->d_last, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SFA_HIP(c, hipStreamSynchronize(c->stream));
+    (void)npx;
     if (change)
-        for (int i = 0; i < 2 * L.nb; i++) change[i] = (float)last[i];
+        for (int i = 0; i < 2 * L.nb; i++) change[i] = (float)c->h_red[i];
     return SFA_OK;
 }
 
@@ -425,6 +427,10 @@ int sfa_ctx_create(int device, sfa_ctx **out) {
     SFA_HIP(c.get(), hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_red, kRedDoubles * sizeof(double)));
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, 2 * kMaxBatch * sizeof(double) + 64, hipHostMallocDefault));
+    SFA_HIP(c.get(), hipMalloc((void **)&c->d_amask, 64));
+    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double)));
+    SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    for (auto &e : c->ev_mask) SFA_HIP(c.get(), hipEventCreateWithFlags(&e, hipEventDisableTiming));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_err, 64));
     SFA_HIP(c.get(), hipMemset(c->d_err, 0, 64));
     SFA_HIP(c.get(), hipEventCreate(&c->t0));
@@ -446,6 +452,10 @@ void sfa_ctx_destroy(sfa_ctx *c) {
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_amask) (void)hipFree(c->d_amask);
+    if (c->d_last) (void)hipFree(c->d_last);
+    if (c->h_amask) (void)hipHostFree(c->h_amask);
+    for (auto e : c->ev_mask) if (e) (void)hipEventDestroy(e);
     if (c->rb_tmp) (void)hipFree(c->rb_tmp);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -559,7 +569,7 @@ struct Staging {
         SFA_HIP(c, hipMemsetAsync(mem.p, 0, (size_t)nplanes * pl * sizeof(float), c->stream));
         return SFA_OK;
     }
-    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, 1ull}; }
+    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, 1ull, nullptr}; }
     int up(int i, const float *host, int stride, int n = 1) {
         for (int k = 0; k < n; k++) SFA_TRY(upload_plane(c, plane(i + k), pitch, host + (size_t)k * stride * h, stride, w, h));
         return SFA_OK;
@@ -788,7 +798,7 @@ int sfa_sor_batch_run(sfa_sor_batch *sb, int iterations, float omega) {
     sfa_ctx *ctx = sb ? sb->ctx : nullptr;
     CHECK_ARGS(sb, "null batch");
     SFA_HIP(ctx, hipSetDevice(ctx->device));
-    Geo g{sb->w, sb->h, sb->pitch, sb->pl, sb->es, sb->nb, sb->nb >= 64 ? ~0ull : ((1ull << sb->nb) - 1)};
+    Geo g{sb->w, sb->h, sb->pitch, sb->pl, sb->es, sb->nb, sb->nb >= 64 ? ~0ull : ((1ull << sb->nb) - 1), nullptr};
     return sor_run(ctx, sb->ws, g, sb->plane(0, 0), sb->plane(0, 1), sb->plane(0, 2), sb->plane(0, 3), sb->plane(0, 4), sb->plane(0, 5), sb->plane(0, 6),
                    sb->plane(0, 7), sb->plane(0, 8), iterations, omega, true);
 }
@@ -918,7 +928,7 @@ struct sfa_sequence {
     DevMem mem;                        // n x 3 planes at the device pitch
     DevMem sums;                       // n x 6 doubles: per frame and channel sum(I), sum(I*I)
     float *frame(int f) const { return mem.f() + (long)f * 3 * pl; }
-    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, 1ull}; }
+    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, 1ull, nullptr}; }
 };
 
 int sfa_sequence_create(sfa_ctx *ctx, int w, int h, int n_frames, sfa_sequence **out) {

@@ -55,7 +55,7 @@ __device__ __forceinline__ float psi_scalar(const PenaltyDev &p, float xsq) {
 __global__ void k_warp(float *__restrict__ dst3, float *__restrict__ mask, const float *__restrict__ src3, const float *__restrict__ wx,
                        const float *__restrict__ wy, Geo g, int factor, long src_es) {
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     dst3 += b * g.es; wx += b * g.es; wy += b * g.es; src3 += b * src_es;
@@ -81,7 +81,7 @@ __global__ void k_warp(float *__restrict__ dst3, float *__restrict__ mask, const
 // all warps of one get_derivatives call in a single launch (grid z = window x job)
 __global__ void k_warp_jobs(WarpJobs J, float *__restrict__ base, const float *__restrict__ wx, const float *__restrict__ wy, Geo g) {
     const int b = blockIdx.z / J.n, j0 = blockIdx.z % J.n;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     const long eb = b * g.es;
@@ -137,7 +137,7 @@ struct TileAcc {
 __global__ void __launch_bounds__(256) k_deriv_stack(float *__restrict__ out24, const float *__restrict__ I1, const float *__restrict__ I2, Geo g, long es1, long es2) {
     __shared__ float sM[DT_R * DT_W], sZ[DT_R * DT_W], sX[DT_R * DT_W], sY[DT_R * DT_W];
     const int b = blockIdx.z / 3, ch = blockIdx.z % 3;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x0 = blockIdx.x * DT_X - DT_H, y0 = blockIdx.y * DT_Y - DT_H;
     const float *a = I1 + b * es1 + ch * g.pl, *bb = I2 + b * es2 + ch * g.pl;
     for (int i = threadIdx.x; i < DT_R * DT_W; i += 256) {
@@ -250,7 +250,7 @@ struct LumAcc {
 __global__ void k_dpsis(float *__restrict__ dst, const float *__restrict__ im3, Geo g, long im_es, float coef, float a1, float a2, float a3,
                         float s1, float s2, float s3, int hbit) {
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     const float *im = im3 + b * im_es;
@@ -269,7 +269,7 @@ void launch_dpsis(sfa_ctx *c, const Geo &g, float *dst, const float *im3, long i
 __global__ void k_smoothness(int method, float *__restrict__ sh, float *__restrict__ sv, const float *__restrict__ uu_, const float *__restrict__ vv_,
                              const float *__restrict__ dps_, Geo g, float alpha, PenaltyDev reg) {
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.pitch || y >= g.h) return;
     const size_t o = (size_t)y * g.pitch + x;
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) k_smoothness_tiled(int method, float *__r
                                                           const float *__restrict__ vv_, const float *__restrict__ dps_, Geo g, float alpha, PenaltyDev reg) {
     __shared__ float tU[SM_R * SM_W], tV[SM_R * SM_W], tD[SM_R * SM_W];
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x0 = blockIdx.x * SM_X - 1, y0 = blockIdx.y * SM_Y - 1;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const float *pu = uu_ + b * g.es, *pv = vv_ + b * g.es, *pd = dps_ + b * g.es;
@@ -530,7 +530,7 @@ void launch_data_2f(sfa_ctx *c, const Geo &g, const float *D, const float *mask,
 // ---------------------------------------------------------------------------------------------------
 __global__ void k_mask_weight(float *__restrict__ masks, const float *__restrict__ occ, Geo g, float data_norm, int ref, int one_direction) {
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     const size_t o = (size_t)y * g.pitch + x;
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(BX *BY) k_assemble(AssembleArgs a, const float
                                                       const float *__restrict__ dv, const float *__restrict__ uu, const float *__restrict__ vv,
                                                       const float *__restrict__ sh, const float *__restrict__ sv, Geo g) {
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     const size_t o = (size_t)y * g.pitch + x;
@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         for (int i = threadIdx.x; i < a.op.ntasks; i += NT) a.op.flags[(size_t)b * a.op.ntasks + i] = 0;
         if (b == 0 && threadIdx.x == 0) a.op.flags[(size_t)a.op.nb * a.op.ntasks] = 0;
     }
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x0 = blockIdx.x * DT_X - DT_H, y0 = blockIdx.y * TY - DT_H;       // origin of the halo-4 tile
     const long eb = b * g.es;
     const int tx = threadIdx.x & 63;
@@ -1213,7 +1213,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner(float *__restrict__ uu,
     const int b = blockIdx.z;
     const int x = blockIdx.x * BX + threadIdx.x;
     double sa = 0, sb = 0;
-    if (elem_active(g.active, b) && x < g.w)
+    if (elem_active(g, b) && x < g.w)
         for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
             const size_t o = b * g.es + (size_t)y * g.pitch + x;
             const float d = du[o], e = dv[o];
@@ -1236,7 +1236,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ u
     const int b = blockIdx.z;
     const int x = blockIdx.x * BX + threadIdx.x;
     double sa = 0, sb = 0;
-    if (elem_active(g.active, b) && x < g.w)
+    if (elem_active(g, b) && x < g.w)
         for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
             const size_t o = b * g.es + (size_t)y * g.pitch + x;
             const unsigned long long xv = xs[(size_t)b * ent + (size_t)(x + y + G) * RP + (y + G)];
@@ -1265,7 +1265,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ u
     const int tid = threadIdx.y * BX + threadIdx.x;
     const int c0 = blockIdx.x * 64;
     double sa = 0, sb = 0;
-    if (elem_active(g.active, b))
+    if (elem_active(g, b))
         for (int r0 = blockIdx.y * 16; r0 < g.h; r0 += gridDim.y * 16) {
             __syncthreads();
             for (int item = tid; item < (64 + 16 - 1) * 16; item += BX * BY) {
@@ -1303,7 +1303,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx,
     const int b = blockIdx.z;
     const int x = blockIdx.x * BX + threadIdx.x;
     double sa = 0, sb = 0;
-    if (elem_active(g.active, b) && x < g.w)
+    if (elem_active(g, b) && x < g.w)
         for (int y = blockIdx.y * BY + threadIdx.y; y < g.h; y += gridDim.y * BY) {
             const size_t o = b * g.es + (size_t)y * g.pitch + x;
             const float u = uu[o], v = vv[o];
@@ -1319,9 +1319,10 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx,
     }
 }
 // one block per batch element sums that element's partials in a fixed order
-__global__ void k_reduce_partials(const double *__restrict__ partial, int per_elem, double *__restrict__ out, unsigned long long active) {
+__global__ void k_reduce_partials(const double *__restrict__ partial, int per_elem, double *__restrict__ out, unsigned long long active,
+                                  const unsigned long long *__restrict__ amask) {
     const int b = blockIdx.x;
-    if (!elem_active(active, b)) return;                              // the result words of passengers keep their last values
+    if (!elem_active(active_mask(active, amask), b)) return;                              // the result words of passengers keep their last values
     double sa = 0, sb = 0;
     for (int i = threadIdx.x; i < per_elem; i += 256) { sa += partial[2 * ((size_t)b * per_elem + i)]; sb += partial[2 * ((size_t)b * per_elem + i) + 1]; }
     __shared__ double s0[256], s1[256];
@@ -1334,6 +1335,27 @@ __global__ void k_reduce_partials(const double *__restrict__ partial, int per_el
     if (threadIdx.x == 0) { out[2 * b] = s0[0]; out[2 * b + 1] = s1[0]; }
 }
 
+// The outer break on the device (variational_mt.cpp:431-436): the norms of the windows that ran this outer iteration, and the windows that go on.
+// One wave; lane b = window b.  `last` keeps every window's norms of ITS last iteration (what the caller gets back as the change).
+__global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict__ red, double *__restrict__ last, unsigned long long *__restrict__ amask,
+                                                        unsigned long long active, int nb, double npx, float thres) {
+    const int b = threadIdx.x;
+    const unsigned long long cur = *amask & active;
+    bool met = false;
+    if (b < nb && ((cur >> b) & 1ull)) {
+        const double a = red[2 * b] / npx, d = red[2 * b + 1] / npx;
+        last[2 * b] = a; last[2 * b + 1] = d;
+        met = thres > 0.0f && fmaxf((float)a, (float)d) < thres;                         // :436
+    }
+    const unsigned long long m = __ballot(met);
+    if (b == 0) *amask = *amask & ~m;
+}
+__global__ void k_set_mask(unsigned long long *amask, unsigned long long v) { *amask = v; }
+void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres) {
+    hipLaunchKernelGGL(k_outer_threshold, dim3(1), dim3(64), 0, c->stream, red, c->d_last, c->d_amask, g.active, g.nb, (double)g.h * g.w, thres);
+}
+void launch_set_mask(sfa_ctx *c, unsigned long long v) { hipLaunchKernelGGL(k_set_mask, dim3(1), dim3(1), 0, c->stream, c->d_amask, v); }
+
 // partial-sum scratch lives behind the result words in ctx->d_red: [0, 2*kMaxBatch) results, then partials
 static double *partials_of(sfa_ctx *c) { return c->d_red + 2 * kMaxBatch; }
 // reduction grids: column strips of BX, at most kRedRows row-blocks that stride over the rows
@@ -1345,31 +1367,31 @@ void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const f
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_inner, grid, block2d(), 0, c->stream, uu, vv, wx, wy, du, dv, old_du, old_dv, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const SorOperandOut &x, const float *old_du,
                            const float *old_dv, float *du_out, float *dv_out, double *red) {
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_inner_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, old_du, old_dv, du_out, dv_out, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red) {
     dim3 grid((g.w + 63) / 64, std::min((g.h + 15) / 16, kRedRows), g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_outer_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red) {
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
     hipLaunchKernelGGL(k_update_outer, grid, block2d(), 0, c->stream, wx, wy, uu, vv, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 
 __global__ void k_copy_planes(float *__restrict__ dst, const float *__restrict__ src, Geo g, int nplanes, long dst_es, long src_es) {
     const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     const size_t o = pl * g.pl + (size_t)y * g.pitch + x;
@@ -1382,7 +1404,7 @@ void launch_copy_planes(sfa_ctx *c, const Geo &g, float *dst, const float *src, 
 // image_erase / fill_n on whole planes (padding lanes included) of every active element
 __global__ void k_fill_planes(float *__restrict__ p, Geo g, int nplanes, float v) {
     const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.pitch || y >= g.h) return;
     p[b * g.es + pl * g.pl + (size_t)y * g.pitch + x] = v;
@@ -1736,7 +1758,7 @@ __global__ void __launch_bounds__(BX *BY) k_norm_sums(const float *__restrict__ 
 void launch_normalize_sums(sfa_ctx *c, const Geo &g, const float *frames3, double *red) {
     dim3 grid = red_grid(g, 3);
     hipLaunchKernelGGL(k_norm_sums, grid, block2d(), 0, c->stream, frames3, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, c->stream, partials_of(c), (int)(grid.x * grid.y), red, 7ull);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, c->stream, partials_of(c), (int)(grid.x * grid.y), red, 7ull, (const unsigned long long *)nullptr);
 }
 __global__ void k_norm_apply(float *__restrict__ frames3, Geo g, double a0, double a1, double a2, double s0, double s1, double s2) {
     const int ch = blockIdx.z;

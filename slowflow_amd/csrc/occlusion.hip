@@ -52,7 +52,7 @@ struct OccTileAcc {
 __global__ void __launch_bounds__(OC_NT) k_occ_costs(OccArgs a, const float *__restrict__ base, float *__restrict__ d0, float *__restrict__ d1, long des, Geo g) {
     __shared__ float sZ[3][OC_R * OC_W];
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const long eb = b * g.es;
     const int x0 = blockIdx.x * OC_X - 2, y0 = blockIdx.y * OC_Y - 2;
     const int tx = threadIdx.x & 63;

@@ -14,6 +14,8 @@ static inline dim3 grid2d(const Geo &g, int zmul = 1) { return dim3((g.w + BX - 
 static inline dim3 block2d() { return dim3(BX, BY, 1); }
 
 __device__ __forceinline__ bool elem_active(unsigned long long active, int b) { return (active >> b) & 1ull; }
+__device__ __forceinline__ unsigned long long active_mask(unsigned long long active, const unsigned long long *amask) { return amask ? (active & *amask) : active; }
+__device__ __forceinline__ bool elem_active(const Geo &g, int b) { return (active_mask(g.active, g.amask) >> b) & 1ull; }
 __device__ __forceinline__ int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
 
 // derivative filter taps as convolution_new builds them (image.c:363-366, variational_mt.cpp:570-573)

@@ -30,6 +30,12 @@ struct sfa_ctx {
     // scratch for reductions / flags
     double *d_red = nullptr;      // device, kRedDoubles doubles
     double *h_red = nullptr;      // pinned host mirror
+    // thresholds on the device (variational_mt.cpp:436): the windows still iterating, the norms of each window's last iteration, and a ring of pinned
+    // copies of the mask (one per outer iteration in flight) with the events that say a copy has landed
+    unsigned long long *d_amask = nullptr;
+    double *d_last = nullptr;                      // 2 * kMaxBatch doubles
+    unsigned long long *h_amask = nullptr;         // kMaskRing pinned words
+    hipEvent_t ev_mask[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned *d_err = nullptr;    // device error/timeout word
     // profiling of the SOR solve kernel
     bool profile = false;
@@ -93,7 +99,9 @@ int download_plane(sfa_ctx *ctx, float *host, int stride, const float *dev, int 
 // `es` floats further (es = 0 for a single element).  `nb` = batch size, `active` = bit mask of the
 // elements that still iterate (threshold breaks).
 // ---------------------------------------------------------------------------------------------------
-struct Geo { int w, h, pitch; long pl; long es; int nb; unsigned long long active; };   // pl = pitch*h
+// pl = pitch*h.  A window b takes part in a launch when bit b is set in `active` (what the host knows) AND in *amask (what the device knows: the windows
+// that have not met the outer threshold yet, sfa_ctx::d_amask; null = no device-side mask)
+struct Geo { int w, h, pitch; long pl; long es; int nb; unsigned long long active; const unsigned long long *amask; };
 
 struct PenaltyDev { int id; float eps, trunc; };
 
@@ -113,6 +121,8 @@ void launch_mask_weight(sfa_ctx *c, const Geo &g, float *masks, const float *occ
 void launch_fill(sfa_ctx *c, float *p, size_t n, float v);
 void launch_fill_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes, float v);
 void launch_zero_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes);
+void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres);   // updates *c->d_amask and c->d_last
+void launch_set_mask(sfa_ctx *c, unsigned long long v);
 
 // Where a kernel other than k_sor_prepare leaves the solver's operands (diagonal-major planes of a SorWorkspace)
 struct SorOperandOut {

@@ -55,6 +55,7 @@ struct SorArgs {
     int W, H, K, NB, NG, RP, G, NS, NCH, ntasks, nb;
     int nwords;                     // progress words per window (padded)
     float omega;
+    unsigned long long active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' tasks return at once
 };
 
 
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(64) k_sor_solve(SorArgs a) {
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= (unsigned)(a.nb * a.ntasks)) return;
     const int job = t % a.nb, idx = t / a.nb;
+    if (!elem_active(active_mask(a.active, a.amask), job)) return;        // a passenger: none of its tasks runs, so none of them waits
     const int2 bg = a.order[idx];
     const int b = __builtin_amdgcn_readfirstlane(bg.x), g = __builtin_amdgcn_readfirstlane(bg.y);
     const int k0 = g * F;
@@ -266,6 +268,7 @@ struct BandArgs {
     int W, H, K, NB, NW, RP, G, NS, NCH, nb, Wp, EP;
     int lead;                      // steps a stage may run ahead of the next one (<= ring slots)
     float omega;
+    unsigned long long active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' bands return at once
 };
 
 // What a band hands to the band below -- lane 63's iterates and the progress word -- leaves as write-through (sc1) stores.  sor_chain.hip found that ONE
@@ -622,6 +625,7 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;                     // band-major tickets
+    if (!elem_active(active_mask(a.active, a.amask), job)) return;
     if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
     else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
     else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
@@ -651,6 +655,7 @@ __global__ void __launch_bounds__((NA + NB_) * 64) k_sor_band_mixed(BandArgs a) 
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;
+    if (!elem_active(active_mask(a.active, a.amask), job)) return;
     unsigned char *win = wave < NA ? win0 + (size_t)wave * WINA : win0 + (size_t)NA * WINA + (size_t)(wave - NA) * WINB_;
     unsigned long long(*est)[MC] = est0 + (size_t)wave * FA;
     unsigned long long *tvb = tvb0 + (size_t)wave * TVB;
@@ -673,6 +678,7 @@ struct PrepArgs {
     float *a11, *a12, *a22;
     long ent, es;
     int W, H, RP, ND, G, pitch, ntasks, nb, inv_out;
+    unsigned long long active; const unsigned long long *amask;
 };
 // One block = a 64-column x 16-row tile: row-major reads coalesced along the columns, the 10 operand floats staged in
 // LDS, then written along the tile's anti-diagonals: 16 consecutive entries (256 B of SA/SB) per diagonal.  Only valid
@@ -689,6 +695,7 @@ __global__ void __launch_bounds__(256) k_sor_prepare(PrepArgs p) {
         for (int i = threadIdx.x; i < p.ntasks; i += 256) p.flags[(size_t)job * p.ntasks + i] = 0;
         if (job == 0 && threadIdx.x == 0) p.flags[(size_t)p.nb * p.ntasks] = 0;      // ticket
     }
+    if (!elem_active(active_mask(p.active, p.amask), job)) return;                   // passengers: progress words reset, operands left alone
 #pragma unroll
     for (int i = 0; i < PT_R / 4; i++) {
         const int rl = ty + 4 * i, r = r0 + rl, c = c0 + tx;
@@ -727,10 +734,10 @@ __global__ void __launch_bounds__(256) k_sor_prepare(PrepArgs p) {
 }
 
 __global__ void k_sor_finish(float *__restrict__ du, float *__restrict__ dv, const unsigned long long *__restrict__ x, long ent, long es, int W, int H,
-                             int RP, int G, int pitch) {
+                             int RP, int G, int pitch, unsigned long long active, const unsigned long long *__restrict__ amask) {
     const int job = blockIdx.z;
     const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y * 4 + threadIdx.y;
-    if (c >= W || r >= H) return;
+    if (c >= W || r >= H || !elem_active(active_mask(active, amask), job)) return;
     const float2 v = u2f(x[(size_t)job * ent + (size_t)(c + r + G) * RP + (r + G)]);
     const size_t o = (size_t)job * es + (size_t)r * pitch + c;
     du[o] = v.x;
@@ -739,8 +746,9 @@ __global__ void k_sor_finish(float *__restrict__ du, float *__restrict__ dv, con
 
 // tiny systems: the reference itself falls back to the readable solver (solver.c:66-69, 17-57)
 __global__ void k_sor_readable(float *du_, float *dv_, const float *a11_, const float *a12_, const float *a22_, const float *b1_, const float *b2_,
-                               const float *sh_, const float *sv_, long es, int w, int h, int stride, int iterations, float omega) {
-    if (threadIdx.x != 0) return;
+                               const float *sh_, const float *sv_, long es, int w, int h, int stride, int iterations, float omega,
+                               unsigned long long active, const unsigned long long *amask) {
+    if (threadIdx.x != 0 || !elem_active(active_mask(active, amask), blockIdx.x)) return;
     const long eb = (long)blockIdx.x * es;
     float *du = du_ + eb, *dv = dv_ + eb;
     const float *a11 = a11_ + eb, *a12 = a12_ + eb, *a22 = a22_ + eb, *b1 = b1_ + eb, *b2 = b2_ + eb, *sh = sh_ + eb, *sv = sv_ + eb;
@@ -772,7 +780,7 @@ __global__ void k_sor_readable(float *du_, float *dv_, const float *a11_, const 
 __global__ void __launch_bounds__(256) k_rb_invert(float *__restrict__ a11, float *__restrict__ a12, float *__restrict__ a22, const float *__restrict__ sh,
                                                    const float *__restrict__ sv, Geo g) {
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     const size_t o = b * g.es + (size_t)y * g.pitch + x;
@@ -789,7 +797,7 @@ __global__ void __launch_bounds__(256) k_rb_pass(float *__restrict__ du, float *
                                                  const float *__restrict__ i22, const float *__restrict__ b1, const float *__restrict__ b2,
                                                  const float *__restrict__ sh, const float *__restrict__ sv, Geo g, int color, float omega) {
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int y = blockIdx.y * 4 + threadIdx.y;
     const int x = 2 * (blockIdx.x * 64 + threadIdx.x) + ((y + color) & 1);
     if (x >= g.w || y >= g.h) return;
@@ -823,7 +831,7 @@ __global__ void __launch_bounds__(256) k_rb_tile(const float *__restrict__ du_in
     constexpr int HAL = 2 * T, RW = 64 + 2 * HAL, RH = 16 + 2 * HAL, HALF = RW / 2, NC = HALF * RH, PER = (NC + 255) / 256;
     __shared__ float2 xs[RH][RW + 1];
     const int b = blockIdx.z;
-    if (!elem_active(g.active, b)) return;
+    if (!elem_active(g, b)) return;
     const int tid = threadIdx.x;
     const int x0 = (int)blockIdx.x * 64 - HAL, y0 = (int)blockIdx.y * 16 - HAL;
     const float *dui = du_in + b * es_in, *dvi = dv_in + b * es_in;
@@ -1116,7 +1124,8 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
 int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, float *a11, float *a12, float *a22, const float *b1, const float *b2,
             const float *sh, const float *sv, int K, float omega, bool inv_out) {
     if (g.w < 2 || g.h < 2 || K < 1) {                                                    // solver.c:66-69
-        hipLaunchKernelGGL(k_sor_readable, dim3(g.nb), dim3(64), 0, c->stream, du, dv, a11, a12, a22, b1, b2, sh, sv, g.es, g.w, g.h, g.pitch, K, omega);
+        hipLaunchKernelGGL(k_sor_readable, dim3(g.nb), dim3(64), 0, c->stream, du, dv, a11, a12, a22, b1, b2, sh, sv, g.es, g.w, g.h, g.pitch, K, omega,
+                           g.active, g.amask);
         return SFA_OK;
     }
     SFA_TRY(ws.configure(c, g.w, g.h, K, g.nb));
@@ -1124,7 +1133,7 @@ int sor_run(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *du, float *dv, fl
     p.sa = (float4 *)ws.sa.p; p.sb = (float4 *)ws.sb.p; p.x = (unsigned long long *)ws.x.p; p.flags = (unsigned *)ws.flags.p;
     p.du = du; p.dv = dv; p.b1 = b1; p.b2 = b2; p.sh = sh; p.sv = sv; p.a11 = a11; p.a12 = a12; p.a22 = a22;
     p.ent = ws.ent; p.es = g.es; p.W = g.w; p.H = g.h; p.RP = ws.RP; p.ND = ws.ND; p.G = ws.G; p.pitch = g.pitch;
-    p.ntasks = ws.nwords; p.nb = g.nb; p.inv_out = inv_out ? 1 : 0;
+    p.ntasks = ws.nwords; p.nb = g.nb; p.inv_out = inv_out ? 1 : 0; p.active = g.active; p.amask = g.amask;
     hipLaunchKernelGGL(k_sor_prepare, dim3((g.w + PT_C - 1) / PT_C, (g.h + PT_R - 1) / PT_R, g.nb), dim3(256), 0, c->stream, p);
     return sor_launch_solve(c, ws, g, du, dv, K, omega);
 }
@@ -1139,7 +1148,7 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
     SorArgs a;
     a.sa = p.sa; a.sb = p.sb; a.x = p.x; a.flags = p.flags; a.order = (const int2 *)ws.order.p; a.err = c->d_err;
     a.ent = ws.ent; a.W = g.w; a.H = g.h; a.K = K; a.NB = ws.NB; a.NG = ws.NG; a.RP = ws.RP; a.G = ws.G; a.NS = ws.NS; a.NCH = ws.NCH;
-    a.ntasks = ws.ntasks; a.nwords = ws.nwords; a.nb = g.nb; a.omega = omega;
+    a.ntasks = ws.ntasks; a.nwords = ws.nwords; a.nb = g.nb; a.omega = omega; a.active = g.active; a.amask = g.amask;
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
     if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
     if (ws.chain) snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_chain shape %d (%d groups of stages per band)", ws.chain, ws.NG);
@@ -1154,7 +1163,7 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         ba.ent = ws.ent; ba.edge_job = ws.edge_job; ba.W = g.w; ba.H = g.h; ba.K = K; ba.NB = ws.NB; ba.NW = ws.NG; ba.RP = ws.RP; ba.G = ws.G;
         ba.lead = band_ring(ws.F);
         if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(band_ch(ws.F) + 2, std::min(atoi(e), band_ring(ws.F)));
-        ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega;
+        ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega; ba.active = g.active; ba.amask = g.amask;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
         const size_t tvb = (ws.F + 1) * band_ch(ws.F) <= 64 ? (size_t)(ws.F + 1) * band_ch(ws.F) * 8 : 0;            // lane-0 values, one chunk per wave
         const size_t lds = (size_t)(ws.NG - 1) * band_ring(ws.F) * 64 * 8 + 256 + ws.NG * band_window(ws.F) + (size_t)ws.NG * ws.F * band_mc(ws.F) * 8 + ws.NG * tvb;
@@ -1181,7 +1190,7 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
     }
     if (du)
         hipLaunchKernelGGL(k_sor_finish, dim3((g.w + 63) / 64, (g.h + 3) / 4, g.nb), dim3(64, 4), 0, c->stream, du, dv, p.x, ws.ent, g.es, g.w, g.h, ws.RP,
-                           ws.G, g.pitch);
+                           ws.G, g.pitch, g.active, g.amask);
     SFA_HIP(c, hipGetLastError());
     return SFA_OK;
 }

@@ -44,6 +44,7 @@ struct ChainArgs {
     int nch;                       // chunks per stage (even)
     int NI;                        // barrier intervals per workgroup (multiple of AH)
     float omega;
+    unsigned long long active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' workgroups return at once
 };
 
 // one progress word per workgroup, each on a 128-byte line of its own: every OUT wave updates its word once per interval (atomic) and up to
@@ -603,6 +604,7 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
     const unsigned t = __builtin_amdgcn_readfirstlane(*s_ticket);
     if (t >= (unsigned)(a.nb * a.NB * a.NG)) return;
     const int job = t % a.nb;
+    if (!elem_active(active_mask(a.active, a.amask), job)) return;        // a passenger: none of its workgroups runs, so none of them waits
     const int2 bg = a.order[t / a.nb];
     const int b = __builtin_amdgcn_readfirstlane(bg.x), g = __builtin_amdgcn_readfirstlane(bg.y);
     // first chunk of the group (even): every stage of the group starts at a local step <= -1
@@ -773,7 +775,7 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
     a.ent = ws.ent; a.edge_job = ws.edge_job; a.edge_bytes = (unsigned long long)g.nb * ws.edge_job * 8ull;
     a.flag_bytes = ((unsigned long long)g.nb * ws.nwords + 16) * 4ull;
     a.W = g.w; a.H = g.h; a.K = K; a.NB = ws.NB; a.NG = ws.NG; a.RP = ws.RP; a.G = ws.G; a.nb = g.nb; a.Wp = ws.Wp; a.EP = ws.EP;
-    a.nch = ws.NCH; a.NI = ws.NS; a.omega = omega;
+    a.nch = ws.NCH; a.NI = ws.NS; a.omega = omega; a.active = g.active; a.amask = g.amask;
     const int nwg = g.nb * ws.NB * ws.NG;
     switch (ws.chain) {
         case 1: chain_launch_shape<1, 3, 1, 0, 4>(c, a, nwg); break;
