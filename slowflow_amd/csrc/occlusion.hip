@@ -13,6 +13,7 @@
 //      prefers label 0, so pushing from the few label-1 pixels converges in a handful of rounds).
 //      GCO v3.0 is not vendored: parity unpinned; the oracle is an exact fp64 Dinic cut and the tests compare energies.
 #include "sfa_device.h"
+#include <vector>
 
 #include <cstdlib>
 #include <utility>
@@ -211,17 +212,38 @@ __global__ void k_cut_bfs_init(CutPlanes P, Geo g) {
     const size_t o = b * g.pl + (size_t)y * g.pitch + x;
     P.hgt[o] = P.tc[o] > 0 ? 1 : kCutInf;
 }
+// the same start on the sweep's own tiling (64 x kBfsRows), which also learns which tiles have anything to relax: a tile whose nodes all sit next to the
+// terminal (distance 1, the minimum) never changes -- `fixed`, never run -- every other tile starts dirty
+constexpr int kBfsRowsDecl = 16;
+__global__ void __launch_bounds__(BX *BY) k_cut_bfs_init_tiles(CutPlanes P, int *__restrict__ dirty, int *__restrict__ fixed, Geo g) {
+    const int b = blockIdx.z, t = cut_tile(b);
+    const int x = blockIdx.x * BX + threadIdx.x;
+    bool far = false;
+#pragma unroll
+    for (int k = 0; k < kBfsRowsDecl / BY; k++) {
+        const int y = blockIdx.y * kBfsRowsDecl + threadIdx.y + BY * k;
+        if (x < g.w && y < g.h) {
+            const size_t o = b * g.pl + (size_t)y * g.pitch + x;
+            const bool near = P.tc[o] > 0;
+            P.hgt[o] = near ? 1 : kCutInf;
+            far |= !near;
+        }
+    }
+    const int any = __syncthreads_or(far);
+    if (threadIdx.x == 0 && threadIdx.y == 0) { dirty[t] = any; fixed[t] = !any; }
+}
 // One launch relaxes every tile that is dirty or has a dirty 4-neighbour tile: the tile (64 x kBfsRows pixels, 4 rows per thread) and
 // a one-pixel halo of heights go to LDS, the residual-arc masks to registers, and the block iterates to the tile's fixpoint with
 // the halo frozen (any value read there is a valid upper bound of a monotone relaxation, so the order of the tiles does not
 // matter; the global fixpoint -- no tile changes -- is the exact distance).  Distances travel a tile per launch, not a pixel.
-constexpr int kBfsRows = 16, kBfsPer = kBfsRows / BY, kBfsIters = 96;
-__global__ void __launch_bounds__(BX *BY) k_cut_bfs_sweep(CutPlanes P, CutTiles T, unsigned *__restrict__ changed, Geo g) {
+constexpr int kBfsRows = kBfsRowsDecl, kBfsPer = kBfsRows / BY, kBfsIters = 96;
+__global__ void __launch_bounds__(BX *BY) k_cut_bfs_sweep(CutPlanes P, CutTiles T, const int *__restrict__ fixed, unsigned *__restrict__ changed, Geo g) {
     __shared__ int sh[kBfsRows + 2][BX + 2];
     const int b = blockIdx.z;
     const int t = cut_tile(b);
     const bool first = threadIdx.x == 0 && threadIdx.y == 0;
-    if (!T.dirty[t] && !cut_tile_nb_any(T.dirty, t, [](int v) { return v != 0; })) {      // nothing it reads has changed since it last ran
+    // nothing it reads has changed since it last ran -- or nothing in it can change (k_cut_bfs_init_tiles: every node next to the terminal)
+    if ((fixed && fixed[t]) || (!T.dirty[t] && !cut_tile_nb_any(T.dirty, t, [](int v) { return v != 0; }))) {
         if (first) T.dirty_next[t] = 0;
         return;
     }
@@ -449,6 +471,167 @@ __global__ void __launch_bounds__(kTailThreads) k_cut_tail(CutPlanes P, CutTiles
     for (int t = tid; t < NT; t += kTailThreads) { gidle[t] = idle[t]; any |= idle[t] == 0; }
     if (__ballot(any) && (tid & 63) == 0) cut_raise(&flags[0]);
 }
+// ---------------------------------------------------------------------------------------------------
+// Tile discharge (round 3): the same synchronous push / collect-and-relabel rounds, but run INSIDE a 64 x 16 tile for as many rounds as the tile
+// stays active: the node state (excess, terminal arc, four neighbour arcs) sits in registers, heights and the flows of the round in LDS, the one-pixel
+// ring of heights around the tile is read once and stays frozen.  Flow that leaves the tile is summed per border node and direction and handed to
+// the neighbour tile at the end (its excess and its reverse arc).  Tiles run in four colours (2 x 2 pattern), one colour per launch: no two tiles of a
+// launch touch (not even at a corner), so the ring a tile reads is what its neighbours last wrote, a border node is written by one block only, and
+// every step is an ordinary push or relabel of a sequential execution -- labels stay valid (h(p) <= h(q) + 1 on residual arcs) and the result is a
+// maximum preflow like before; the labelling (k_cut_labels: who still reaches the passive terminal) does not depend on which maximum flow was found.
+// One launch moves excess across a whole tile where a grid round moved it one pixel.
+// act[t] (64 x 16 tiles, the breadth-first sweep's tiling): the tile holds an active node, or has been handed flow since it last ran.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kDisRows = kBfsRows, kDisPer = kDisRows / BY;
+__global__ void __launch_bounds__(BX *BY) k_cut_discharge(CutPlanes P, int *__restrict__ act, unsigned *__restrict__ flags, Geo g, int hmax, int colour,
+                                                          int tiles_x, int tiles_y, int max_rounds) {
+    __shared__ int sh[2][kDisRows + 2][BX + 2];
+    __shared__ float sf[4][kDisRows][BX];
+    const int b = blockIdx.z;
+    const int bx = 2 * (int)blockIdx.x + (colour & 1), by = 2 * (int)blockIdx.y + (colour >> 1);
+    if (bx >= tiles_x || by >= tiles_y) return;
+    const int t = (b * tiles_y + by) * tiles_x + bx;
+    if (!act[t]) return;
+    const bool first = threadIdx.x == 0 && threadIdx.y == 0;
+    const int x0 = bx * BX, y0 = by * kDisRows, tid = threadIdx.y * BX + threadIdx.x;
+    const size_t wb = (size_t)b * g.pl;
+    for (int i = tid; i < (kDisRows + 2) * (BX + 2); i += BX * BY) {                          // tile + ring (outside the image: unreachable, and no arc leads there)
+        const int ly = i / (BX + 2), lx = i % (BX + 2), x = x0 + lx - 1, y = y0 + ly - 1;
+        const int v = (x >= 0 && x < g.w && y >= 0 && y < g.h) ? P.hgt[wb + (size_t)y * g.pitch + x] : kCutInf;
+        sh[0][ly][lx] = v; sh[1][ly][lx] = v;
+    }
+    const int x = x0 + threadIdx.x, lx = threadIdx.x + 1;
+    float e[kDisPer], tc[kDisPer], c[kDisPer][4], out[kDisPer][4];
+    bool in[kDisPer];
+#pragma unroll
+    for (int k = 0; k < kDisPer; k++) {
+        const int y = y0 + threadIdx.y + BY * k;
+        in[k] = x < g.w && y < g.h;
+        e[k] = 0.0f; tc[k] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 4; d++) { c[k][d] = 0.0f; out[k][d] = 0.0f; }
+        if (in[k]) {
+            const size_t o = wb + (size_t)y * g.pitch + x;
+            e[k] = P.e[o]; tc[k] = P.tc[o];
+#pragma unroll
+            for (int d = 0; d < 4; d++) c[k][d] = P.c[d][o];                                    // 0 towards the outside of the image (k_cut_init)
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    bool still = true;
+    for (int r = 0; r < max_rounds && still; r++) {
+        // push: decisions from the heights of the previous round only
+#pragma unroll
+        for (int k = 0; k < kDisPer; k++) {
+            const int ly = threadIdx.y + BY * k + 1;
+            float f[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const int hp = sh[cur][ly][lx];
+            if (e[k] > 0 && hp < hmax) {
+                if (tc[k] > 0) { const float dlt = fminf(e[k], tc[k]); e[k] -= dlt; tc[k] -= dlt; }
+                const int hn[4] = {sh[cur][ly][lx + 1], sh[cur][ly][lx - 1], sh[cur][ly + 1][lx], sh[cur][ly - 1][lx]};
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+                    if (e[k] > 0 && c[k][d] > 0 && hn[d] == hp - 1) {
+                        const float dlt = fminf(e[k], c[k][d]);
+                        e[k] -= dlt; c[k][d] -= dlt; f[d] = dlt;
+                    }
+            }
+#pragma unroll
+            for (int d = 0; d < 4; d++) sf[d][ly - 1][threadIdx.x] = f[d];
+            // what leaves the tile waits in registers
+            if (threadIdx.x == BX - 1) out[k][0] += f[0];
+            if (threadIdx.x == 0) out[k][1] += f[1];
+            if (ly == kDisRows) out[k][2] += f[2];
+            if (ly == 1) out[k][3] += f[3];
+        }
+        __syncthreads();
+        // collect what the neighbours inside the tile sent, then relabel an active node that has no admissible arc left
+        bool a = false;
+#pragma unroll
+        for (int k = 0; k < kDisPer; k++) {
+            const int ly = threadIdx.y + BY * k + 1, row = ly - 1;
+            float inc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (threadIdx.x + 1 < BX) inc[0] = sf[1][row][threadIdx.x + 1];
+            if (threadIdx.x > 0) inc[1] = sf[0][row][threadIdx.x - 1];
+            if (row + 1 < kDisRows) inc[2] = sf[3][row + 1][threadIdx.x];
+            if (row > 0) inc[3] = sf[2][row - 1][threadIdx.x];
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+                if (inc[d] > 0) { e[k] += inc[d]; c[k][d] += inc[d]; }
+            const int hp = sh[cur][ly][lx];
+            int hnew = hp;
+            if (e[k] > 0 && hp < hmax) {
+                int best = kCutInf;
+                bool admissible = tc[k] > 0;
+                if (admissible) best = 0;
+                const int hn[4] = {sh[cur][ly][lx + 1], sh[cur][ly][lx - 1], sh[cur][ly + 1][lx], sh[cur][ly - 1][lx]};
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+                    if (c[k][d] > 0) {
+                        if (hn[d] == hp - 1) admissible = true;
+                        if (hn[d] < best) best = hn[d];
+                    }
+                if (!admissible) hnew = best >= hmax ? hmax : best + 1;
+                a |= hnew < hmax;
+            }
+            sh[cur ^ 1][ly][lx] = hnew;
+        }
+        still = __syncthreads_or(a);
+        cur ^= 1;
+    }
+    // the tile goes home; what left it goes to the neighbours (none of them runs in this launch)
+    bool sent[4] = {false, false, false, false};
+#pragma unroll
+    for (int k = 0; k < kDisPer; k++) {
+        if (!in[k]) continue;
+        const int y = y0 + threadIdx.y + BY * k, ly = threadIdx.y + BY * k + 1;
+        const size_t o = wb + (size_t)y * g.pitch + x;
+        P.e[o] = e[k]; P.tc[o] = tc[k];
+#pragma unroll
+        for (int d = 0; d < 4; d++) P.c[d][o] = c[k][d];
+        P.hgt[o] = sh[cur][ly][lx];
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (out[k][d] > 0) {
+                const size_t q = d == 0 ? o + 1 : d == 1 ? o - 1 : d == 2 ? o + g.pitch : o - g.pitch;
+                P.e[q] += out[k][d];
+                P.c[d ^ 1][q] += out[k][d];
+                sent[d] = true;
+            }
+    }
+    bool any_sent = false;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int s = __syncthreads_or(sent[d]);
+        if (first && s) act[d == 0 ? t + 1 : d == 1 ? t - 1 : d == 2 ? t + tiles_x : t - tiles_x] = 1;
+        any_sent |= s != 0;
+    }
+    if (first) {
+        act[t] = still ? 1 : 0;
+        if (still || any_sent) cut_raise(&flags[0]);
+    }
+}
+// after a global relabelling: which tiles hold an active node (flags[1]: their number)
+__global__ void __launch_bounds__(BX *BY) k_cut_mark_tiles(CutPlanes P, int *__restrict__ act, unsigned *__restrict__ n_active, unsigned cap, Geo g, int hmax, int tiles_x, int tiles_y) {
+    const int b = blockIdx.z, t = (b * tiles_y + blockIdx.y) * tiles_x + blockIdx.x;
+    const int x = blockIdx.x * BX + threadIdx.x;
+    bool a = false;
+#pragma unroll
+    for (int k = 0; k < kDisPer; k++) {
+        const int y = blockIdx.y * kDisRows + threadIdx.y + BY * k;
+        if (x < g.w && y < g.h) {
+            const size_t o = b * g.pl + (size_t)y * g.pitch + x;
+            a |= P.e[o] > 0 && P.hgt[o] < hmax;
+        }
+    }
+    const int any = __syncthreads_or(a);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        act[t] = any;
+        // counted up to `cap`: beyond it only "many" matters, and thousands of atomics on one word would cost more than the pass
+        if (any && __hip_atomic_load(n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= cap) atomicAdd(n_active, 1u);
+    }
+}
 // after the final breadth-first pass: a node that still reaches the passive terminal lies on its side
 __global__ void k_cut_labels(float *__restrict__ occ, long occ_es, CutPlanes P, const unsigned *__restrict__ counts, Geo g) {
     const int b = blockIdx.z;
@@ -471,8 +654,8 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
     for (int d = 0; d < 4; d++) { P.c[d] = work + (2 + d) * n; P.f[d] = work + (6 + d) * n; }
     P.hgt = reinterpret_cast<int *>(work + 10 * n);
     P.hgt_next = reinterpret_cast<int *>(work + 11 * n);
-    unsigned *flags = reinterpret_cast<unsigned *>(c->d_red);     // [0]: changed / active, [2 ..]: per-window counts
-    unsigned *counts = flags + 2;
+    unsigned *flags = reinterpret_cast<unsigned *>(c->d_red);     // [0]: changed / active, [1]: active tiles, [2 .. 5]: changed, per sweep of a batch, [8 ..]: per-window counts
+    unsigned *counts = flags + 8;
     unsigned *h_flag = reinterpret_cast<unsigned *>(c->h_red);
     Geo gc = g;
     gc.es = g.pl;                                                 // the cut planes are packed [nb][pl]
@@ -484,7 +667,7 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
     T.idle_next = T.idle + ntiles;
     T.dirty = T.idle + 2 * ntiles;
     T.dirty_next = T.idle + 3 * ntiles;
-    SFA_HIP(c, hipMemsetAsync(flags, 0, (2 + 2 * g.nb) * sizeof(unsigned), c->stream));
+    SFA_HIP(c, hipMemsetAsync(flags, 0, (8 + 2 * g.nb) * sizeof(unsigned), c->stream));
     hipLaunchKernelGGL(k_cut_count, dim3(grid.x, std::min((int)grid.y, kCountRows), grid.z), block, 0, c->stream, d0, d1, counts, gc);
     hipLaunchKernelGGL(k_cut_init, grid, block, 0, c->stream, P, d0, d1, counts, alpha, gc);
     SFA_HIP(c, hipMemsetAsync(T.idle, 0, ntiles * sizeof(int), c->stream));                  // no tile is settled yet (k_cut_mark refines this)
@@ -498,7 +681,7 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
         for (long guard = 0; guard < (long)g.w * g.h + 8; guard += kSweeps) {
             SFA_HIP(c, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), c->stream));
             for (int i = 0; i < kSweeps; i++) {
-                hipLaunchKernelGGL(k_cut_bfs_sweep, bfs_grid, block, 0, c->stream, P, T, flags, gc);
+                hipLaunchKernelGGL(k_cut_bfs_sweep, bfs_grid, block, 0, c->stream, P, T, (const int *)nullptr, flags, gc);
                 std::swap(T.dirty, T.dirty_next);
             }
             // new heights everywhere: resynchronise the height buffers and the tile states, and count the active tiles -- valid if this
@@ -510,6 +693,64 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
         }
         return set_error(c, SFA_ERR_TIMEOUT, "grid cut: breadth-first relabelling did not settle");   // unreachable: distances are < w*h
     };
+    // ---- tile discharge (the default; SFA_CUT_DISCHARGE=0: the grid rounds below, kept as the cross-check) ----
+    const bool discharge = !getenv("SFA_CUT_DISCHARGE") || atoi(getenv("SFA_CUT_DISCHARGE")) != 0;
+    if (discharge) {
+        const int tiles_x = (int)bfs_grid.x, tiles_y = (int)bfs_grid.y;
+        int *act = T.idle, *fixed = T.idle_next;                  // the grid rounds' bookkeeping is not in use: [nb][tiles_y][tiles_x] flags each
+        const unsigned few_tiles = std::max(8u, (unsigned)(tiles_x * tiles_y * g.nb) / 64);     // active tiles up to which a batch is a tail batch
+        const dim3 dgrid((tiles_x + 1) / 2, (tiles_y + 1) / 2, g.nb);
+        const int kInner = getenv("SFA_CUT_INNER") ? atoi(getenv("SFA_CUT_INNER")) : 16;      // rounds a tile runs per local relabelling, at most
+        const int kSuper = getenv("SFA_CUT_SUPER") ? atoi(getenv("SFA_CUT_SUPER")) : 2;       // visits of every colour between two relabellings
+        const int kTailInner = getenv("SFA_CUT_TAIL_INNER") ? atoi(getenv("SFA_CUT_TAIL_INNER")) : 32;   // the same once few tiles are active
+        const int kTailSuper = getenv("SFA_CUT_TAIL_SUPER") ? atoi(getenv("SFA_CUT_TAIL_SUPER")) : 4;
+        // exact distances, then which tiles hold active nodes; flags[1]: any at all
+        auto relabel_and_mark = [&]() -> int {
+            hipLaunchKernelGGL(k_cut_bfs_init_tiles, bfs_grid, block, 0, c->stream, P, T.dirty, fixed, gc);
+            // a sweep that changes nothing leaves the exact distances (so do all after it): one flag per sweep of a batch, the last one decides
+            constexpr int kSweeps = 4;
+            for (long guard = 0; guard < (long)g.w * g.h + 8; guard += kSweeps) {
+                SFA_HIP(c, hipMemsetAsync(flags, 0, 6 * sizeof(unsigned), c->stream));
+                for (int i = 0; i < kSweeps; i++) {
+                    hipLaunchKernelGGL(k_cut_bfs_sweep, bfs_grid, block, 0, c->stream, P, T, fixed, flags + 2 + i, gc);
+                    std::swap(T.dirty, T.dirty_next);
+                }
+                hipLaunchKernelGGL(k_cut_mark_tiles, bfs_grid, block, 0, c->stream, P, act, flags + 1, few_tiles, gc, hmax, tiles_x, tiles_y);
+                SFA_HIP(c, hipMemcpyAsync(h_flag, flags, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                SFA_HIP(c, hipStreamSynchronize(c->stream));
+                if (!h_flag[2 + kSweeps - 1]) {
+                    if (getenv("SFA_CUT_DEBUG")) {
+                        std::vector<int> ha((size_t)tiles_x * tiles_y * g.nb);
+                        (void)hipMemcpy(ha.data(), act, ha.size() * sizeof(int), hipMemcpyDeviceToHost);
+                        long na = 0;
+                        for (int v : ha) na += v != 0;
+                        fprintf(stderr, "cut %dx%d: relabel settled after %ld sweeps, %ld of %zu tiles active\n", g.w, g.h, guard + kSweeps, na, ha.size());
+                    }
+                    return SFA_OK;
+                }
+            }
+            return set_error(c, SFA_ERR_TIMEOUT, "grid cut: breadth-first relabelling did not settle");
+        };
+        SFA_TRY(relabel_and_mark());
+        const int max_batches = 64 * (g.w + g.h);
+        int batch = 0;
+        // a maximum preflow is reached when, with exact distances, no node with excess reaches the passive terminal any more
+        while (h_flag[1]) {
+            if (++batch > max_batches) return set_error(c, SFA_ERR_TIMEOUT, "grid cut: tile discharge did not settle in %d batches", max_batches);
+            // between two relabellings (which strand the excess that can no longer reach the terminal -- left to itself it would climb to hmax one
+            // height per round) every colour is visited kSuper times
+            // few tiles left: a visit costs next to nothing and the relabelling as much as ever -- more of the former per latter
+            const bool tail = h_flag[1] <= few_tiles;
+            const int supers = tail ? kTailSuper : kSuper, rounds = tail ? kTailInner : kInner;
+            for (int s = 0; s < supers; s++)
+                for (int colour = 0; colour < 4; colour++)
+                    hipLaunchKernelGGL(k_cut_discharge, dgrid, block, 0, c->stream, P, act, flags, gc, hmax, colour, tiles_x, tiles_y, rounds);
+            SFA_TRY(relabel_and_mark());
+        }
+        hipLaunchKernelGGL(k_cut_labels, grid, block, 0, c->stream, occ, occ_es, P, counts, gc);
+        SFA_HIP(c, hipGetLastError());
+        return SFA_OK;
+    }
     SFA_TRY(global_relabel());
     const int max_rounds = 64 * (g.w + g.h);
     // Rounds come in batches between two global relabellings (which strand the excess that can no longer reach the terminal):

@@ -748,12 +748,34 @@ def test_grid_cut_sparse_phase_runs_the_same_rounds(ctx, monkeypatch, kind, w, h
     """the one-workgroup-per-window kernel of the sparse phase executes the rounds the grid launches would: identical labels"""
     rng = np.random.default_rng(w + h)
     d0, d1 = _cut_case(rng, w, h, kind)
+    monkeypatch.setenv("SFA_CUT_DISCHARGE", "0")                # the grid rounds (round 2's schedule, the cross-check of the tile discharge)
     monkeypatch.setenv("SFA_CUT_TAIL", "1")                     # a single window would not take it by itself
     occ_tail = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
     monkeypatch.delenv("SFA_CUT_TAIL")
     monkeypatch.setenv("SFA_CUT_NO_TAIL", "1")
     occ_grid = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
     assert np.array_equal(occ_tail, occ_grid)
+
+
+@pytest.mark.parametrize("kind,w,h", [("blobs", 1024, 436), ("stripes", 300, 200), ("noise", 130, 98), ("blobs", 67, 45), ("stripes", 64, 16), ("noise", 65, 17)])
+def test_grid_cut_tile_discharge_finds_the_same_cut(ctx, oracle, monkeypatch, kind, w, h):
+    """the tile-discharge schedule (rounds inside 64 x 16 tiles, four colours) and the grid rounds reach a maximum flow each; the labelling read off
+    it (who still reaches the passive terminal) is the same set whichever maximum flow it is -- and the energy is the oracle's minimum"""
+    rng = np.random.default_rng(w + 3 * h)
+    d0, d1 = _cut_case(rng, w, h, kind)
+    occ_tiles = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
+    for inner, sup in ((3, 1), (200, 4)):
+        monkeypatch.setenv("SFA_CUT_INNER", str(inner)); monkeypatch.setenv("SFA_CUT_SUPER", str(sup))
+        assert np.array_equal(occ_tiles, ctx.grid_cut(c_(d0), c_(d1), 0.5, w))
+    monkeypatch.setenv("SFA_CUT_DISCHARGE", "0")
+    occ_grid = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
+    a0 = orc.plane(*d0.shape); a0[...] = d0
+    a1 = orc.plane(*d1.shape); a1[...] = d1
+    og = orc.plane(*d0.shape)
+    og[...] = occ_tiles; e_t = oracle.grid_cut_energy(og, a0, a1, 0.5, w)
+    og[...] = occ_grid; e_g = oracle.grid_cut_energy(og, a0, a1, 0.5, w)
+    assert abs(e_t - e_g) <= 1e-6 * max(1.0, abs(e_g)), (e_t, e_g)
+    assert (valid(occ_tiles, w) != valid(occ_grid, w)).mean() < 1e-3
 
 
 @pytest.mark.parametrize("S,rho,omega", [(2, [1], [0]), (3, [1, 1], [0, 2])])
