@@ -589,6 +589,9 @@ __device__ __forceinline__ void chain_out(const ChainArgs &a, unsigned char *lds
 // ---------------------------------------------------------------------------------------------------------------------------------
 // waves of a workgroup: 0 = IN, 1 .. NW = the stages, NW + 1 = OUT (with NW = 3 the two I/O waves share SIMD 0, the stages have a SIMD each)
 template <int FA, int NA, int FB, int NB_, int CH, int PD, int AH, int PL, int PUBD>
+#ifdef SFA_CHAIN_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(SFA_CHAIN_WAVES_PER_EU, SFA_CHAIN_WAVES_PER_EU)))
+#endif
 __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) {
     using S = ChainShape<FA, NA, FB, NB_>;
     using L = ChainLds<S, CH>;

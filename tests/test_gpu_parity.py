@@ -660,6 +660,31 @@ def test_config3_shape_2560x1440_cfg_terms(ctx, oracle, monkeypatch):
     assert abs(np.median(valid(out[1][0], w)) - 2.0) < 0.2 and abs(np.median(valid(out[1][1], w)) - 1.0) < 0.2
 
 
+def test_config3_level_2560x1440_against_the_oracle(ctx, oracle):
+    """config 3's frame size and cfg terms (S = 3: four image pairs, the to-reference terms omega = 0/2 included) through ONE full-size level, two
+    outer iterations, against the oracle -- the comparison the full schedule is too slow for on the CPU (full-size configs 3 and 5 were
+    property tests only)"""
+    w, h = 2560, 1440
+    frames, af, sf = normalized_frames(oracle, w, h, 5, seed=23)
+    po, ps = mk_params(oracle, S=3, rho=[1, 1], omega=[0, 2], norm_avg=af, norm_std=sf, niter_outer=2)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_LEVEL, d
+    assert np.abs(valid(g[0], w)).max() > 0.05                       # the level did move the flow
+
+
+def test_config5_two_levels_2048_against_the_oracle(ctx, oracle):
+    """config 5's frame size and operator set (Lorentzian) through the two finest levels of the pyramid (down-sampling, flow rescale and both levels'
+    iterations), against the oracle at <= 1e-4"""
+    w = h = 2048
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=21)
+    lor = (2, 0.05, 0.5)
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=1, layers=2, robust_color=lor, robust_grad=lor, robust_reg=lor)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h, level_only=False)
+    d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+    assert d <= TOL_UV, d
+
+
 # ------------------------------------------------------------------------------------------------------
 # occlusion step between alternations (optimizeOcc, variational_aux_mt.cpp:758-887)
 # ------------------------------------------------------------------------------------------------------
