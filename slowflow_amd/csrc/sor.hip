@@ -948,6 +948,7 @@ int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float
 // sor_chain.hip: the few-windows pipeline (groups of stages per workgroup, I/O wave)
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX);
 int chain_ch();
+int chain_shift(int id);
 int chain_flag_stride();
 int chain_ah();
 int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float omega);
@@ -1042,7 +1043,7 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
         NG = K / KG;
         G = K + 64;
         RP = round_up(h + 2 * G, 16);
-        NCH = round_up((w + 64 + KG - NW + 2 * CH + FMAX + CH - 1) / CH, 4);
+        NCH = round_up((w + 64 + KG - NW + 2 * CH + FMAX + CH - 1) / CH + chain_shift(chain), 4);     // + the chunks by which the groups start early
         NS = round_up(NCH + LEAD + NW + 2, AH);
         ND = NS * CH + 64 * NB + G + 32;                      // diagonals: the I/O wave reads the x plane up to interval NS, the bands sit 64 rows apart
         ntasks = NB * NG;                                     // workgroups per window

@@ -110,6 +110,11 @@ __device__ unsigned long long g_chain_timing[64 * 8 * 16];
 #define SFA_CHAIN_BARRIER_T2(acc, accw) SFA_CHAIN_BARRIER()
 #endif
 
+#ifndef SFA_CHAIN_OPRING
+#define SFA_CHAIN_OPRING 1
+#endif
+// chunks by which a group with an operand ring starts early: the first stage's first step then sits at column <= 1 - KG - ... (s_start <= -1 - 4 SHIFT)
+__host__ __device__ constexpr int chain_start_shift(int KG) { return KG <= 10 ? 2 : 4; }
 // shape of a workgroup: NA stages of FA sweeps, then NB_ stages of FB sweeps
 template <int FA, int NA, int FB, int NB_>
 struct ChainShape {
@@ -131,7 +136,14 @@ struct ChainLds {
     static constexpr int ESW = 2 * (S::FMAX > 1 ? S::FMAX - 1 : 1) * CH * 8;   // per wave
     static constexpr int dummy0 = es0 + S::NW * ESW;
     static constexpr int DUMMY = 64 * 8 + ESW;
-    static constexpr int ticket = dummy0 + DUMMY;
+    // operand ring (see chain_compute): the rows of SA / SB the group's FIRST sweep reads, kept for the KG - 1 sweeps that read the same rows later --
+    // sweep kappa of stage w reads, at its local step s, the row of step s + w - 2 kappa, kappa lanes down.  OPW entries per row: KG - 1 entries of the
+    // band above (IN wave), then the 64 of this band (first stage); OPR rows: a row is last read 3 (NW - 1) + 2 (KG - 1) + 3 steps after the first
+    // stage used it, and its slot is rewritten (IN wave: the entries of the band above) up to 5 steps before the first stage gets there again
+    static constexpr int OPW = 64 + S::KG - 1, OPROWB = OPW * 16, OPR = 3 * (S::NW - 1) + 2 * (S::KG - 1) + 10, OPPLANE = OPR * OPROWB;
+    static constexpr int ops0 = (dummy0 + DUMMY + 15) & ~15;
+    static constexpr bool OPRING = SFA_CHAIN_OPRING && S::KG <= 16 && ops0 + 2 * OPPLANE + 32 <= 160 * 1024;
+    static constexpr int ticket = ops0 + (OPRING ? 2 * OPPLANE : 0);
     static constexpr int total = ticket + 16;
 };
 
@@ -166,9 +178,15 @@ __device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bott
 // P0 = PD * CH steps of operand prefetch in registers for sweep 0 (first touch of the rows: Infinity Cache / HBM), P1 for the trailing
 // sweeps (the rows this CU fetched 2 f steps earlier: L2).  PD even: the ring parity of a chunk is its position in the unrolled body.
 // A slot is refilled one step AFTER its use: the next column's left weight (hp of this column) is read from it in place.
-template <int F, int CH, int PD, bool SHORT = false>
+// ROLE 0: every sweep loads its operands from memory (shapes without an operand ring).  ROLE 1 (the group's first stage): sweep 0 loads from memory and
+// leaves every row in the LDS ring when it uses it; ROLE 2 and the trailing sweeps of ROLE 1 read the ring, one step ahead of their use (kap0 = sweeps of
+// the group in front of this stage, w = the stage).  Measured first (a what-if build that read arbitrary LDS rows): the operand loads of the trailing sweeps,
+// not arithmetic or the hand-over between workgroups, were what a launch of several windows waited for -- 16 windows 942 -> 642 us.
+template <int F, int CH, int PD, bool SHORT = false, int ROLE = 0, int OPS0 = 0, int OPR = 1, int OPROWB = 0, int KG = 1>
 __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char *lds, int ring_in, int ring_out, int tvb, int esb, int dummy, int job, int b,
-                                              int k0, int s_start, int lead, int lane) {
+                                              int k0, int s_start, int lead, int lane, int kap0 = 0, int w = 0) {
+    constexpr int OPPLANE = OPR * OPROWB;
+    constexpr int F0 = ROLE == 2 ? 0 : 1;                            // sweeps of this wave that load from memory (ROLE 0: all of them, below)
     static_assert(PD % 2 == 0, "the chunk parity must be a compile-time constant of the body position");
     // ring lengths divide the body (PD * CH steps): wide stages (F >= 4: a whole band's sweeps in one workgroup, large batches, slow steps) keep one chunk
     constexpr int P0 = (F >= 4 || SHORT) ? CH : PD * CH, P1 = (F <= 2 && !SHORT) ? P0 : CH;
@@ -190,13 +208,35 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
     const unsigned st16 = (unsigned)RP * 16u;
     unsigned so = 0;                                                  // byte offset of the step about to be computed
 
-    float4 sa0[P0], sb0[P0], sa1[F > 1 ? F - 1 : 1][P1], sb1[F > 1 ? F - 1 : 1][P1];
+    float4 sa0[ROLE == 2 ? 1 : P0], sb0[ROLE == 2 ? 1 : P0], sa1[(F > 1 && ROLE == 0) ? F - 1 : 1][ROLE == 0 ? P1 : 1], sb1[(F > 1 && ROLE == 0) ? F - 1 : 1][ROLE == 0 ? P1 : 1];
+    if (ROLE != 2) {
 #pragma unroll
-    for (int j = 0; j < P0; j++) { sa0[j] = bload16(rA, vo[0], j * st16); sb0[j] = bload16(rB, vo[0], j * st16); }
+        for (int j = 0; j < P0; j++) { sa0[j] = bload16(rA, vo[0], j * st16); sb0[j] = bload16(rB, vo[0], j * st16); }
+    }
+    if (ROLE == 0) {
 #pragma unroll
-    for (int f = 1; f < F; f++)
+        for (int f = 1; f < F; f++)
 #pragma unroll
-        for (int j = 0; j < P1; j++) { sa1[f - 1][j] = bload16(rA, vo[f], j * st16); sb1[f - 1][j] = bload16(rB, vo[f], j * st16); }
+            for (int j = 0; j < P1; j++) { sa1[f - 1][j] = bload16(rA, vo[f], j * st16); sb1[f - 1][j] = bload16(rB, vo[f], j * st16); }
+    }
+    // operand ring: byte offset of the row the first stage writes next / each ring-fed sweep reads next (uniform; rows wrap at OPPLANE), the lane's place in
+    // a row, and the operands of the current and the next step
+    unsigned wr_off = 0, rd_off[F];
+    unsigned rd_lane[F];
+    float4 la[F][2], lb[F][2];
+#pragma unroll
+    for (int f = 0; f < F; f++) {
+        const int kap = kap0 + f;
+        rd_lane[f] = (unsigned)(OPS0 + (KG - 1 + lane - kap) * 16);
+        rd_off[f] = (unsigned)(((w - 2 * kap) % OPR + OPR) % OPR * OPROWB);      // the row of step 0: step w - 2 kappa of the first stage (not written yet: zeros)
+        la[f][0] = la[f][1] = lb[f][0] = lb[f][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ROLE != 0 && f >= F0) {
+            la[f][0] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);
+            lb[f][0] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
+            rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
+        }
+    }
+    const unsigned wr_lane = (unsigned)(OPS0 + (KG - 1 + lane) * 16);
     float2 res[F], selfv[F];
     v2f hlz[F];                                                       // (hp, vp) of the previous column; the first step sits in the zero guards
 #pragma unroll
@@ -261,8 +301,9 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
                 for (int f = 0; f < F; f++) {
                     const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
                     const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
-                    const float4 &SA = f == 0 ? sa0[j0] : sa1[f > 0 ? f - 1 : 0][j1];
-                    const float4 &SB = f == 0 ? sb0[j0] : sb1[f > 0 ? f - 1 : 0][j1];
+                    const bool ringfed = ROLE != 0 && f >= F0;
+                    const float4 &SA = ringfed ? la[f][j & 1] : f == 0 ? sa0[ROLE == 2 ? 0 : j0] : sa1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
+                    const float4 &SB = ringfed ? lb[f][j & 1] : f == 0 ? sb0[ROLE == 2 ? 0 : j0] : sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
                     const v2f xn = sor_point2(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hlz[f], SA, SB, omega);
                     nres[f] = make_float2(xn.x, xn.y);
                     selfv[f] = right;
@@ -272,13 +313,28 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
 #pragma unroll
                 for (int f = 0; f + 1 < F; f++) esp[(par * (F - 1) + f) * CH + j] = f2u(res[f].x, res[f].y);
                 rout[(par * CH + j) * 64] = f2u(res[F - 1].x, res[F - 1].y);
+                if (ROLE == 1) {                                     // the row this step used goes to the ring (the later sweeps of the group read it there)
+                    *reinterpret_cast<float4 *>(lds + wr_lane + wr_off) = sa0[j0];
+                    *reinterpret_cast<float4 *>(lds + wr_lane + wr_off + OPPLANE) = sb0[j0];
+                    wr_off = wr_off + OPROWB == (unsigned)OPPLANE ? 0u : wr_off + OPROWB;
+                }
                 // the PREVIOUS step's slots are refilled now (beyond the last step: zero guards); this step's (hp, vp) stay readable in place
-                sa0[p0] = bload16(rA, vo[0], so + (P0 - 1) * st16); sb0[p0] = bload16(rB, vo[0], so + (P0 - 1) * st16);
+                if (ROLE != 2) { sa0[p0] = bload16(rA, vo[0], so + (P0 - 1) * st16); sb0[p0] = bload16(rB, vo[0], so + (P0 - 1) * st16); }
+                if (ROLE == 0) {
 #pragma unroll
-                for (int f = 1; f < F; f++) { sa1[f - 1][p1] = bload16(rA, vo[f], so + (P1 - 1) * st16); sb1[f - 1][p1] = bload16(rB, vo[f], so + (P1 - 1) * st16); }
-                hlz[0] = (v2f){sb0[j0].z, sb0[j0].w};
+                    for (int f = 1; f < F; f++) { sa1[f - 1][p1] = bload16(rA, vo[f], so + (P1 - 1) * st16); sb1[f - 1][p1] = bload16(rB, vo[f], so + (P1 - 1) * st16); }
+                }
 #pragma unroll
-                for (int f = 1; f < F; f++) hlz[f] = (v2f){sb1[f - 1][j1].z, sb1[f - 1][j1].w};
+                for (int f = 0; f < F; f++) {
+                    const bool ringfed = ROLE != 0 && f >= F0;
+                    if (ringfed) {
+                        hlz[f] = (v2f){lb[f][j & 1].z, lb[f][j & 1].w};
+                        la[f][(j + 1) & 1] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);              // the next step's row
+                        lb[f][(j + 1) & 1] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
+                        rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
+                    } else if (f == 0) hlz[0] = (v2f){sb0[ROLE == 2 ? 0 : j0].z, sb0[ROLE == 2 ? 0 : j0].w};
+                    else hlz[f] = (v2f){sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0].z, sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0].w};
+                }
                 so += st16;
             }
         }
@@ -415,6 +471,20 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
     }
     unsigned so_tv = 0, so_xin = 0;                                  // advance by one chunk per interval
     unsigned char *const ldsb = lds;
+    // operand ring (ChainLds): the KG - 1 entries above the band of the rows the first stage reads -- chunk I of its local steps is fetched at interval I
+    // (lane = step of the chunk x entry) and written AH intervals later, one interval before the first stage uses (and writes) the rows themselves
+    constexpr bool OPX = L::OPRING;
+    const int xj = lane >> 4, xe = lane & 15;
+    const bool ox_on = OPX && xj < CH && xe < S::KG - 1;
+    const long ox_e = G.U00 + (long)G.s_start0 * RP - (S::KG - 1);
+    const __amdgpu_buffer_rsrc_t rOA = plane_rsrc(a.sa + (size_t)job * a.ent + ox_e, 0xffffff00ull);
+    const __amdgpu_buffer_rsrc_t rOB = plane_rsrc(a.sb + (size_t)job * a.ent + ox_e, 0xffffff00ull);
+    const unsigned ox_voff = ox_on ? (unsigned)((xj * RP + xe) * 16) : kOobOffset;
+    float4 oxa[AH], oxb[AH];
+#pragma unroll
+    for (int q = 0; q < AH; q++) oxa[q] = oxb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned ox_so = 0;
+    int ox_row4 = 0;                                                 // ring row of the first step of the chunk written next
 #ifdef SFA_CHAIN_TIMING
     unsigned long long t_begin = __builtin_readcyclecounter(), t_bar = 0, t_slow = 0, n_slow = 0, t0, t1;
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();      // 100 MHz, the same clock on every XCD
@@ -430,6 +500,15 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
             for (int n = 0; n < NLT; n++) *reinterpret_cast<unsigned long long *>(ldsb + tv_lds[n][p]) = tvx_lane[n] ? tvxr[q] : tvr[q][n];
 #pragma unroll
             for (int j = 0; j < CH; j++) reinterpret_cast<unsigned long long *>(ldsb + L::ring0 + ((p * CH + j) * 64) * 8)[lane] = xr[q][j];
+            if (OPX && I >= AH) {
+                int row = ox_row4 + xj;
+                if (row >= L::OPR) row -= L::OPR;
+                if (ox_on) {
+                    *reinterpret_cast<float4 *>(ldsb + L::ops0 + row * L::OPROWB + xe * 16) = oxa[q];
+                    *reinterpret_cast<float4 *>(ldsb + L::ops0 + L::OPPLANE + row * L::OPROWB + xe * 16) = oxb[q];
+                }
+                ox_row4 = ox_row4 + CH >= L::OPR ? ox_row4 + CH - L::OPR : ox_row4 + CH;
+            }
             // ---- the workgroups this one depends on: polls issued PL intervals ago -------------------------------------------------------
             known_up = max(known_up, (unsigned)__builtin_amdgcn_readfirstlane(pend_up[(q + AH - PL) % AH]));
             known_up2 = max(known_up2, (unsigned)__builtin_amdgcn_readfirstlane(pend_up2[(q + AH - PL) % AH]));
@@ -462,6 +541,11 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
 #pragma unroll
             for (int j = 0; j < CH; j++) xr[q][j] = bload8_sc1(rXin, vXin, so_xin + (unsigned)j * st8);
 #endif
+            if (OPX) {
+                oxa[q] = bload16(rOA, ox_voff, ox_so);
+                oxb[q] = bload16(rOB, ox_voff, ox_so);
+                ox_so += (unsigned)(CH * RP) * 16u;
+            }
             so_tv += CH * 8u; so_xin += CH * st8;
         }
     }
@@ -610,9 +694,11 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
     if (!elem_active(active_mask(a.active, a.amask), job)) return;        // a passenger: none of its workgroups runs, so none of them waits
     const int2 bg = a.order[t / a.nb];
     const int b = __builtin_amdgcn_readfirstlane(bg.x), g = __builtin_amdgcn_readfirstlane(bg.y);
-    // first chunk of the group (even): every stage of the group starts at a local step <= -1
-    const int c_first = ((g * (S::KG - NW)) / CH) & ~1;
-    const int c_first_prev = g > 0 ? (((g - 1) * (S::KG - NW)) / CH) & ~1 : 0;
+    // first chunk of the group (even): every stage of the group starts at a local step <= -1 -- with an operand ring SHIFT chunks earlier still, so
+    // that the rows in front of the first stage's first step (which nobody writes to the ring) are guard zeros up to KG - 1 entries above the band
+    constexpr int SHIFT = L::OPRING ? chain_start_shift(S::KG) : 0;
+    const int c_first = (((g * (S::KG - NW)) / CH) & ~1) - SHIFT;
+    const int c_first_prev = g > 0 ? ((((g - 1) * (S::KG - NW)) / CH) & ~1) - SHIFT : 0;
 #ifdef SFA_X_NOIO         // timing experiment only: the I/O waves just walk through the barriers (nothing crosses workgroups: wrong results, compute speed)
 #ifdef SFA_X_NOIO_POLL    // ... except that wave 0 issues ONE real bypassing load (or store) per interval: does a slow access of another wave delay this CU's operand stream?
     if (wave == 0) {
@@ -713,8 +799,12 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
     const int ring_in = L::ring0 + w * L::RING, ring_out = ring_in + L::RING;
     const int tvb = L::tv0 + w * L::TVW, esb = L::es0 + w * L::ESW;
     constexpr bool SHORT = NW >= 8;                  // many waves per workgroup: fewer registers each
-    if (w < NA) chain_compute<FA, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
-    else        chain_compute<FB, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
+    if (L::OPRING) {
+        if (w == 0)      chain_compute<FA, CH, PD, SHORT, 1, L::ops0, L::OPR, L::OPROWB, S::KG>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, 0, 0);
+        else if (w < NA) chain_compute<FA, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
+        else             chain_compute<FB, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
+    } else if (w < NA) chain_compute<FA, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
+    else               chain_compute<FB, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -754,6 +844,21 @@ bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
     return false;
 }
 int chain_ch() { return kChainCH; }
+// extra chunks per stage a shape needs because its groups start early (operand ring)
+template <int FA, int NA, int FB, int NB_> static int shape_shift() { using S = ChainShape<FA, NA, FB, NB_>; return ChainLds<S, kChainCH>::OPRING ? chain_start_shift(S::KG) : 0; }
+int chain_shift(int id) {
+    switch (id) {
+        case 1: return shape_shift<1, 3, 1, 0>();
+        case 2: return shape_shift<2, 3, 2, 0>();
+        case 3: return shape_shift<3, 5, 3, 0>();
+        case 5: return shape_shift<2, 5, 2, 0>();
+        case 6: return shape_shift<1, 5, 1, 0>();
+        case 8: return shape_shift<3, 2, 3, 0>();
+        case 9: return shape_shift<5, 6, 5, 0>();
+        case 10: return shape_shift<3, 10, 3, 0>();
+    }
+    return 0;
+}
 int chain_flag_stride() { return kFlagStride; }
 int chain_ah() { return kChainAH; }
 

@@ -28,6 +28,18 @@ MODE = os.environ.get("SIM_MODE", "raw")
 SLACK = int(os.environ.get("SIM_SLACK", "0"))      # > 0: weaken every wait threshold by that many intervals (the model must then FAIL)
 
 
+def start_shift(S):
+    """sor_chain.hip chain_start_shift / ChainLds::OPRING: chunks by which the groups of a shape with an operand ring start early"""
+    NW, KG, FMAX = S.NW, S.KG, S.FMAX
+    ring = 2 * CH * 64 * 8
+    tv0 = (NW + 1) * ring; tvw = 2 * CH * (FMAX + 1) * 8; es0 = tv0 + NW * tvw; esw = 2 * (FMAX - 1 if FMAX > 1 else 1) * CH * 8
+    dummy0 = es0 + NW * esw; dummy = 64 * 8 + esw
+    ops0 = (dummy0 + dummy + 15) & ~15
+    opplane = (3 * (NW - 1) + 2 * (KG - 1) + 10) * (64 + KG - 1) * 16
+    opring = KG <= 16 and ops0 + 2 * opplane + 32 <= 160 * 1024
+    return (2 if KG <= 10 else 4) if opring else 0
+
+
 def round_up(a, m):
     return (a + m - 1) // m * m
 
@@ -53,7 +65,7 @@ def prepare(sysm, W, H, K, S, nb):
     ws.NG = K // S.KG
     ws.G = K + 64
     ws.RP = round_up(H + 2 * ws.G, 16)
-    ws.NCH = round_up((W + 64 + S.KG - S.NW + 2 * CH + S.FMAX + CH - 1) // CH, 4)
+    ws.NCH = round_up((W + 64 + S.KG - S.NW + 2 * CH + S.FMAX + CH - 1) // CH + start_shift(S), 4)
     ws.NS = round_up(ws.NCH + LEAD + S.NW + 2, AH)
     ws.ND = ws.NS * CH + 64 * ws.NB + ws.G + 32
     ws.ent = ws.ND * ws.RP
@@ -110,8 +122,8 @@ class WG:
     def __init__(self, ws, S, W, H, K, omega, job, b, g, nb):
         self.ws, self.S, self.W, self.H, self.K, self.omega, self.job, self.b, self.g, self.nb = ws, S, W, H, K, f32(omega), job, b, g, nb
         NW = S.NW
-        self.c_first = ((g * (S.KG - NW)) // CH) & ~1
-        self.c_first_prev = (((g - 1) * (S.KG - NW)) // CH) & ~1 if g > 0 else 0
+        self.c_first = (((g * (S.KG - NW)) // CH) & ~1) - start_shift(S)
+        self.c_first_prev = ((((g - 1) * (S.KG - NW)) // CH) & ~1) - start_shift(S) if g > 0 else 0
         self.I = 0
         self.done = False
         # LDS
