@@ -959,10 +959,17 @@ static int chain_choice(int K, int nb, int NBands) {
     if (const char *e = getenv("SFA_SOR_CHAIN")) id = atoi(e);
     else if (getenv("SFA_SOR_BAND") || getenv("SFA_SOR_F")) id = 0;          // an explicit choice of the other kernels
     else {
-        // default: by the number of bands in the launch (measured at 1024x436, K = 30, 8 bands per window; us per launch, chain shape 1 / 2 / band kernel):
-        // 1 window 268 / 379 / 581 (task kernel), 4: 376 / 394 / 1025, 8: 611 / 605 / 1250, 16: 1076 / 946 / 1310, 32: 2150 / 1590 / 1372
+        // default: by the number of bands in the launch.  Measured at 1024x436, K = 30 (8 bands per window), us per launch, with the operand ring
+        // (sor_chain.hip): shape 6 (5 stages of 1 sweep) / 5 (5 x 2) / 3 (5 x 3) / the band kernel --
+        //   1 window 268 / 385 / 529 / 582 (task kernel), 4: 282 / 392 / 534 / 896, 8: 407 / 414 / 551 / 1243, 16: 615 / 592 / 575 / 1291,
+        //   32: 1106 / 840 / 853 / 1347, 64: 2140 / 1614 / 1502 / 2005.
+        // Few bands: many short groups per band (the start-up skew of a band is what a lone solve waits for); many bands: few long groups (fewer
+        // hand-overs, operands fetched from memory once per 15 sweeps).  A shape whose sweeps per group do not divide K falls back to the next one.
         const int bands = nb * NBands;
-        id = bands <= 48 ? 1 : bands <= 160 ? 2 : 0;
+        static const int few[] = {6, 1, 2, 5, 3, 0}, many[] = {3, 5, 2, 6, 1, 0};
+        int KG, NW, FMAX;
+        for (const int *cand = bands <= 96 ? few : many; *cand; cand++)
+            if (chain_shape(*cand, K, &KG, &NW, &FMAX)) { id = *cand; break; }
     }
     int KG, NW, FMAX;
     if (id > 0 && !chain_shape(id, K, &KG, &NW, &FMAX)) id = 0;
