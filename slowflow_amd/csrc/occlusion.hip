@@ -482,9 +482,13 @@ __global__ void __launch_bounds__(kTailThreads) k_cut_tail(CutPlanes P, CutTiles
 // One launch moves excess across a whole tile where a grid round moved it one pixel.
 // act[t] (64 x 16 tiles, the breadth-first sweep's tiling): the tile holds an active node, or has been handed flow since it last ran.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kDisRows = kBfsRows, kDisPer = kDisRows / BY;
-__global__ void __launch_bounds__(BX *BY) k_cut_discharge(CutPlanes P, int *__restrict__ act, unsigned *__restrict__ flags, Geo g, int hmax, int colour,
+constexpr int kDisRows = kBfsRows;
+// PER rows per thread: the block is 64 x (kDisRows / PER) threads.  One row per thread (16 waves) halves a round's latency twice over against four rows
+// per thread, which is what the last batches of a cut consist of (a handful of tiles, each running its rounds alone on a CU)
+template <int PER>
+__global__ void __launch_bounds__(BX * (kDisRows / PER)) k_cut_discharge(CutPlanes P, int *__restrict__ act, unsigned *__restrict__ flags, Geo g, int hmax, int colour,
                                                           int tiles_x, int tiles_y, int max_rounds) {
+    constexpr int kDisPer = PER, TYN = kDisRows / PER;             // rows per thread, threads along y
     __shared__ int sh[2][kDisRows + 2][BX + 2];
     __shared__ float sf[4][kDisRows][BX];
     const int b = blockIdx.z;
@@ -495,7 +499,7 @@ __global__ void __launch_bounds__(BX *BY) k_cut_discharge(CutPlanes P, int *__re
     const bool first = threadIdx.x == 0 && threadIdx.y == 0;
     const int x0 = bx * BX, y0 = by * kDisRows, tid = threadIdx.y * BX + threadIdx.x;
     const size_t wb = (size_t)b * g.pl;
-    for (int i = tid; i < (kDisRows + 2) * (BX + 2); i += BX * BY) {                          // tile + ring (outside the image: unreachable, and no arc leads there)
+    for (int i = tid; i < (kDisRows + 2) * (BX + 2); i += BX * TYN) {                          // tile + ring (outside the image: unreachable, and no arc leads there)
         const int ly = i / (BX + 2), lx = i % (BX + 2), x = x0 + lx - 1, y = y0 + ly - 1;
         const int v = (x >= 0 && x < g.w && y >= 0 && y < g.h) ? P.hgt[wb + (size_t)y * g.pitch + x] : kCutInf;
         sh[0][ly][lx] = v; sh[1][ly][lx] = v;
@@ -505,7 +509,7 @@ __global__ void __launch_bounds__(BX *BY) k_cut_discharge(CutPlanes P, int *__re
     bool in[kDisPer];
 #pragma unroll
     for (int k = 0; k < kDisPer; k++) {
-        const int y = y0 + threadIdx.y + BY * k;
+        const int y = y0 + threadIdx.y + TYN * k;
         in[k] = x < g.w && y < g.h;
         e[k] = 0.0f; tc[k] = 0.0f;
 #pragma unroll
@@ -524,7 +528,7 @@ __global__ void __launch_bounds__(BX *BY) k_cut_discharge(CutPlanes P, int *__re
         // push: decisions from the heights of the previous round only
 #pragma unroll
         for (int k = 0; k < kDisPer; k++) {
-            const int ly = threadIdx.y + BY * k + 1;
+            const int ly = threadIdx.y + TYN * k + 1;
             float f[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             const int hp = sh[cur][ly][lx];
             if (e[k] > 0 && hp < hmax) {
@@ -550,7 +554,7 @@ __global__ void __launch_bounds__(BX *BY) k_cut_discharge(CutPlanes P, int *__re
         bool a = false;
 #pragma unroll
         for (int k = 0; k < kDisPer; k++) {
-            const int ly = threadIdx.y + BY * k + 1, row = ly - 1;
+            const int ly = threadIdx.y + TYN * k + 1, row = ly - 1;
             float inc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (threadIdx.x + 1 < BX) inc[0] = sf[1][row][threadIdx.x + 1];
             if (threadIdx.x > 0) inc[1] = sf[0][row][threadIdx.x - 1];
@@ -585,7 +589,7 @@ __global__ void __launch_bounds__(BX *BY) k_cut_discharge(CutPlanes P, int *__re
 #pragma unroll
     for (int k = 0; k < kDisPer; k++) {
         if (!in[k]) continue;
-        const int y = y0 + threadIdx.y + BY * k, ly = threadIdx.y + BY * k + 1;
+        const int y = y0 + threadIdx.y + TYN * k, ly = threadIdx.y + TYN * k + 1;
         const size_t o = wb + (size_t)y * g.pitch + x;
         P.e[o] = e[k]; P.tc[o] = tc[k];
 #pragma unroll
@@ -613,6 +617,7 @@ __global__ void __launch_bounds__(BX *BY) k_cut_discharge(CutPlanes P, int *__re
     }
 }
 // after a global relabelling: which tiles hold an active node (flags[1]: their number)
+constexpr int kDisPer = kDisRows / BY;
 __global__ void __launch_bounds__(BX *BY) k_cut_mark_tiles(CutPlanes P, int *__restrict__ act, unsigned *__restrict__ n_active, unsigned cap, Geo g, int hmax, int tiles_x, int tiles_y) {
     const int b = blockIdx.z, t = (b * tiles_y + blockIdx.y) * tiles_x + blockIdx.x;
     const int x = blockIdx.x * BX + threadIdx.x;
@@ -703,6 +708,7 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
         const int kInner = getenv("SFA_CUT_INNER") ? atoi(getenv("SFA_CUT_INNER")) : 16;      // rounds a tile runs per local relabelling, at most
         const int kSuper = getenv("SFA_CUT_SUPER") ? atoi(getenv("SFA_CUT_SUPER")) : 2;       // visits of every colour between two relabellings
         const int kTailInner = getenv("SFA_CUT_TAIL_INNER") ? atoi(getenv("SFA_CUT_TAIL_INNER")) : 32;   // the same once few tiles are active
+        const int kPer = getenv("SFA_CUT_PER") ? atoi(getenv("SFA_CUT_PER")) : 2, kTailPer = getenv("SFA_CUT_TAIL_PER") ? atoi(getenv("SFA_CUT_TAIL_PER")) : 1;   // rows per thread
         const int kTailSuper = getenv("SFA_CUT_TAIL_SUPER") ? atoi(getenv("SFA_CUT_TAIL_SUPER")) : 4;
         // exact distances, then which tiles hold active nodes; flags[1]: any at all
         auto relabel_and_mark = [&]() -> int {
@@ -742,9 +748,12 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
             // few tiles left: a visit costs next to nothing and the relabelling as much as ever -- more of the former per latter
             const bool tail = h_flag[1] <= few_tiles;
             const int supers = tail ? kTailSuper : kSuper, rounds = tail ? kTailInner : kInner;
+            const int per = tail ? kTailPer : kPer;
             for (int s = 0; s < supers; s++)
                 for (int colour = 0; colour < 4; colour++)
-                    hipLaunchKernelGGL(k_cut_discharge, dgrid, block, 0, c->stream, P, act, flags, gc, hmax, colour, tiles_x, tiles_y, rounds);
+                    if (per == 1)      hipLaunchKernelGGL(k_cut_discharge<1>, dgrid, dim3(BX, kDisRows), 0, c->stream, P, act, flags, gc, hmax, colour, tiles_x, tiles_y, rounds);
+                    else if (per == 2) hipLaunchKernelGGL(k_cut_discharge<2>, dgrid, dim3(BX, kDisRows / 2), 0, c->stream, P, act, flags, gc, hmax, colour, tiles_x, tiles_y, rounds);
+                    else               hipLaunchKernelGGL(k_cut_discharge<4>, dgrid, dim3(BX, kDisRows / 4), 0, c->stream, P, act, flags, gc, hmax, colour, tiles_x, tiles_y, rounds);
             SFA_TRY(relabel_and_mark());
         }
         hipLaunchKernelGGL(k_cut_labels, grid, block, 0, c->stream, occ, occ_es, P, counts, gc);
