@@ -245,7 +245,7 @@ def measured_traffic(batch, kernel=None):
                 continue
             # a counter file taken from another kernel (shape) says nothing about this run: refuse it
             def norm(k):
-                return k.replace("void ", "").replace("sfa::", "").replace(" ", "").split("(")[0]
+                return k.replace("void ", "").replace("sfa::", "").split("(")[0].replace(" ", "")
             if kernel is not None and t.get("kernel") and norm(t["kernel"]) != norm(kernel):
                 continue
             valu = None
@@ -605,12 +605,14 @@ def main():
                                    "symmetric window, modified-L1 penalties, thresholds off",
                        "frame_windows_per_gpu": B, "streams": S, "windows_per_launch": BL, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
                        "parallelism": f"frame-window data parallel x{world}" + ("" if backend == "nccl" or world == 1 else f" (REHEARSAL over {backend}: ranks share {ndev} GPU(s))")},
-            # What bounds the solver: NOT bandwidth.  A kernel that fuses all K sweeps of a band re-reads nothing, so the 8(d) byte model
-            # (44 K + 12 bytes per pixel: every sweep re-reads its operands) gives frac > 1; the launch is as long as the dependency chain of the
-            # reference's raster order: W + H + 2K hyperplane steps at the finest level, each a chain of ~14 dependent packed operations + one DPP
-            # shift (~150 cycles, tools/ubench/valu_rates.hip), plus what the hand-overs between workgroups add.  `frac` stays the 8(d) figure;
+            # What bounds the solver: NOT bandwidth.  A kernel that fuses the sweeps of a band re-reads little, so the 8(d) byte model
+            # (44 K + 12 bytes per pixel: every sweep re-reads its operands) gives frac > 1.  Few windows per launch: the launch is as long as the dependency
+            # chain of the reference's raster order (W + H + 2K hyperplane steps at the finest level, each a chain of ~14 dependent packed operations + one DPP
+            # shift, ~150 cycles, plus the start-up skew of the bands).  Many windows (the bench's 64 per launch): the issue rate of the compute waves --
+            # one workgroup per CU (its operand ring fills the LDS), five compute waves, each issuing an instruction every 5-8 cycles: a build whose I/O waves
+            # only walk the barriers needs 94 % of the real kernel's time, one without operand loads 97 %.  `frac` stays the 8(d) figure;
             # the physical picture is in hbm_physical / traffic_over_compulsory, the latency picture in the sor_1024x436_* entries.
-            "roofline": {"bound": "dependency-latency", "kernel": sor_kernel + " (the shape the library picked for %d windows per launch; single solves and small batches: k_sor_chain)" % BL,
+            "roofline": {"bound": "dependency-latency (wave issue rate at this batch size: compute-only build = 0.94 of the launch; DESIGN.md 5.1b)", "kernel": sor_kernel + " -- the shape the library picked for %d windows per launch" % BL,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),

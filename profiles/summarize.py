@@ -66,7 +66,9 @@ for k in sorted(set(fetch) | set(write)):
     fb = 2 * 1024 * sum(fz) / max(len(fz), 1)
     wb = 1024 * sum(wz) / max(len(wz), 1)
     res["kernels"][k] = {"dispatches": len(fz), "fetch_bytes_per_launch_x2": round(fb), "write_bytes_per_launch": round(wb), "traffic_bytes_per_launch": round(fb + wb)}
-sor = [k for k in res["kernels"] if "k_sor_band" in k]
+# the solver kernel of the path: the k_sor_* kernel that moves the most bytes over the run (the lone-window sections launch another shape a few times)
+sor = sorted((k for k in res["kernels"] if "k_sor_" in k and "prepare" not in k and "finish" not in k),
+             key=lambda k: -res["kernels"][k]["traffic_bytes_per_launch"] * res["kernels"][k]["dispatches"])
 if sor:
     res["traffic_bytes_per_launch"] = res["kernels"][sor[0]]["traffic_bytes_per_launch"]
     res["kernel"] = sor[0]
@@ -96,7 +98,7 @@ try:
             n = len(v.get("SQ_WAVE_CYCLES", v.get("SQ_WAVES", [])))
             f.write('"%s",%d,' % (k, n) + ",".join("%.0f" % m[x] for x in names) + ",%.4f,%.4f,%.4f,%.4f\n" % (valu, conf, act, wait))
             sqj["kernels"][k] = {"valu_active_frac": round(valu, 4), "lds_conflict_frac": round(conf, 4), "wave_active_frac": round(act, 4), "wave_wait_frac": round(wait, 4)}
-    sor_k = [k for k in sqj["kernels"] if "k_sor_band" in k]
+    sor_k = [k for k in sqj["kernels"] if k == res.get("kernel")] or [k for k in sqj["kernels"] if "k_sor_band" in k]
     if sor_k:
         sqj["valu_busy_frac"] = sqj["kernels"][sor_k[0]]["valu_active_frac"]
         sqj["kernel"] = sor_k[0]

@@ -949,6 +949,7 @@ int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX);
 int chain_ch();
 int chain_shift(int id);
+void chain_kernel_name(int id, int NG, char *buf, size_t n);
 int chain_flag_stride();
 int chain_ah();
 int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float omega);
@@ -1159,7 +1160,7 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
     a.ntasks = ws.ntasks; a.nwords = ws.nwords; a.nb = g.nb; a.omega = omega; a.active = g.active; a.amask = g.amask;
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
     if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
-    if (ws.chain) snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_chain shape %d (%d groups of stages per band)", ws.chain, ws.NG);
+    if (ws.chain) chain_kernel_name(ws.chain, ws.NG, c->sor_kernel, sizeof c->sor_kernel);
     else if (ws.band == 43) snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_band_mixed<4,6,3,2,4,12,16>");
     else if (ws.band) snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_band<%d>", ws.F);
     else snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_solve<%d,%d>", ws.F, ws.CHK);

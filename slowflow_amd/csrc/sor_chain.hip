@@ -844,6 +844,16 @@ bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
     return false;
 }
 int chain_ch() { return kChainCH; }
+// the kernel's name as the profiler prints it (bench.py matches counter files against it)
+void chain_kernel_name(int id, int NG, char *buf, size_t n) {
+    for (const ChainShapeInfo &s : kChainShapes)
+        if (s.id == id) {
+            snprintf(buf, n, "k_sor_chain<%d,%d,%d,%d,%d,%d,%d,%d,%d> (%d stages of %d sweeps, %d groups per band)", s.FA, s.NA, s.FB, s.NB_, kChainCH, s.PD, kChainAH, kChainPL, kChainPUBD,
+                     s.NA + s.NB_, s.FA, NG);
+            return;
+        }
+    snprintf(buf, n, "k_sor_chain shape %d", id);
+}
 // extra chunks per stage a shape needs because its groups start early (operand ring)
 template <int FA, int NA, int FB, int NB_> static int shape_shift() { using S = ChainShape<FA, NA, FB, NB_>; return ChainLds<S, kChainCH>::OPRING ? chain_start_shift(S::KG) : 0; }
 int chain_shift(int id) {
