@@ -24,6 +24,7 @@
 //
 // Deadlock freedom: tickets are drawn in ascending 3 b + g, every dependency has a smaller ticket; only the I/O wave ever waits for
 // another workgroup, and a wait that gives up (bounded) poisons the run (error word) but still walks through every barrier.
+#include <atomic>
 #include "sfa_internal.h"
 #include "sfa_device.h"
 #include "sor_device.h"
@@ -878,10 +879,12 @@ static void chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
     using L = ChainLds<S, kChainCH>;
     size_t lds = L::total;
     if (const char *e = getenv("SFA_CHAIN_LDS")) lds = std::max(lds, (size_t)atoi(e));      // experiment: a larger request limits the workgroups per CU
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
+    // more than 64 KB of dynamic LDS has to be allowed per function AND per device (the driver refines on several GPUs from one process, one thread each)
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << (c->device & 63);
+    if (lds > 64 * 1024 && !(attr_set.load(std::memory_order_relaxed) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>), dim3(nwg), dim3((S::NW + 2) * 64), lds, c->stream, a);
 }
