@@ -225,6 +225,30 @@ def test_sor_golden(ctx, w, h):
         assert np.array_equal(s["dv"][:, :w], G[f"sor_{w}x{h}_K{K}_dv"][:, :w])
 
 
+@pytest.mark.parametrize("nb,shape", [(1, "k_sor_chain<1,5,1,0"), (8, "k_sor_chain<1,5,1,0"), (16, "k_sor_chain<3,5,3,0"), (64, "k_sor_chain<3,5,3,0")])
+def test_default_solver_shape_and_its_bits(ctx, oracle, nb, shape):
+    """what the library launches by default at 1024x436 x 30 for 1 / 8 / 16 / 64 systems per launch (round 3: the chain kernel with the operand ring at every
+    batch size -- five stages of one sweep up to 96 bands per launch, five stages of three above), and that the first and the last system of the launch are
+    the raster-order oracle's bits"""
+    w, h, K = 1024, 436, 30
+    rng = np.random.default_rng(100 + nb)
+    systems = [sor_system(rng, w, h) for _ in range(2)]
+    sb = sfa.SorBatch(ctx, w, h, nb)
+    for b in range(nb):
+        sb.upload(b, *[c_(systems[b % 2][k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    ctx.profile_enable(True)
+    sb.run(K, 1.9)
+    kernel = ctx.profile_read_kernels()[3]
+    ctx.profile_enable(False)
+    assert kernel.startswith(shape), kernel
+    for b in sorted({0, nb - 1}):
+        a = copy_sys(systems[b % 2])
+        oracle.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, K, 1.9)
+        du, dv = sb.download(b)
+        assert np.array_equal(valid(a["du"], w), valid(du, w)) and np.array_equal(valid(a["dv"], w), valid(dv, w)), b
+    sb.close()
+
+
 def test_sor_full_size_and_batch(ctx, oracle):
     """1024x436, K=30 (the metric's configuration): bit-identical to the raster-order oracle, for every element of a
     batch of different systems solved by one launch; repeated runs are deterministic."""
