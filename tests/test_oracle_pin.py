@@ -294,7 +294,8 @@ def test_compute_one_level_forward_is_the_two_frame_variational(oracle, reflib, 
     derivatives (which only enter squared or in pairs), the same weights written as alpha*psi'(x) = alpha/(2 sqrt(x+eps^2)) instead of
     half_alpha/sqrt(x+eps), mask weights 1 (occ = -1, data_norm = 1), sub_laplacian on uu == wx.  The two differ by rounding order only
     (near-pins of smoothness 4e-7 and data term 2e-6, amplified through the outer iterations: SURVEY H3 measured <= 2e-5 for 5e-7
-    per solve); the bound asserted is north_star's own 1e-4 on (u, v)."""
+    per solve).  Measured on these nine cases: 9.5e-7 .. 1.2e-5; the bound asserted is 2.5e-5, a quarter of north_star's 1e-4 on (u, v), so that a
+    restatement slip of half the acceptance tolerance in the level's glue does not pass."""
     rng = np.random.default_rng(w + h)
     base = smooth_noise_color(rng, w + 8, h + 8, 40)
     st = orc.stride_of(w)
@@ -322,7 +323,7 @@ def test_compute_one_level_forward_is_the_two_frame_variational(oracle, reflib, 
     assert rc == 0
     d = max(np.abs(valid(wxo, w) - valid(wxr, w)).max(), np.abs(valid(wyo, w) - valid(wyr, w)).max())
     moved = np.abs(valid(wxr, w) - valid(wx0, w)).max()
-    assert moved > 1e-3 and d <= 1e-4, (d, moved)
+    assert moved > 1e-3 and d <= 2.5e-5, (d, moved)
     # and the whole entry point with one layer is that level
     wxv, wyv = orc.plane(h, st), orc.plane(h, st)
     wxv[...] = wx0; wyv[...] = wy0
