@@ -929,6 +929,32 @@ def test_batch_with_thresholds_keeps_every_window_exact(ctx, oracle):
     assert np.abs(alone[0][0]).max() < 1e-3                                                 # the still window did stop early (and stayed put)
 
 
+def test_full_batch_of_64_with_thresholds(ctx, oracle):
+    """the largest lockstep batch (64 windows: every bit of the device-side mask in use) under break thresholds: windows that stop at different outer
+    iterations, each with the result it gets alone"""
+    w, h = 130, 98
+    sets = [normalized_frames(oracle, w, h, 3, seed=s)[0] for s in (1, 2)]
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=3)
+    still = [frames[1], frames[1], frames[1]]
+    kinds = [still, sets[0], sets[1], frames]
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=8, layers=2, thres_outer=2e-3, thres_inner=1e-3)
+    alone = []
+    for f in kinds:
+        j1 = sfa.Job(ctx, ps, w, h, 1)
+        j1.upload(0, [c_(x) for x in f]); j1.run()
+        alone.append(j1.download(0))
+        j1.close()
+    job = sfa.Job(ctx, ps, w, h, 64)
+    for b in range(64):
+        job.upload(b, [c_(x) for x in kinds[(b * 7 + b // 4) % 4]])
+    job.run()
+    for b in (0, 1, 2, 3, 31, 32, 62, 63):
+        gx, gy, chg = job.download(b)
+        ref = alone[(b * 7 + b // 4) % 4]
+        assert np.array_equal(gx, ref[0]) and np.array_equal(gy, ref[1]) and chg == ref[2], b
+    job.close()
+
+
 def test_job_can_be_run_again_and_slots_reused(ctx, oracle):
     """a resident job is reused: run(); run() gives run() -- also with presmoothing (cfg sigma > 0), which replaces the uploaded frames once
     per upload -- and a slot that held channel weights forgets them when the next window comes without"""
