@@ -314,52 +314,109 @@ def cfg_schedule_sample(ctx, B=16):
                 p.niter_alter, p.niter_outer, p.niter_inner, p.niter_solver, p.thres_outer, p.thres_inner, p.occlusion_reasoning, p.layers)}
 
 
-def config4_strong(ctxs, dev, world, rank, dist, xdev, total_windows=128):
-    """BASELINE config 4 as north_star states it: a FIXED set of 128 frame windows (64 jets x 2 directions, slow_flow.cpp:706) under the cfg's
-    schedule (cfgs/slow_flow.cfg: S = 3, 5 levels, 10 alternations x 10 outer x 30 sweeps, occlusion reasoning, break thresholds 1e-5), partitioned
-    over the ranks (shard.partition: contiguous blocks, no data-path collective) -- STRONG scaling: 128 windows on one GPU, 16 per GPU on eight.
-    Wall time = max over ranks of one resident refinement of the rank's share (each rank's windows in len(ctxs) lockstep groups)."""
+def run_groups(work, n):
+    """work(g) for g in range(n) on one host thread each; an exception in any of them is re-raised here after every thread has ended
+    (threading.Thread swallows it otherwise, and a failed refinement would still be timed)"""
     import threading
+    errs = [None] * n
+
+    def guarded(g):
+        try:
+            work(g)
+        except BaseException as e:                    # re-raised below
+            errs[g] = e
+    if n == 1:
+        guarded(0)
+    else:
+        th = [threading.Thread(target=guarded, args=(g,)) for g in range(n)]
+        for t in th: t.start()
+        for t in th: t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+
+
+def strong_section(ctxs, world, rank, dist, xdev, total_windows, make_params, w, h, n_frames, label):
+    """A FIXED set of frame windows partitioned over the ranks (shard.partition: contiguous blocks, no data-path collective) -- STRONG scaling.
+    Wall time = max over ranks of one resident refinement of the rank's share (each rank's windows in len(ctxs) lockstep groups).
+    Everything that can fail (allocation, upload, the refinement) runs under try on every rank and only sets a flag; the collectives (two barriers, the
+    max of the seconds, the min of the flags) are then reached by EVERY rank in the same order, failed or not, so one rank's error can never leave
+    the others waiting in a collective."""
     from slowflow_amd import shard
     lo, hi = shard.partition(total_windows, world, rank)
     nloc = hi - lo
     S_ = len(ctxs)
-    p = sfa.default_params()
-    p.S = 3; p.layers = LAYERS; p.hbit = 0
-    p.rho[0] = 1; p.rho[1] = 1; p.omega[0] = 0; p.omega[1] = 2
-    base = [synth_window(300 + b, n=5) for b in range(4)]
-    avg, std = ctxs[0].normalize([f for w_ in base for f in w_], W)
-    for k in range(3):
-        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    jobs, err, sec, p = [], None, 0.0, None
     groups = [(nloc * g // S_, nloc * (g + 1) // S_) for g in range(S_)]
-    jobs = [sfa.Job(c, p, W, H, max(1, b1 - b0)) if b1 > b0 else None for c, (b0, b1) in zip(ctxs, groups)]
-    for job, (b0, b1) in zip(jobs, groups):
-        for b in range(b1 - b0):
-            job.upload(b, base[(lo + b0 + b) % len(base)])
 
     def run_all():
         def work(g):
             if jobs[g] is not None:
                 jobs[g].run(); ctxs[g].sync()
-        th = [threading.Thread(target=work, args=(g,)) for g in range(S_)]
-        for t in th: t.start()
-        for t in th: t.join()
-    run_all()                                         # warm-up (workspaces, first-touch)
+        run_groups(work, S_)
+    try:
+        p = make_params()
+        base = [synth_window(300 + b, n=n_frames, w=w, h=h) for b in range(4)]
+        avg, std = ctxs[0].normalize([f for w_ in base for f in w_], w)
+        for k in range(3):
+            p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+        jobs = [sfa.Job(c, p, w, h, max(1, b1 - b0)) if b1 > b0 else None for c, (b0, b1) in zip(ctxs, groups)]
+        for job, (b0, b1) in zip(jobs, groups):
+            for b in range(b1 - b0):
+                job.upload(b, base[(lo + b0 + b) % len(base)])
+        run_all()                                     # warm-up (workspaces, first-touch)
+    except Exception as e:
+        err = "rank %d: %s" % (rank, str(e)[:160])
     if dist is not None:
         dist.barrier()
-    t0 = time.perf_counter()
-    run_all()
-    sec = time.perf_counter() - t0
+    if err is None:
+        try:
+            t0 = time.perf_counter()
+            run_all()
+            sec = time.perf_counter() - t0
+        except Exception as e:
+            err = "rank %d: %s" % (rank, str(e)[:160])
     if dist is not None:
         dist.barrier()
     sec_max = shard.max_over_ranks(dist, sec, device=xdev)
+    failed_ranks = int(round(shard.sum_over_ranks(dist, 0.0 if err is None else 1.0, device=xdev)))
+    windows_seen = int(round(shard.sum_over_ranks(dist, float(nloc), device=xdev)))
+    per_rank = shard.gather_timings(dist, {rank: sec}, world, device=xdev)
     for job in jobs:
         if job is not None:
             job.close()
-    return {"windows_total": total_windows, "windows_this_rank": nloc, "groups_per_rank": S_, "n_gpus": world, "seconds": round(sec_max, 4),
+    if failed_ranks:
+        return {"error": err or "%d other rank(s) failed" % failed_ranks, "failed_ranks": failed_ranks, "n_gpus": world, "workload": label}
+    return {"workload": label, "windows_total": total_windows, "windows_this_rank": nloc, "windows_all_ranks": windows_seen, "groups_per_rank": S_, "n_gpus": world,
+            "seconds": round(sec_max, 4), "seconds_per_rank": [round(float(v), 4) for v in per_rank],
             "windows_per_second": round(total_windows / sec_max, 2), "scaling": "strong",
-            "schedule": "cfgs/slow_flow.cfg: S=3 (5 frames), %d levels, %d alternations x %d outer x %d inner x %d sweeps, thresholds %g / %g, occlusion reasoning %d" % (
-                p.layers, p.niter_alter, p.niter_outer, p.niter_inner, p.niter_solver, p.thres_outer, p.thres_inner, p.occlusion_reasoning)}
+            "schedule": "S=%d (%d frames), %d levels, %d alternations x %d outer x %d inner x %d sweeps, thresholds %g / %g, occlusion reasoning %d, penalties %d/%d/%d" % (
+                p.S, 2 * p.S - 1, p.layers, p.niter_alter, p.niter_outer, p.niter_inner, p.niter_solver, p.thres_outer, p.thres_inner, p.occlusion_reasoning,
+                p.robust_color.id, p.robust_grad.id, p.robust_reg.id)}
+
+
+def config4_strong(ctxs, dev, world, rank, dist, xdev, total_windows=128):
+    """BASELINE config 4 as north_star states it: a FIXED set of 128 frame windows (64 jets x 2 directions, slow_flow.cpp:706) under the cfg's
+    schedule (cfgs/slow_flow.cfg: S = 3, 5 levels, 10 alternations x 10 outer x 30 sweeps, occlusion reasoning, break thresholds 1e-5):
+    128 windows on one GPU, 16 per GPU on eight."""
+    def make():
+        p = sfa.default_params()
+        p.S = 3; p.layers = LAYERS; p.hbit = 0
+        p.rho[0] = 1; p.rho[1] = 1; p.omega[0] = 0; p.omega[1] = 2
+        return p
+    return strong_section(ctxs, world, rank, dist, xdev, total_windows, make, W, H, 5, "BASELINE configs[3]: cfgs/slow_flow.cfg schedule over 64 jets x 2 directions at 1024x436")
+
+
+def config5_strong(ctxs, dev, world, rank, dist, xdev, total_windows=32):
+    """BASELINE config 5: 2048 x 2048 synthetic sequence, 6 pyramid levels, Lorentzian penalties (data and smoothness), S = 2, fixed work
+    (5 outer x 30 sweeps per level): a FIXED set of 32 windows over the ranks (32 on one GPU: what the arena of 1.63 GB per window allows in
+    two groups of 16; 4 per GPU on eight)."""
+    def make():
+        p = bench_params()
+        p.layers = 6
+        p.robust_color.id = 2; p.robust_grad.id = 2; p.robust_reg.id = 2
+        return p
+    return strong_section(ctxs, world, rank, dist, xdev, total_windows, make, 2048, 2048, 3, "BASELINE configs[4]: 2048x2048, 6 levels, Lorentzian penalties, 5 outer x 30 sweeps")
 
 
 def sor_launch(ctx, B, rank, reps=20):
@@ -544,14 +601,7 @@ def main():
             for _ in range(n):
                 jobs[g].run()
             ctxs[g].sync()
-        if S == 1:
-            work(0)
-            return
-        th = [threading.Thread(target=work, args=(g,)) for g in range(S)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        run_groups(work, S)
 
     run_all(args.warmup)
     barrier()
@@ -583,12 +633,11 @@ def main():
     if not args.path_only:
         n1, ms1, by1, n2, ms2, by2 = sor_only(ctx, BL, rank)
         sor16 = sor_launch(ctx, 16, rank)            # what one GPU of an 8-GPU node gets of config 4's 128 windows
-    strong = None
+    # the strong-scaling sections: every rank walks the same collectives whether its own share worked or not (strong_section), so nothing here may raise
+    # between them; the bench's own jobs are closed first -- config 5's 32 windows need the memory
+    strong = strong5 = None
     if not args.no_strong and not args.path_only:
-        try:
-            strong = config4_strong(ctxs, dev, world, rank, dist, xdev)
-        except Exception as e:                        # a reported extra
-            strong = {"error": str(e)[:200]}
+        strong = config4_strong(ctxs, dev, world, rank, dist, xdev)
     if rank == 0:
         total = mpix_iters * args.steps * world
         value = total / elapsed_max

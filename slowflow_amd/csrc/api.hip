@@ -223,7 +223,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     // kernel (the solver included) leaves the windows without a bit alone.  The host never waits for the iteration it has just queued: it reads the mask
     // of kLag iterations ago (a superset -- windows only ever leave) to stop queueing once nothing iterates any more, so the GPU always has work queued
     // and at most kLag iterations of empty launches follow the last window's break.  One blocking read per level (the norms), not one per iteration.
-    constexpr int kLag = 2, kRing = 4;
+    constexpr int kLag = kMaskLag, kRing = kMaskRing;
     static const bool dbg = getenv("SFA_DEBUG_ACTIVE") != nullptr;
     g.amask = c->d_amask;
     SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double), c->stream));
@@ -429,7 +429,7 @@ int sfa_ctx_create(int device, sfa_ctx **out) {
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, 2 * kMaxBatch * sizeof(double) + 64, hipHostMallocDefault));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_amask, 64));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double)));
-    SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, kMaskRing * sizeof(unsigned long long), hipHostMallocDefault));
     for (auto &e : c->ev_mask) SFA_HIP(c.get(), hipEventCreateWithFlags(&e, hipEventDisableTiming));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_err, 64));
     SFA_HIP(c.get(), hipMemset(c->d_err, 0, 64));

@@ -849,11 +849,29 @@ namespace sfa {
 #else
 #define AT_MARK(i)
 #endif
+// LDS-DMA issued from inline assembly (global_load_lds_dwordx4: every lane's 16 bytes land at M0 + 16 * lane).  The builtin form made the compiler's wait-count
+// pass put an `s_waitcnt vmcnt(0)` INSIDE the issue loops (a register of the address arithmetic had a load pending), so every wave-instruction waited for the
+// one before it: one exposed memory round trip per piece, 30 % of the kernel's wave time (round-4 ISA reading).  The assembly form is invisible to that pass:
+// nothing waits until the explicit `dma_wait` below.  Untracked DMA is safe next to tracked loads: vmcnt retires in order, so a compiler-made wait for an older
+// load is unaffected and one for a younger load over-waits.  M0 is not used by anything else in the kernels that call this.
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p; }
+__device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte) : "memory");
+}
+
 // TY rows x 64 columns per block of NT threads (NT/64 rows in flight, TY*64/NT pixels per thread).
 // Column borders: the staged planes carry REPLICATED columns outside the image, so the clamped taps of image.c:501-516
 // become fixed LDS offsets.  Row borders use folded coefficients (different expressions, image.c:433-457): rows are
 // wave-uniform here, so that is a scalar branch.
-template <int TY, int NT, int MINB, bool ZUV>
+// FAST: the cfg's defaults as compile-time constants (normalised data term, modified-L1 penalties, no channel weights): the same arithmetic with the
+// penalty switch and the weight planes folded away -- fewer live registers, no spills (a spill reload is a vector-memory instruction, and a wait for it is a
+// wait for every DMA issued before it).
+// timing-only what-if builds (-DSFA_X_AI=bits, wrong results by construction, never shipped; tools/README.md): 1 no image DMA, 2 no conversion pass,
+// 4 no stage 1, 8 single reads instead of the second-derivative taps, 16 no term arithmetic, 32 no epilogue DMA, 64 no operand stores, 128 no prologue / mask loads
+#ifndef SFA_X_AI
+#define SFA_X_AI 0
+#endif
+template <int TY, int NT, int MINB, bool ZUV, bool FAST>
 __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, const float *__restrict__ base, float *__restrict__ a11, float *__restrict__ a12,
                                                               float *__restrict__ a22, float *__restrict__ b1, float *__restrict__ b2,
                                                               const float *__restrict__ du, const float *__restrict__ dv, const float *__restrict__ uu,
@@ -889,30 +907,31 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     const int tx = threadIdx.x & 63;
     const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // one row per wave
     const int x = x0 + DT_H + tx;
+    const int dt_norm = FAST ? 1 : a.dt_norm;
+    PenaltyDev pcolor = a.color, pgrad = a.grad;
+    if (FAST) { pcolor.id = 1; pgrad.id = 1; }
     Acc A[NP];
-    float u[NP], v[NP], wk[NP][3], fwd[NP], bwd[NP];
+    float u[NP], v[NP], wk[NP][3], fwd[NP], bwd[NP], oc[NP];
     bool ok[NP];
+    // Every per-pixel global load of the prologue is only ISSUED here; the values are first looked at behind the wait for the first image DMA, so their
+    // round trip runs beside it (before: a wait of its own in front of the DMA issue, 12 % of the wave time).
 #pragma unroll
     for (int k = 0; k < NP; k++) {
         const int y = y0 + DT_H + ty + NR * k;
         ok[k] = x < g.w && y < g.h;
         A[k].a11 = A[k].a12 = A[k].a22 = A[k].b1 = A[k].b2 = 0.0f;                    // image_erase, variational_mt.cpp:336-340
-        u[k] = v[k] = 0.0f; fwd[k] = bwd[k] = 0.0f;
+        u[k] = v[k] = 0.0f; fwd[k] = bwd[k] = 0.0f; oc[k] = 0.0f;
         wk[k][0] = wk[k][1] = wk[k][2] = 1.0f;
         if (!ok[k]) continue;
         const size_t o = (size_t)y * g.pitch + x;
         if (!ZUV) { u[k] = du[eb + o]; v[k] = dv[eb + o]; }
-        if (a.chw) {                                                                   // see k_assemble
+        if (!FAST && a.chw) {                                                          // see k_assemble
             const unsigned lin = (unsigned)y * (unsigned)a.lstride + (unsigned)x;      // < 2^31: checked where the weights are attached
             const unsigned r0 = lin / (unsigned)a.chw_stride0, c0 = lin % (unsigned)a.chw_stride0;
             const float *cw = a.chw + b * a.chw_es + r0 * a.chw_pitch + c0;
             wk[k][0] = cw[0]; wk[k][1] = cw[a.chw_pl]; wk[k][2] = cw[2 * a.chw_pl];
         }
-        const float oc = occ[eb + o];                                                  // k_mask_weight
-        float factor = (oc == 0.0f) ? 1.0f : 0.0f;
-        factor = (1 + factor) * a.data_norm;
-        bwd[k] = __fdiv_rn((oc >= 0.0f) ? 1.0f : 0.0f, factor);
-        fwd[k] = __fdiv_rn((oc <= 0.0f) ? 1.0f : 0.0f, factor);
+        if (!(SFA_X_AI & 128)) oc[k] = occ[eb + o];                                   // k_mask_weight
     }
     constexpr int QM = DT_W / 4, Q1 = AT_W1 / 4;                     // float4 quads per staged row
     // global -> LDS by DMA like the image quads: rows y-1 .. y+TY of the four planes, the 18 aligned quads that cover columns x0 .. x0+71.  Quads outside
@@ -925,13 +944,13 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             const int q = item % QM, row = (item / QM) % GR, pl = item / (QM * GR);
             const int gy = y0 + DT_H - 1 + row, gx = x0 + 4 * q;
             const float *src = pl == 0 ? uu : pl == 1 ? vv : pl == 2 ? sh : sv;
-            if (item < NGQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.pitch && (pl >= 2 || a.do_laplacian))
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + eb + (size_t)gy * g.pitch + gx),
-                                                 (__attribute__((address_space(3))) void *)(lds + 4 * (i0 + 64 * ty)), 16, 0, 0);
+            if (!(SFA_X_AI & 32) && item < NGQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.pitch && (pl >= 2 || a.do_laplacian))
+                dma16(src + eb + (size_t)gy * g.pitch + gx, lds_addr(lds + 4 * (i0 + 64 * ty)));
         }
     };
     AT_MARK(13);
     if (a.n == 0) stage_epilogue_operands();
+    float mk2[2][NP];                                                  // the raw warp masks of the staged pair of terms
     for (int t = 0; t < a.n; t++) {
         const Term &T = a.t[t];
         const int ub = t & 1;                                      // staging buffer of this term
@@ -951,6 +970,13 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         const int npair = t + 1 < a.n ? 2 : 1;
         constexpr int NSQ = 3 * TR * QM, NSI = (NSQ + 63) / 64;        // quads / wave-instructions per image set
         const Term &T0 = a.t[t], &T1 = a.t[t + npair - 1];
+        // the masks of both terms: issued in front of the DMA, looked at behind its wait
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const size_t o = (size_t)(y0 + DT_H + ty + NR * k) * g.pitch + x;
+            mk2[0][k] = ok[k] && !(SFA_X_AI & 128) ? base[eb + T0.mask_off + o] : 0.0f;
+            mk2[1][k] = ok[k] && !(SFA_X_AI & 128) ? base[eb + T1.mask_off + o] : 0.0f;
+        }
         // where the next term's I1 / I2 come from: 0 this term's I1, 1 this term's I2, 2 own fetch
         const int from_a = npair == 2 ? (T1.i1_off == T0.i1_off ? 0 : T1.i1_off == T0.i2_off ? 1 : 2) : 0;
         const int from_b = npair == 2 ? (T1.i2_off == T0.i1_off ? 0 : T1.i2_off == T0.i2_off ? 1 : 2) : 0;
@@ -963,18 +989,33 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 const int k = part * 64 + tx;
                 const int q = k % QM, ly = (k / QM) % TR, ch = k / (QM * TR);
                 const int gy = y0 + ly, gx = x0 + 4 * q;
-                if (k < NSQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.w)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(base + eb + set_src[set] + (size_t)ch * g.pl + (size_t)gy * g.pitch + gx),
-                        (__attribute__((address_space(3))) void *)(lds + set_dst[set] + 256 * part), 16, 0, 0);      // the hardware adds 16 bytes per lane
+                if (!(SFA_X_AI & 1) && k < NSQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.w)
+                    dma16(base + eb + set_src[set] + (size_t)ch * g.pl + (size_t)gy * g.pitch + gx, lds_addr(lds + set_dst[set] + 256 * part));
             }
         }
         AT_MARK(2);
+        // everything issued so far has landed behind this wait: the DMA pieces and the prologue's / the masks' loads (tied to it through the operand list,
+        // so that no use of them can be scheduled, and waited for, in front of the DMA issue)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            asm volatile("" : "+v"(mk2[0][k]), "+v"(mk2[1][k]), "+v"(oc[k]));
+            if (!FAST) asm volatile("" : "+v"(wk[k][0]), "+v"(wk[k][1]), "+v"(wk[k][2]));
+            if (!ZUV) asm volatile("" : "+v"(u[k]), "+v"(v[k]));
+        }
         AT_MARK(3);
         __syncthreads();                                           // the DMA of every wave has landed
         AT_MARK(4);
-        for (int item = threadIdx.x; item < NSQ; item += NT) {     // both terms of the pair in one item: the shared image is read before it is overwritten
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {                          // k_mask_weight (variational_mt.cpp:293-320)
+                float factor = (oc[k] == 0.0f) ? 1.0f : 0.0f;
+                factor = (1 + factor) * a.data_norm;
+                bwd[k] = __fdiv_rn((oc[k] >= 0.0f) ? 1.0f : 0.0f, factor);
+                fwd[k] = __fdiv_rn((oc[k] <= 0.0f) ? 1.0f : 0.0f, factor);
+            }
+        }
+        for (int item = threadIdx.x; item < ((SFA_X_AI & 2) ? 0 : NSQ); item += NT) {     // both terms of the pair in one item: the shared image is read before it is overwritten
             const int q = item % QM, ly = (item / QM) % TR, ch = item / (QM * TR);
             const int gy = y0 + ly, gx = x0 + 4 * q;
             if (gy < 0 || gy >= g.h) continue;
@@ -1004,7 +1045,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         __syncthreads();                                           // staged planes complete / the previous term is done with Ix, Iy
         AT_MARK(6);
         // stage 1: Ix, Iy on the halo-2 region, four columns per item (two aligned quads of M per tap row)
-        for (int item = threadIdx.x; item < AT_R1 * 3 * Q1; item += NT) {
+        for (int item = threadIdx.x; item < ((SFA_X_AI & 4) ? 0 : AT_R1 * 3 * Q1); item += NT) {
             const int q = item % Q1, ch = (item / Q1) % 3, ly = item / (3 * Q1);
             const int gy = y0 + 2 + ly, gx = x0 + 2 + 4 * q;
             if (gy < 0 || gy >= g.h) continue;
@@ -1037,18 +1078,11 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             *reinterpret_cast<float4 *>(&sX[ch][ly * AT_W1 + 4 * q]) = make_float4(X[0], X[1], X[2], X[3]);
             *reinterpret_cast<float4 *>(&sY[ch][ly * AT_W1 + 4 * q]) = make_float4(Y[0], Y[1], Y[2], Y[3]);
         }
-        float mk[NP];
-#pragma unroll
-        for (int k = 0; k < NP; k++) mk[k] = ok[k] ? base[eb + T.mask_off + (size_t)(y0 + DT_H + ty + NR * k) * g.pitch + x] : 0.0f;
         AT_MARK(7);
         __syncthreads();
         AT_MARK(8);
-        if (t == a.n - 1) {
-            // no ordinary load may be outstanding while the DMA flies (the compiler would wait for everything at its first use)
-#pragma unroll
-            for (int k = 0; k < NP; k++) asm volatile("" : "+v"(mk[k]));
-            stage_epilogue_operands();
-        }
+        // the last term's arithmetic runs beside the DMA of the epilogue's operands: no vector-memory instruction may follow until the wait behind the loop
+        if (t == a.n - 1) stage_epilogue_operands();
 #pragma unroll
         for (int k = 0; k < NP; k++) {
             const int y = y0 + DT_H + ty + NR * k;
@@ -1057,7 +1091,10 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             const int c = (ty + NR * k + 2) * AT_W1 + (tx + 2);   // halo-2 planes (Ix, Iy)
             const int cz = (ty + NR * k + 4) * DT_W + (tx + 4);   // halo-4 plane (Iz)
             Px p;
-            if (y_in) {
+            if (SFA_X_AI & 8) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) { p.ixy[ch] = sX[ch][c + 1]; p.iyy[ch] = sY[ch][c + 1]; p.iyz[ch] = sZ[ch][cz + 1]; }
+            } else if (y_in) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     p.ixy[ch] = d5y_in<AT_W1>(sX[ch], c);                              // :130
@@ -1077,16 +1114,20 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                p.wk[ch] = wk[k][ch];
+                p.wk[ch] = FAST ? 1.0f : wk[k][ch];
                 p.ix[ch] = sX[ch][c]; p.iy[ch] = sY[ch][c]; p.iz[ch] = sZ[ch][cz];
-                p.ixx[ch] = d5x_in<AT_W1>(sX[ch], c);                                  // :129
-                p.ixz[ch] = d5x_in<DT_W>(sZ[ch], cz);                                  // :132
+                p.ixx[ch] = (SFA_X_AI & 8) ? sX[ch][c - 1] : d5x_in<AT_W1>(sX[ch], c);   // :129
+                p.ixz[ch] = (SFA_X_AI & 8) ? sZ[ch][cz - 1] : d5x_in<DT_W>(sZ[ch], cz);  // :132
             }
             if (!ok[k]) continue;
-            float m = mk[k];
+            float m = mk2[ub][k];
             if (!a.one_direction || !T.backward) m = T.backward ? 1.0f * bwd[k] * m : 1.0f * fwd[k] * m;   // :314,316
-            if (T.is_ref) term_ref<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
-            else          term_succ<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, a.dt_norm, a.color, a.grad);
+            if (SFA_X_AI & 16) {
+                for (int ch = 0; ch < 3; ch++) {
+                    A[k].a11 += p.ix[ch] + p.ixx[ch] + m; A[k].a12 += p.iy[ch] + p.ixy[ch]; A[k].a22 += p.iz[ch] + p.iyy[ch]; A[k].b1 += p.ixz[ch]; A[k].b2 += p.iyz[ch];
+                }
+            } else if (T.is_ref) term_ref<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad);
+            else          term_succ<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad);
         }
     }
     // row strides chosen for the anti-diagonal read-out below (entry 64*rl + dl of a 65-wide row puts the TY rows of a diagonal into one bank group:
@@ -1144,6 +1185,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         const int r = r0 + rl, c = c0 + cl;
         if (r >= g.h || c >= g.w) continue;
         const size_t e = (size_t)b * a.op.ent + (size_t)(c + r + a.op.G) * a.op.RP + (r + a.op.G);
+        if (SFA_X_AI & 64) continue;
         a.op.sa[e] = tA[rl][cl];
         a.op.sb[e] = tB[rl][cl];
         const float2 xv = tX[rl][cl];
@@ -1159,21 +1201,19 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
 }
 void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
-    static const int shape = getenv("SFA_ASSEMBLE_SHAPE") ? atoi(getenv("SFA_ASSEMBLE_SHAPE")) : 0;
     const bool prof = c->profile && c->ev2_used + 2 <= c->ev2.size();
     if (prof) (void)hipEventRecord(c->ev2[c->ev2_used], c->stream);
-#define SFA_LAUNCH_AI(TY, NT, MINB)                                                                                                                       \
-    do {                                                                                                                                                \
-        const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + TY - 1) / TY, g.nb);                                                                          \
-        if (a.zero_duv) hipLaunchKernelGGL((k_assemble_images<TY, NT, MINB, true>), grid_, dim3(NT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g);  \
-        else            hipLaunchKernelGGL((k_assemble_images<TY, NT, MINB, false>), grid_, dim3(NT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g); \
-    } while (0)
-    // SFA_ASSEMBLE_SHAPE=5: the taller tile (64 x 16, two pixels per thread, 209 VGPRs, one block per CU) measured slower than the default and kept for
-    // comparison; 8 x 256 threads and 16 x 1024 threads were tried in rounds 1 / 2 and dropped (the latter spills at its 128-register cap)
-    switch (shape) {
-    case 5: SFA_LAUNCH_AI(16, 512, 1); break;
-    default: SFA_LAUNCH_AI(8, 512, 4); break;
-    }
+    // the cfg's defaults (slow_flow_dataterm 1, modified-L1 penalties -- every id select_robust_function maps to the default class,
+    // variational_aux_mt.cpp:909-925 --, no channel weights) take the instance with those choices folded in
+    auto is_modl1 = [](int id) { return id != 0 && id != 2 && id != 3 && id != 4; };
+    const bool fast = a.dt_norm == 1 && is_modl1(a.color.id) && is_modl1(a.grad.id) && !a.chw && !getenv("SFA_ASSEMBLE_GENERIC");
+    const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + 8 - 1) / 8, g.nb);
+#define SFA_LAUNCH_AI(ZUV_, FAST_)                                                                                                                      \
+    hipLaunchKernelGGL((k_assemble_images<8, 512, 4, ZUV_, FAST_>), grid_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g)
+    // 64 x 8 tiles, 512 threads, 128 VGPRs (two blocks per CU).  Measured and dropped: 64 x 16 with two pixels per thread (209 VGPRs, one block per CU: slower),
+    // 8 x 256 threads, 16 x 1024 threads (spills at its 128-register cap)
+    if (a.zero_duv) { if (fast) SFA_LAUNCH_AI(true, true); else SFA_LAUNCH_AI(true, false); }
+    else            { if (fast) SFA_LAUNCH_AI(false, true); else SFA_LAUNCH_AI(false, false); }
 #undef SFA_LAUNCH_AI
     if (prof) {
         (void)hipEventRecord(c->ev2[c->ev2_used + 1], c->stream);
@@ -1345,7 +1385,11 @@ __global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict
     if (b < nb && ((cur >> b) & 1ull)) {
         const double a = red[2 * b] / npx, d = red[2 * b + 1] / npx;
         last[2 * b] = a; last[2 * b + 1] = d;
-        met = thres > 0.0f && fmaxf((float)a, (float)d) < thres;                         // :436
+        // std::max(a, d) as the reference writes it (:436): (a < d) ? d : a -- a NaN norm in `a` stays a NaN, the comparison is false and the window
+        // keeps iterating (fmaxf would drop the NaN and could declare the window converged)
+        const float fa = (float)a, fd = (float)d;
+        const float mx = (fa < fd) ? fd : fa;
+        met = thres > 0.0f && mx < thres;
     }
     const unsigned long long m = __ballot(met);
     if (b == 0) *amask = *amask & ~m;

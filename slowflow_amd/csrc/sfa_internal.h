@@ -15,6 +15,9 @@ namespace sfa {
 
 constexpr int kMaxBatch = 64;
 constexpr int kMaxTerms = 4 * SFA_MAX_REF;
+// device-side outer break (api.hip run_level): the host reads the mask of kMaskLag iterations ago from a ring of kMaskRing pinned words
+constexpr int kMaskLag = 2, kMaskRing = 4;
+static_assert(kMaskLag < kMaskRing, "a ring slot is rewritten kMaskRing iterations after it was read kMaskLag iterations late");
 
 // ---------------------------------------------------------------------------------------------------
 // context
@@ -35,7 +38,7 @@ struct sfa_ctx {
     unsigned long long *d_amask = nullptr;
     double *d_last = nullptr;                      // 2 * kMaxBatch doubles
     unsigned long long *h_amask = nullptr;         // kMaskRing pinned words
-    hipEvent_t ev_mask[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_mask[sfa::kMaskRing] = {};
     unsigned *d_err = nullptr;    // device error/timeout word
     // profiling of the SOR solve kernel
     bool profile = false;

@@ -874,19 +874,26 @@ int chain_flag_stride() { return kFlagStride; }
 int chain_ah() { return kChainAH; }
 
 template <int FA, int NA, int FB, int NB_, int PD>
-static void chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
+static int chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
     using S = ChainShape<FA, NA, FB, NB_>;
     using L = ChainLds<S, kChainCH>;
     size_t lds = L::total;
     if (const char *e = getenv("SFA_CHAIN_LDS")) lds = std::max(lds, (size_t)atoi(e));      // experiment: a larger request limits the workgroups per CU
     // more than 64 KB of dynamic LDS has to be allowed per function AND per device (the driver refines on several GPUs from one process, one thread each)
+    // the bit of a device is set only once the call has succeeded there; devices beyond the 64 bits are asked every time (the call is cheap and idempotent)
     static std::atomic<unsigned long long> attr_set{0};
-    const unsigned long long bit = 1ull << (c->device & 63);
+    const bool tracked = c->device >= 0 && c->device < 64;
+    const unsigned long long bit = tracked ? 1ull << c->device : 0ull;
     if (lds > 64 * 1024 && !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return set_error(c, SFA_ERR_HIP, "k_sor_chain<%d,%d,%d,%d>: %zu bytes of LDS per workgroup refused on device %d: %s", FA, NA, FB, NB_, lds, c->device,
+                             hipGetErrorString(e));
         attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>), dim3(nwg), dim3((S::NW + 2) * 64), lds, c->stream, a);
+    return SFA_OK;
 }
 
 int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float omega) {
@@ -899,17 +906,16 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
     a.nch = ws.NCH; a.NI = ws.NS; a.omega = omega; a.active = g.active; a.amask = g.amask;
     const int nwg = g.nb * ws.NB * ws.NG;
     switch (ws.chain) {
-        case 1: chain_launch_shape<1, 3, 1, 0, 4>(c, a, nwg); break;
-        case 2: chain_launch_shape<2, 3, 2, 0, 2>(c, a, nwg); break;
-        case 3: chain_launch_shape<3, 5, 3, 0, 2>(c, a, nwg); break;
-        case 5: chain_launch_shape<2, 5, 2, 0, 2>(c, a, nwg); break;
-        case 6: chain_launch_shape<1, 5, 1, 0, 4>(c, a, nwg); break;
-        case 8: chain_launch_shape<3, 2, 3, 0, 2>(c, a, nwg); break;
-        case 9: chain_launch_shape<5, 6, 5, 0, 2>(c, a, nwg); break;
-        case 10: chain_launch_shape<3, 10, 3, 0, 2>(c, a, nwg); break;
+        case 1: return chain_launch_shape<1, 3, 1, 0, 4>(c, a, nwg);
+        case 2: return chain_launch_shape<2, 3, 2, 0, 2>(c, a, nwg);
+        case 3: return chain_launch_shape<3, 5, 3, 0, 2>(c, a, nwg);
+        case 5: return chain_launch_shape<2, 5, 2, 0, 2>(c, a, nwg);
+        case 6: return chain_launch_shape<1, 5, 1, 0, 4>(c, a, nwg);
+        case 8: return chain_launch_shape<3, 2, 3, 0, 2>(c, a, nwg);
+        case 9: return chain_launch_shape<5, 6, 5, 0, 2>(c, a, nwg);
+        case 10: return chain_launch_shape<3, 10, 3, 0, 2>(c, a, nwg);
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }
-    return SFA_OK;
 }
 
 }  // namespace sfa

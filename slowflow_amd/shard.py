@@ -37,3 +37,11 @@ def max_over_ranks(dist, value, device=None):
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sum_over_ranks(dist, value, device=None):
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
