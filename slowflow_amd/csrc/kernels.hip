@@ -845,7 +845,10 @@ extern "C" int sfa_debug_asm_timing(unsigned long long *out, int reset) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sfa::g_asm_timing), sizeof(unsigned long long) * 16);
 }
 namespace sfa {
-#define AT_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); at_acc[i] += n_ - at_t; at_t = n_; } while (0)
+// the stamp is fenced on both sides: nothing of the phase before it may sink below it, nothing of the phase behind it may rise above it (without the fences the
+// scheduler moved the per-pixel arithmetic across the marks and the table charged it to the barriers)
+#define AT_MARK(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); at_acc[i] += n_ - at_t; at_t = n_; } while (0)
 #else
 #define AT_MARK(i)
 #endif
@@ -855,6 +858,10 @@ namespace sfa {
 // nothing waits until the explicit `dma_wait` below.  Untracked DMA is safe next to tracked loads: vmcnt retires in order, so a compiler-made wait for an older
 // load is unaffected and one for a younger load over-waits.  M0 is not used by anything else in the kernels that call this.
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p; }
+// the same with a wave-uniform 64-bit base and a 32-bit byte offset per lane (no 64-bit address arithmetic in the vector unit)
+__device__ __forceinline__ void dma16s(const float *sbase, unsigned voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
 __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte) : "memory");
 }
@@ -871,12 +878,20 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
 #ifndef SFA_X_AI
 #define SFA_X_AI 0
 #endif
-template <int TY, int NT, int MINB, bool ZUV, bool FAST>
+// wave priority of the staging phases (DMA issue, conversion, stage 1, epilogue) against the per-pixel arithmetic (priority 0).  The two blocks of a CU drift into
+// step (both stage, then both compute); with the short staging phases preferred a block gets through them while the other one computes: 1174 -> 1146 us per launch
+// (priorities 1, 2, 3 measured alike; 0 = off)
+#ifndef SFA_PRIO_STAGE
+#define SFA_PRIO_STAGE 1
+#endif
+#define SFA_PRIO(p) do { if (SFA_PRIO_STAGE) __builtin_amdgcn_s_setprio(p); } while (0)
+struct XcdTiles { int nx, ny, chunk; };      // tile columns, tile rows, ceil(tiles of the launch / 8)
+template <int TY, int NT, int MINB, bool ZUV, bool FAST, bool XT>
 __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, const float *__restrict__ base, float *__restrict__ a11, float *__restrict__ a12,
                                                               float *__restrict__ a22, float *__restrict__ b1, float *__restrict__ b2,
                                                               const float *__restrict__ du, const float *__restrict__ dv, const float *__restrict__ uu,
                                                               const float *__restrict__ vv, const float *__restrict__ sh, const float *__restrict__ sv,
-                                                              const float *__restrict__ occ, Geo g) {
+                                                              const float *__restrict__ occ, Geo g, XcdTiles xt) {
     constexpr int TR = TY + 2 * DT_H, AT_R1 = TY + 4, NR = NT / 64, NP = TY / NR;
     // one LDS block: staged planes during the terms, the operand tile of the solver afterwards
     constexpr int NM = TR * DT_W, N1 = AT_R1 * AT_W1;
@@ -894,15 +909,30 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
 #ifdef SFA_ASM_TIMING
     unsigned long long at_acc[14] = {0}, at_t = __builtin_readcyclecounter();
 #endif
-    const int b = blockIdx.z;
+    // Tile of this block.  The hardware hands consecutive workgroups of a launch to the 8 XCDs in turn (workgroup i -> XCD i % 8, each with an L2 of its
+    // own), so with the plain (x, y, window) grid a tile's horizontal neighbours -- which share two of the four 128-byte lines of every staged row -- and its
+    // vertical neighbours (8 of 16 staged rows) are fetched through OTHER L2s: 2.9 GB crossed the fabric per 64-window launch for 1.4 GB of unique
+    // inputs.  XT: a 1-D grid whose workgroup i works on tile (i % 8) * ceil(N / 8) + i / 8 of the row-major (window, tile row, tile column) order: every XCD
+    // walks a contiguous eighth of the tiles, its CUs hold neighbouring tiles at any time, and the shared lines are L2 hits.
+    int bx_, by_, b_;
+    if (XT) {
+        const unsigned nxy = (unsigned)xt.nx * (unsigned)xt.ny;
+        const unsigned j = (blockIdx.x & 7u) * (unsigned)xt.chunk + (blockIdx.x >> 3);
+        if (j >= nxy * (unsigned)g.nb) return;
+        b_ = (int)(j / nxy);
+        const unsigned r = j - (unsigned)b_ * nxy;
+        by_ = (int)(r / (unsigned)xt.nx);
+        bx_ = (int)(r - (unsigned)by_ * (unsigned)xt.nx);
+    } else { bx_ = blockIdx.x; by_ = blockIdx.y; b_ = blockIdx.z; }
+    const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_), b = __builtin_amdgcn_readfirstlane(b_);
     // reset the solver's progress words and ticket -- for EVERY window of the launch: the solver that follows runs all of them, also the
     // passengers whose operands this launch leaves alone (Geo::active), and draws its tickets from window 0's block whoever is active
-    if (a.op.sa && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (a.op.sa && bx == 0 && by == 0) {
         for (int i = threadIdx.x; i < a.op.ntasks; i += NT) a.op.flags[(size_t)b * a.op.ntasks + i] = 0;
         if (b == 0 && threadIdx.x == 0) a.op.flags[(size_t)a.op.nb * a.op.ntasks] = 0;
     }
     if (!elem_active(g, b)) return;
-    const int x0 = blockIdx.x * DT_X - DT_H, y0 = blockIdx.y * TY - DT_H;       // origin of the halo-4 tile
+    const int x0 = bx * DT_X - DT_H, y0 = by * TY - DT_H;                       // origin of the halo-4 tile
     const long eb = b * g.es;
     const int tx = threadIdx.x & 63;
     const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // one row per wave
@@ -960,6 +990,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         AT_MARK(0);
         if (t > 0) __syncthreads();                                // the staged planes are free again
         AT_MARK(1);
+        SFA_PRIO(SFA_PRIO_STAGE);
         // stage 0 for this term and the next: M and Iz (halo 4) of the three channels, one float4 of a row per item; columns outside
         // the image are replicated (clamped source column), rows outside are never read
         // The raw image quads go global -> LDS by DMA (no register staging: at this kernel's VGPR budget a register pipeline spills, and the
@@ -982,15 +1013,23 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         const int from_b = npair == 2 ? (T1.i2_off == T0.i1_off ? 0 : T1.i2_off == T0.i2_off ? 1 : 2) : 0;
         const long set_src[4] = {T0.i1_off, T0.i2_off, T1.i1_off, T1.i2_off};
         const int set_dst[4] = {0, 6 * NM, 3 * NM, 9 * NM};
+        // one wave-instruction per part and set; a part's quad -> (row, channel) arithmetic is the same for every set, so it runs once per part (it was a
+        // third of this phase's instructions when it ran per set), and the address is a wave-uniform base per set + one 32-bit lane offset
+        const float *set_base[4];
 #pragma unroll
-        for (int set = 0; set < 4; set++) {
-            if (set >= 2 && (npair == 1 || (set == 2 ? from_a : from_b) != 2)) continue;
-            for (int part = ty; part < NSI; part += NR) {              // one wave-instruction per part
-                const int k = part * 64 + tx;
-                const int q = k % QM, ly = (k / QM) % TR, ch = k / (QM * TR);
-                const int gy = y0 + ly, gx = x0 + 4 * q;
-                if (!(SFA_X_AI & 1) && k < NSQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.w)
-                    dma16(base + eb + set_src[set] + (size_t)ch * g.pl + (size_t)gy * g.pitch + gx, lds_addr(lds + set_dst[set] + 256 * part));
+        for (int set = 0; set < 4; set++) set_base[set] = base + eb + set_src[set];
+        const bool own_a = npair == 2 && from_a == 2, own_b = npair == 2 && from_b == 2;
+        for (int part = ty; part < NSI; part += NR) {
+            const int k = part * 64 + tx;
+            const int q = k % QM, ly = (k / QM) % TR, ch = k / (QM * TR);
+            const int gy = y0 + ly, gx = x0 + 4 * q;
+            if (!(SFA_X_AI & 1) && k < NSQ && gy >= 0 && gy < g.h && gx >= 0 && gx + 3 < g.w) {
+                const unsigned po = 4u * ((unsigned)ch * (unsigned)g.pl + (unsigned)gy * (unsigned)g.pitch + (unsigned)gx);   // offset inside one image set: < 12 * plane bytes < 2^32 (launcher)
+                const unsigned ld = lds_addr(lds + 256 * part);
+                dma16s(set_base[0], po, ld + 4u * set_dst[0]);
+                dma16s(set_base[1], po, ld + 4u * set_dst[1]);
+                if (own_a) dma16s(set_base[2], po, ld + 4u * set_dst[2]);
+                if (own_b) dma16s(set_base[3], po, ld + 4u * set_dst[3]);
             }
         }
         AT_MARK(2);
@@ -1044,6 +1083,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         AT_MARK(0);
         __syncthreads();                                           // staged planes complete / the previous term is done with Ix, Iy
         AT_MARK(6);
+        SFA_PRIO(SFA_PRIO_STAGE);
         // stage 1: Ix, Iy on the halo-2 region, four columns per item (two aligned quads of M per tap row)
         for (int item = threadIdx.x; item < ((SFA_X_AI & 4) ? 0 : AT_R1 * 3 * Q1); item += NT) {
             const int q = item % Q1, ch = (item / Q1) % 3, ly = item / (3 * Q1);
@@ -1081,6 +1121,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         AT_MARK(7);
         __syncthreads();
         AT_MARK(8);
+        SFA_PRIO(0);
         // the last term's arithmetic runs beside the DMA of the epilogue's operands: no vector-memory instruction may follow until the wait behind the loop
         if (t == a.n - 1) stage_epilogue_operands();
 #pragma unroll
@@ -1091,33 +1132,59 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             const int c = (ty + NR * k + 2) * AT_W1 + (tx + 2);   // halo-2 planes (Ix, Iy)
             const int cz = (ty + NR * k + 4) * DT_W + (tx + 4);   // halo-4 plane (Iz)
             Px p;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) p.wk[ch] = FAST ? 1.0f : wk[k][ch];
             if (SFA_X_AI & 8) {
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) { p.ixy[ch] = sX[ch][c + 1]; p.iyy[ch] = sY[ch][c + 1]; p.iyz[ch] = sZ[ch][cz + 1]; }
-            } else if (y_in) {
-#pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    p.ixy[ch] = d5y_in<AT_W1>(sX[ch], c);                              // :130
-                    p.iyy[ch] = d5y_in<AT_W1>(sY[ch], c);                              // :131
-                    p.iyz[ch] = d5y_in<DT_W>(sZ[ch], cz);                              // :133
+                    p.ixy[ch] = sX[ch][c + 1]; p.iyy[ch] = sY[ch][c + 1]; p.iyz[ch] = sZ[ch][cz + 1];
+                    p.ix[ch] = sX[ch][c]; p.iy[ch] = sY[ch][c]; p.iz[ch] = sZ[ch][cz]; p.ixx[ch] = sX[ch][c - 1]; p.ixz[ch] = sZ[ch][cz - 1];
                 }
+            } else if (y_in) {
+                // All 69 taps of the pixel (per channel: a row and a column of Ix and of Iz, a column of Iy) are READ first and the filters run behind a scheduling
+                // fence.  Left to itself the compiler read two taps, waited, used them, read the next two (82 LDS instructions per term, nearly each with a wait
+                // of its own, in a kernel with 4 waves per SIMD): the per-pixel phase was 36 % of a wave's life, and most of that LDS latency (round-4 phase stamps).
+                // Two channels' taps in flight at most (all three at once: 69 registers of taps, spills at this kernel's 128).
+                float xr[3][5], xc[3][4], yc[3][5], zr[3][5], zc[3][4];
+                auto read_taps = [&](int ch) {
+                    const float *X = sX[ch] + c, *Y = sY[ch] + c, *Z = sZ[ch] + cz;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) xr[ch][j] = X[j - 2];
+                    xc[ch][0] = X[-2 * AT_W1]; xc[ch][1] = X[-AT_W1]; xc[ch][2] = X[AT_W1]; xc[ch][3] = X[2 * AT_W1];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) yc[ch][j] = Y[(j - 2) * AT_W1];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) zr[ch][j] = Z[j - 2];
+                    zc[ch][0] = Z[-2 * DT_W]; zc[ch][1] = Z[-DT_W]; zc[ch][2] = Z[DT_W]; zc[ch][3] = Z[2 * DT_W];
+                };
+                auto filters = [&](int ch) {
+                    p.ix[ch] = xr[ch][2]; p.iy[ch] = yc[ch][2]; p.iz[ch] = zr[ch][2];
+                    p.ixx[ch] = tap5(xr[ch][0], xr[ch][1], xr[ch][2], xr[ch][3], xr[ch][4]);     // :129
+                    p.ixy[ch] = tap5(xc[ch][0], xc[ch][1], xr[ch][2], xc[ch][2], xc[ch][3]);     // :130
+                    p.iyy[ch] = tap5(yc[ch][0], yc[ch][1], yc[ch][2], yc[ch][3], yc[ch][4]);     // :131
+                    p.ixz[ch] = tap5(zr[ch][0], zr[ch][1], zr[ch][2], zr[ch][3], zr[ch][4]);     // :132
+                    p.iyz[ch] = tap5(zc[ch][0], zc[ch][1], zr[ch][2], zc[ch][2], zc[ch][3]);     // :133
+                };
+                read_taps(0); read_taps(1);
+                __builtin_amdgcn_sched_barrier(0);
+                filters(0);
+                __builtin_amdgcn_sched_barrier(0);
+                read_taps(2);
+                __builtin_amdgcn_sched_barrier(0);
+                filters(1); filters(2);
             } else {
-                const int xc = x < g.w ? x : g.w - 1;
+                const int xc_ = x < g.w ? x : g.w - 1;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     const Tile2Acc X{sX[ch], x0 + 2, y0 + 2}, Y{sY[ch], x0 + 2, y0 + 2};
                     const TileAcc Z{sZ[ch], x0, y0};
-                    p.ixy[ch] = d5y(X, xc, y, g.h);
-                    p.iyy[ch] = d5y(Y, xc, y, g.h);
-                    p.iyz[ch] = d5y(Z, xc, y, g.h);
+                    p.ixy[ch] = d5y(X, xc_, y, g.h);
+                    p.iyy[ch] = d5y(Y, xc_, y, g.h);
+                    p.iyz[ch] = d5y(Z, xc_, y, g.h);
+                    p.ix[ch] = sX[ch][c]; p.iy[ch] = sY[ch][c]; p.iz[ch] = sZ[ch][cz];
+                    p.ixx[ch] = d5x_in<AT_W1>(sX[ch], c);                              // :129
+                    p.ixz[ch] = d5x_in<DT_W>(sZ[ch], cz);                              // :132
                 }
-            }
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                p.wk[ch] = FAST ? 1.0f : wk[k][ch];
-                p.ix[ch] = sX[ch][c]; p.iy[ch] = sY[ch][c]; p.iz[ch] = sZ[ch][cz];
-                p.ixx[ch] = (SFA_X_AI & 8) ? sX[ch][c - 1] : d5x_in<AT_W1>(sX[ch], c);   // :129
-                p.ixz[ch] = (SFA_X_AI & 8) ? sZ[ch][cz - 1] : d5x_in<DT_W>(sZ[ch], cz);  // :132
             }
             if (!ok[k]) continue;
             float m = mk2[ub][k];
@@ -1142,6 +1209,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         __syncthreads();                                            // the DMA has landed / every thread is done with the staged planes
     }
     AT_MARK(9);
+    SFA_PRIO(SFA_PRIO_STAGE);
     const Tile1Acc U{lds, x0, y0 + DT_H - 1}, V{lds + GR * DT_W, x0, y0 + DT_H - 1}, Hh{lds + 2 * GR * DT_W, x0, y0 + DT_H - 1},
         Wv{lds + 3 * GR * DT_W, x0, y0 + DT_H - 1};
 #pragma unroll
@@ -1195,12 +1263,15 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     }
 #ifdef SFA_ASM_TIMING
     AT_MARK(12);
-    if ((threadIdx.x & 63) == 0)
+    // a sample of the blocks only: with every wave adding its 14 slots the atomics on 14 addresses were the kernel (0.85 s per bench step instead of 0.07)
+    if ((threadIdx.x & 63) == 0 && (bx + 3 * by + 7 * b) % 61 == 0)
         for (int i = 0; i < 14; i++) atomicAdd(&g_asm_timing[i], at_acc[i]);
 #endif
 }
 void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
+    // the kernel addresses the three planes of an image set with a 32-bit byte offset (dma16s): 12 bytes x plane entries must fit (357 Mpx per plane)
+    if ((unsigned long long)g.pl * 12ull >= (1ull << 32)) { (void)set_error(c, SFA_ERR_ARG, "k_assemble_images: plane of %ld entries is beyond the kernel's 32-bit offsets", g.pl); return; }
     const bool prof = c->profile && c->ev2_used + 2 <= c->ev2.size();
     if (prof) (void)hipEventRecord(c->ev2[c->ev2_used], c->stream);
     // the cfg's defaults (slow_flow_dataterm 1, modified-L1 penalties -- every id select_robust_function maps to the default class,
@@ -1208,8 +1279,17 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, con
     auto is_modl1 = [](int id) { return id != 0 && id != 2 && id != 3 && id != 4; };
     const bool fast = a.dt_norm == 1 && is_modl1(a.color.id) && is_modl1(a.grad.id) && !a.chw && !getenv("SFA_ASSEMBLE_GENERIC");
     const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + 8 - 1) / 8, g.nb);
+    // the XCD-contiguous tile order (see the kernel) from 8 workgroups per XCD on; SFA_ASM_XCD=0: the plain grid, for A/B measurements
+    static const bool xcd_env = !getenv("SFA_ASM_XCD") || atoi(getenv("SFA_ASM_XCD")) != 0;
+    const long ntiles = (long)grid_.x * grid_.y * grid_.z;
+    const bool xcd = xcd_env && ntiles >= 64 && ntiles < (1l << 30);
+    const XcdTiles xt{(int)grid_.x, (int)grid_.y, (int)((ntiles + 7) / 8)};
+    const dim3 grid1_(8u * (unsigned)xt.chunk, 1, 1);
 #define SFA_LAUNCH_AI(ZUV_, FAST_)                                                                                                                      \
-    hipLaunchKernelGGL((k_assemble_images<8, 512, 4, ZUV_, FAST_>), grid_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g)
+    do {                                                                                                                                                \
+        if (xcd) hipLaunchKernelGGL((k_assemble_images<8, 512, 4, ZUV_, FAST_, true>), grid1_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
+        else hipLaunchKernelGGL((k_assemble_images<8, 512, 4, ZUV_, FAST_, false>), grid_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
+    } while (0)
     // 64 x 8 tiles, 512 threads, 128 VGPRs (two blocks per CU).  Measured and dropped: 64 x 16 with two pixels per thread (209 VGPRs, one block per CU: slower),
     // 8 x 256 threads, 16 x 1024 threads (spills at its 128-register cap)
     if (a.zero_duv) { if (fast) SFA_LAUNCH_AI(true, true); else SFA_LAUNCH_AI(true, false); }
