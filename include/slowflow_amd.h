@@ -17,6 +17,8 @@
 #ifndef SLOWFLOW_AMD_H
 #define SLOWFLOW_AMD_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -222,6 +224,13 @@ int  sfa_sor_batch_upload(sfa_sor_batch *sb, int b, const float *du, const float
                           const float *a22, const float *b1, const float *b2, const float *sh, const float *sv, int stride);
 int  sfa_sor_batch_run(sfa_sor_batch *sb, int iterations, float omega);   /* prepare + solve + finish, async */
 int  sfa_sor_batch_download(sfa_sor_batch *sb, int b, float *du, float *dv, int stride);
+
+/* ---- test hook: the division of the normalised data terms --------------------------------------------------------------------
+ * The cfg-default instance of the fused assembly kernel forms the quotients r^2 / n and t / n of variational_aux_mt.cpp:240-250, 333-347, 479-490, 556-572
+ * with the hardware's correctly-rounded chain and ONE refined reciprocal per denominator, behind range guards (kernels.hip: recip_of / div_by / num_ok).
+ * Per element: q_chain = that chain without any guard, q_exact = the IEEE division, admitted = 1 where the guards let the chain be used.  The parity test
+ * asserts q_chain == q_exact bit for bit wherever admitted == 1. */
+int  sfa_division_chain(sfa_ctx *ctx, const float *numerators, const float *denominators, float *q_chain, float *q_exact, unsigned char *admitted, size_t n);
 
 /* ---- in-library kernel timing (HIP events on the context's stream) ---------------------------------
  * While enabled every SOR solve kernel launch is bracketed by an event pair on the launch stream. */

@@ -70,7 +70,7 @@ EXPORTS = [
     "sfa_sequence_create", "sfa_sequence_destroy", "sfa_sequence_upload", "sfa_sequence_download", "sfa_sequence_normalize",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_upload_resident", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters", "sfa_job_device_bytes",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
-    "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
+    "sfa_division_chain", "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
 ]
 
 _lib = None
@@ -299,6 +299,17 @@ class Context:
         name = C.create_string_buffer(160)
         self._ck(lib().sfa_profile_read_kernels(self.h, C.byref(n), C.byref(ms), C.byref(px), name, 160), "sfa_profile_read_kernels")
         return n.value, ms.value, px.value, name.value.decode()
+
+    def division_chain(self, a, b):
+        """(q_chain, q_exact, admitted) of the shared-reciprocal division test hook (include/slowflow_amd.h: sfa_division_chain)"""
+        import numpy as np
+        a = np.ascontiguousarray(a, np.float32).ravel(); b = np.ascontiguousarray(b, np.float32).ravel()
+        assert a.size == b.size
+        qc, qe, ad = np.empty_like(a), np.empty_like(a), np.empty(a.size, np.uint8)
+        L = lib()
+        L.sfa_division_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        self._ck(L.sfa_division_chain(self.h, a.ctypes.data, b.ctypes.data, qc.ctypes.data, qe.ctypes.data, ad.ctypes.data, a.size), "sfa_division_chain")
+        return qc, qe, ad
 
     def timer_start(self):
         self._ck(lib().sfa_timer_start(self.h), "sfa_timer_start")

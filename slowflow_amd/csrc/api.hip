@@ -645,6 +645,19 @@ int sfa_sub_laplacian(sfa_ctx *ctx, float *dst, const float *src, const float *w
     return sfa_ctx_sync(ctx);
 }
 
+int sfa_division_chain(sfa_ctx *ctx, const float *a, const float *b, float *q_chain, float *q_exact, unsigned char *admitted, size_t n) {
+    CHECK_ARGS(ctx && a && b && q_chain && q_exact && admitted && n > 0, "bad arguments");
+    DevMem da, db, dq, de, dm;
+    SFA_TRY(da.alloc(ctx, n * 4)); SFA_TRY(db.alloc(ctx, n * 4)); SFA_TRY(dq.alloc(ctx, n * 4)); SFA_TRY(de.alloc(ctx, n * 4)); SFA_TRY(dm.alloc(ctx, n));
+    SFA_HIP(ctx, hipMemcpyAsync(da.p, a, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SFA_HIP(ctx, hipMemcpyAsync(db.p, b, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_division_chain(ctx, da.f(), db.f(), dq.f(), de.f(), (unsigned char *)dm.p, n);
+    SFA_HIP(ctx, hipMemcpyAsync(q_chain, dq.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFA_HIP(ctx, hipMemcpyAsync(q_exact, de.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFA_HIP(ctx, hipMemcpyAsync(admitted, dm.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    return sfa_ctx_sync(ctx);
+}
+
 int sfa_occlusion_costs(sfa_ctx *ctx, const sfa_params *p, float *d0, float *d1, const float *const *masks, const float *const *succ1,
                         const float *const *succ2, const float *const *ref1, const float *const *ref2, int w, int h, int stride) {
     CHECK_ARGS(ctx && p && d0 && d1 && masks && succ1 && succ2 && ref1 && ref2 && w > 0 && h >= 4 && stride >= w, "bad arguments");

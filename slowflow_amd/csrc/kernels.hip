@@ -566,6 +566,64 @@ void launch_fill(sfa_ctx *c, float *p, size_t n, float v) {
 // ---------------------------------------------------------------------------------------------------
 #define DATANORM (0.1f * 0.1f)   // variational_aux_mt.h:23
 
+
+// Division by a denominator that two quotients share (r^2 / n and t / n in the normalised data terms): the hardware's own correctly-rounded chain
+// (v_rcp, one Newton step, quotient, two residual corrections -- what __fdiv_rn expands to between its v_div_scale and v_div_fixup instructions) with the
+// refined reciprocal computed once per denominator.
+struct Recip { float b, r; };
+__device__ __forceinline__ Recip recip_of(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return Recip{b, r};
+}
+__device__ __forceinline__ float div_by(float a, const Recip &d) {
+    float q = a * d.r;
+    float e = __builtin_fmaf(-d.b, q, a);
+    q = __builtin_fmaf(e, d.r, q);
+    e = __builtin_fmaf(-d.b, q, a);
+    return __builtin_fmaf(e, d.r, q);
+}
+// When is that chain the IEEE quotient?  v_div_scale_f32 leaves numerator a and denominator b alone (and v_div_fmas / v_div_fixup are then a plain fma and
+// the identity) unless: a or b is zero, exponent(a) - exponent(b) >= 96, b or 1 / b or a / b is denormal, or the biased exponent of a is <= 23 (CDNA3 ISA,
+// V_DIV_SCALE_F32).  The guards below admit   b in [2^-27, 2^33)   (the data terms' denominators are sums of squares + 0.01: only the upper bound can fail) and
+// a = +0  or  a in [2^-87, 2^53)   (for a = +0 the chain returns +0 like the division): exponent differences stay within (-121, 81).  The squared residuals
+// are checked per pixel; the second numerator, the weight t = mask weight * (rho delta / 3 or rho gamma / 3) * psi'(s), is in range whenever the scalars are
+// (launch_assemble_images: hd, hg in [2^-16, 2^16], data_norm in [2^-8, 2^8], eps in [2^-20, 2^20]; the mask weights are 0, 1, 1 / data_norm or 1 / (2 data_norm),
+// s < 6 * 2^53 / 0.01 by the first guard, so t = +0 or 2^-58 < t < 2^43) -- AssembleArgs::chain_ok, evaluated on the host.  A wave in which any live lane fails a guard takes the __fdiv_rn path for that group of quotients (wave-uniform branch): same bits either way,
+// checked on the GPU over the boundary cases (tests/test_gpu_parity.py::test_shared_reciprocal_division_is_ieee).  SFA_EXACT_DIV_ONLY (build flag): always the slow path.
+__device__ __forceinline__ bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
+__device__ __forceinline__ unsigned num_key(float a) { return __float_as_uint(a) - 1u; }                 // +0 -> 0xffffffff, otherwise monotone in a >= 0
+constexpr unsigned kNumLo = 0x14000000u - 1u;                                                            // key of 2^-87 (biased exponent 40)
+constexpr float kNumHi = 9007199254740992.0f, kDenHi = 8589934592.0f;                                    // 2^53, 2^33
+__device__ __forceinline__ bool num_ok(float a) { return (int)__float_as_uint(a) >= 0 && num_key(a) >= kNumLo && a < kNumHi; }     // any float: negative values and -0 fail
+__device__ __forceinline__ bool num_ok3(float a, float b, float c) {
+    const unsigned ka = num_key(a), kb = num_key(b), kc = num_key(c);
+    return min(ka, min(kb, kc)) >= kNumLo && fmaxf(a, fmaxf(b, c)) < kNumHi;
+}
+__device__ __forceinline__ bool den_ok3(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)) < kDenHi; }
+// SHDIV: a template parameter of the term functions -- on in the cfg-default instance of the fused kernel only (the generic instance is at its register cap:
+// the reciprocals kept across the penalty evaluation made it spill)
+#ifdef SFA_EXACT_DIV_ONLY
+#define SFA_FAST_DIV(cond) false
+#else
+#define SFA_FAST_DIV(cond) (SHDIV && chain && wave_all(cond))
+#endif
+
+// test hook (sfa_division_chain): per element the shared-reciprocal quotient, the __fdiv_rn quotient and whether the guards admit the pair
+__global__ void k_division_chain(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ q_chain, float *__restrict__ q_exact,
+                                 unsigned char *__restrict__ admitted, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = a[i], y = b[i];
+        q_chain[i] = div_by(x, recip_of(y));
+        q_exact[i] = __fdiv_rn(x, y);
+        admitted[i] = (num_ok(x) && den_ok3(y, y, y) && y >= 7.450580596923828125e-9f) ? 1 : 0;     // y >= 2^-27: the data terms' denominators are >= 0.01 by construction
+    }
+}
+void launch_division_chain(sfa_ctx *c, const float *a, const float *b, float *q_chain, float *q_exact, unsigned char *admitted, size_t n) {
+    hipLaunchKernelGGL(k_division_chain, dim3(2048), dim3(256), 0, c->stream, a, b, q_chain, q_exact, admitted, n);
+}
+
 struct Acc { float a11, a12, a22, b1, b2; };
 
 struct Px {   // per-pixel inputs of one term
@@ -574,9 +632,9 @@ struct Px {   // per-pixel inputs of one term
 
 // ZUV: du = dv = 0 (first inner iteration): the flow products in the residuals are +-0 and only the squares of the residuals are used,
 // so r = wk * Iz (etc.) gives the same bits as the full expression
-template <bool ZUV = false>
+template <bool ZUV = false, bool SHDIV = false>
 __device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u, float v, float hd, float hg, float s, int dt_norm,
-                                          const PenaltyDev &color, const PenaltyDev &grad) {
+                                          const PenaltyDev &color, const PenaltyDev &grad, bool chain = false) {
     const float factor = s, factorp1 = s + 1;
     if (hd) {                                                                            // :189
         float r[3], tx[3], ty[3];
@@ -602,10 +660,20 @@ __device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u,
             float n[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) n[k] = tx[k] * tx[k] + ty[k] * ty[k] + DATANORM;   // :236-238
-            const float t = m * hd * psi_vec(color, __fdiv_rn(r[0] * r[0], n[0]) + __fdiv_rn(r[1] * r[1], n[1]) + __fdiv_rn(r[2] * r[2], n[2]));   // :240
+            const float a0 = r[0] * r[0], a1 = r[1] * r[1], a2 = r[2] * r[2];
+            const bool f1 = SFA_FAST_DIV(num_ok3(a0, a1, a2) && den_ok3(n[0], n[1], n[2]));
+            Recip d[3];
+            float q0, q1, q2;
+            if (f1) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) d[k] = recip_of(n[k]);
+                q0 = div_by(a0, d[0]); q1 = div_by(a1, d[1]); q2 = div_by(a2, d[2]);
+            } else { q0 = __fdiv_rn(a0, n[0]); q1 = __fdiv_rn(a1, n[1]); q2 = __fdiv_rn(a2, n[2]); }
+            const float t = m * hd * psi_vec(color, q0 + q1 + q2);                       // :240
+            const bool f2 = f1;                                                         // t is in range by the launcher's parameter check (AssembleArgs::chain_ok)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                float tk = __fdiv_rn(t, n[k]);
+                float tk = f2 ? div_by(t, d[k]) : __fdiv_rn(t, n[k]);
                 tk = tk * p.wk[k];
                 A.a11 += tk * tx[k] * tx[k];                                             // :246-250
                 A.a12 += tk * tx[k] * ty[k];
@@ -644,11 +712,23 @@ __device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u,
             n[2 * k] = X[k] * X[k] + Z[k] * Z[k] + DATANORM;                             // :326-331
             n[2 * k + 1] = Y[k] * Y[k] + Z[k] * Z[k] + DATANORM;
         }
-        const float t = m * hg * psi_vec(grad, __fdiv_rn(r[0] * r[0], n[0]) + __fdiv_rn(r[1] * r[1], n[1]) + __fdiv_rn(r[2] * r[2], n[2]) +
-                                                   __fdiv_rn(r[3] * r[3], n[3]) + __fdiv_rn(r[4] * r[4], n[4]) + __fdiv_rn(r[5] * r[5], n[5]));   // :333
+        float a[6], q[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) a[k] = r[k] * r[k];
+        const bool f1 = SFA_FAST_DIV(num_ok3(a[0], a[1], a[2]) && num_ok3(a[3], a[4], a[5]) && den_ok3(n[0], n[1], n[2]) && den_ok3(n[3], n[4], n[5]));
+        Recip d[6];
+        if (f1) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { d[k] = recip_of(n[k]); q[k] = div_by(a[k], d[k]); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) q[k] = __fdiv_rn(a[k], n[k]);
+        }
+        const float t = m * hg * psi_vec(grad, q[0] + q[1] + q[2] + q[3] + q[4] + q[5]);   // :333
+        const bool f2 = f1;                                                         // t is in range by the launcher's parameter check (AssembleArgs::chain_ok)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            float ta = __fdiv_rn(t, n[2 * k]), tb = __fdiv_rn(t, n[2 * k + 1]);
+            float ta = f2 ? div_by(t, d[2 * k]) : __fdiv_rn(t, n[2 * k]), tb = f2 ? div_by(t, d[2 * k + 1]) : __fdiv_rn(t, n[2 * k + 1]);
             ta = ta * p.wk[k];
             tb = tb * p.wk[k];
             A.a11 += ta * X[k] * X[k] + tb * Z[k] * Z[k];                                // :343-347
@@ -660,9 +740,9 @@ __device__ __forceinline__ void term_succ(Acc &A, const Px &p, float m, float u,
     }
 }
 
-template <bool ZUV = false>
+template <bool ZUV = false, bool SHDIV = false>
 __device__ __forceinline__ void term_ref(Acc &A, const Px &p, float m, float u, float v, float hd, float hg, float s, int dt_norm,
-                                         const PenaltyDev &color, const PenaltyDev &grad) {
+                                         const PenaltyDev &color, const PenaltyDev &grad, bool chain = false) {
     float factor = s;
     const float factorsq = factor * factor;                                              // :417
     if (s >= 0) factor = -factor;                                                        // :424-425
@@ -699,10 +779,20 @@ __device__ __forceinline__ void term_ref(Acc &A, const Px &p, float m, float u, 
             float n[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) n[k] = factorsq * p.ix[k] * p.ix[k] + factorsq * p.iy[k] * p.iy[k] + DATANORM;   // :475-477
-            const float t = m * hd * psi_vec(color, __fdiv_rn(r[0] * r[0], n[0]) + __fdiv_rn(r[1] * r[1], n[1]) + __fdiv_rn(r[2] * r[2], n[2]));   // :479
+            const float a0 = r[0] * r[0], a1 = r[1] * r[1], a2 = r[2] * r[2];
+            const bool f1 = SFA_FAST_DIV(num_ok3(a0, a1, a2) && den_ok3(n[0], n[1], n[2]));
+            Recip d[3];
+            float q0, q1, q2;
+            if (f1) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) d[k] = recip_of(n[k]);
+                q0 = div_by(a0, d[0]); q1 = div_by(a1, d[1]); q2 = div_by(a2, d[2]);
+            } else { q0 = __fdiv_rn(a0, n[0]); q1 = __fdiv_rn(a1, n[1]); q2 = __fdiv_rn(a2, n[2]); }
+            const float t = m * hd * psi_vec(color, q0 + q1 + q2);                       // :479
+            const bool f2 = f1;                                                         // t is in range by the launcher's parameter check (AssembleArgs::chain_ok)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                float tk = __fdiv_rn(t, n[k]);
+                float tk = f2 ? div_by(t, d[k]) : __fdiv_rn(t, n[k]);
                 tk = tk * p.wk[k] * factor;                                              // :484-490
                 A.b1 -= tk * p.iz[k] * p.ix[k];
                 A.b2 -= tk * p.iz[k] * p.iy[k];
@@ -746,11 +836,23 @@ __device__ __forceinline__ void term_ref(Acc &A, const Px &p, float m, float u, 
             n[2 * k] = factorsq * p.ixx[k] * p.ixx[k] + factorsq * p.ixy[k] * p.ixy[k] + DATANORM;       // :549-554
             n[2 * k + 1] = factorsq * p.iyy[k] * p.iyy[k] + factorsq * p.ixy[k] * p.ixy[k] + DATANORM;
         }
-        const float t = m * hg * psi_vec(grad, __fdiv_rn(r[0] * r[0], n[0]) + __fdiv_rn(r[1] * r[1], n[1]) + __fdiv_rn(r[2] * r[2], n[2]) +
-                                                   __fdiv_rn(r[3] * r[3], n[3]) + __fdiv_rn(r[4] * r[4], n[4]) + __fdiv_rn(r[5] * r[5], n[5]));   // :556
+        float a[6], q[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) a[k] = r[k] * r[k];
+        const bool f1 = SFA_FAST_DIV(num_ok3(a[0], a[1], a[2]) && num_ok3(a[3], a[4], a[5]) && den_ok3(n[0], n[1], n[2]) && den_ok3(n[3], n[4], n[5]));
+        Recip d[6];
+        if (f1) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { d[k] = recip_of(n[k]); q[k] = div_by(a[k], d[k]); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) q[k] = __fdiv_rn(a[k], n[k]);
+        }
+        const float t = m * hg * psi_vec(grad, q[0] + q[1] + q[2] + q[3] + q[4] + q[5]);   // :556
+        const bool f2 = f1;                                                         // t is in range by the launcher's parameter check (AssembleArgs::chain_ok)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            float ta = __fdiv_rn(t, n[2 * k]), tb = __fdiv_rn(t, n[2 * k + 1]);
+            float ta = f2 ? div_by(t, d[2 * k]) : __fdiv_rn(t, n[2 * k]), tb = f2 ? div_by(t, d[2 * k + 1]) : __fdiv_rn(t, n[2 * k + 1]);
             ta = ta * p.wk[k] * factor;                                                  // :564-572
             tb = tb * p.wk[k] * factor;
             A.b1 -= ta * p.ixx[k] * p.ixz[k] + tb * p.ixy[k] * p.iyz[k];
@@ -1193,8 +1295,8 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 for (int ch = 0; ch < 3; ch++) {
                     A[k].a11 += p.ix[ch] + p.ixx[ch] + m; A[k].a12 += p.iy[ch] + p.ixy[ch]; A[k].a22 += p.iz[ch] + p.iyy[ch]; A[k].b1 += p.ixz[ch]; A[k].b2 += p.iyz[ch];
                 }
-            } else if (T.is_ref) term_ref<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad);
-            else          term_succ<ZUV>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad);
+            } else if (T.is_ref) term_ref<ZUV, FAST>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad, a.chain_ok != 0);
+            else          term_succ<ZUV, FAST>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad, a.chain_ok != 0);
         }
     }
     // row strides chosen for the anti-diagonal read-out below (entry 64*rl + dl of a 65-wide row puts the TY rows of a diagonal into one bank group:
@@ -1268,8 +1370,9 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         for (int i = 0; i < 14; i++) atomicAdd(&g_asm_timing[i], at_acc[i]);
 #endif
 }
-void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
+void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
+    AssembleArgs a = a_in;
     // the kernel addresses the three planes of an image set with a 32-bit byte offset (dma16s): 12 bytes x plane entries must fit (357 Mpx per plane)
     if ((unsigned long long)g.pl * 12ull >= (1ull << 32)) { (void)set_error(c, SFA_ERR_ARG, "k_assemble_images: plane of %ld entries is beyond the kernel's 32-bit offsets", g.pl); return; }
     const bool prof = c->profile && c->ev2_used + 2 <= c->ev2.size();
@@ -1278,6 +1381,12 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, con
     // variational_aux_mt.cpp:909-925 --, no channel weights) take the instance with those choices folded in
     auto is_modl1 = [](int id) { return id != 0 && id != 2 && id != 3 && id != 4; };
     const bool fast = a.dt_norm == 1 && is_modl1(a.color.id) && is_modl1(a.grad.id) && !a.chw && !getenv("SFA_ASSEMBLE_GENERIC");
+    {   // the shared-reciprocal divisions' precondition on the scalars (see recip_of / div_by)
+        auto in = [](float v, float lo, float hi) { return v >= lo && v <= hi; };
+        bool okp = fast && in(a.data_norm, 1.0f / 256, 256.0f) && in(a.color.eps, 1.0f / 1048576, 1048576.0f) && in(a.grad.eps, 1.0f / 1048576, 1048576.0f);
+        for (int t = 0; t < a.n && okp; t++) okp = (a.t[t].hd == 0.0f || in(a.t[t].hd, 1.0f / 65536, 65536.0f)) && (a.t[t].hg == 0.0f || in(a.t[t].hg, 1.0f / 65536, 65536.0f));
+        a.chain_ok = okp && !getenv("SFA_EXACT_DIV") ? 1 : 0;
+    }
     const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + 8 - 1) / 8, g.nb);
     // the XCD-contiguous tile order (see the kernel) from 8 workgroups per XCD on; SFA_ASM_XCD=0: the plain grid, for A/B measurements
     static const bool xcd_env = !getenv("SFA_ASM_XCD") || atoi(getenv("SFA_ASM_XCD")) != 0;

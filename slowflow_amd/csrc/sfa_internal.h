@@ -122,6 +122,7 @@ void launch_smoothness(sfa_ctx *c, const Geo &g, int method, float *sh, float *s
 void launch_sub_laplacian(sfa_ctx *c, const Geo &g, float *dst, const float *src, const float *wh, const float *wv);
 void launch_mask_weight(sfa_ctx *c, const Geo &g, float *masks, const float *occ, float data_norm, int ref, int one_direction);
 void launch_fill(sfa_ctx *c, float *p, size_t n, float v);
+void launch_division_chain(sfa_ctx *c, const float *a, const float *b, float *q_chain, float *q_exact, unsigned char *admitted, size_t n);
 void launch_fill_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes, float v);
 void launch_zero_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes);
 void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres);   // updates *c->d_amask and c->d_last
@@ -153,6 +154,7 @@ struct AssembleArgs {
     // (what k_sor_prepare does from the planes); a11 .. b2 are then not written at all
     SorOperandOut op;
     int zero_duv;        // fused form: du = dv = 0 (first inner iteration, variational_mt.cpp:323-324): the planes are not read
+    int chain_ok = 0;    // fused form, set by the launcher: the scalars admit the shared-reciprocal divisions (kernels.hip: recip_of / div_by)
 };
 void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base /*element arena of batch 0*/, float *a11, float *a12,
                      float *a22, float *b1, float *b2, const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv);

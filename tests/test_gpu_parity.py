@@ -1282,3 +1282,51 @@ def test_boundary_rejects_bad_arguments_without_exiting(ctx):
     wx, wy, _ = j.download(1)
     assert np.isfinite(wx).all() and np.isfinite(wy).all()
     j.close()
+
+
+def test_shared_reciprocal_division_is_ieee(ctx):
+    """The cfg-default assembly kernel divides by a denominator two quotients share through one refined reciprocal (kernels.hip: recip_of / div_by), behind
+    range guards; wherever the guards admit a pair the chain must BE the IEEE quotient.  Numerators: +0, every biased exponent around both guard edges
+    (2^-87, 2^53) with random and extreme mantissas, squares of image-like values; denominators: 0.01 + sums of squares, the edges 2^-27 .. 2^33, exact
+    powers of two and their neighbours.  Also: the guards do admit the values the data terms produce (otherwise the fast path would be dead code), and
+    reject -0, negative, tiny and huge numerators."""
+    rng = np.random.default_rng(7)
+    def with_exp(e, n):                                   # n floats with biased exponent e, random mantissa
+        return ((np.uint32(e) << np.uint32(23)) | rng.integers(0, 1 << 23, n, dtype=np.uint32)).view(np.float32)
+    nums = [np.zeros(64, np.float32)]
+    for e in list(range(30, 50)) + list(range(170, 190)) + list(range(100, 150, 7)):
+        v = with_exp(e, 4096)
+        v[:4] = np.array([e << 23, (e << 23) | 0x7fffff, (e << 23) | 1, (e << 23) | 0x400000], np.uint32).view(np.float32)
+        nums.append(v)
+    img = rng.normal(0, 1.5, 200000).astype(np.float32)
+    nums.append(img * img)
+    nums.append((rng.uniform(0, 500, 50000)).astype(np.float32))        # weights t
+    nums = np.concatenate(nums)
+    dens = [np.float32(0.01) + (rng.normal(0, 2, 100000).astype(np.float32)) ** 2 + (rng.normal(0, 2, 100000).astype(np.float32)) ** 2]
+    for e in list(range(96, 104)) + list(range(118, 165)):
+        v = with_exp(e, 512)
+        v[:4] = np.array([e << 23, (e << 23) | 0x7fffff, (e << 23) | 1, (e << 23) | 0x400000], np.uint32).view(np.float32)
+        dens.append(v)
+    dens = np.concatenate(dens)
+    n = 6_000_000
+    a = nums[rng.integers(0, nums.size, n)]
+    b = dens[rng.integers(0, dens.size, n)]
+    # every edge numerator against every edge denominator as well
+    ea = np.concatenate([with_exp(e, 4) for e in range(36, 46)] + [with_exp(e, 4) for e in range(176, 184)] + [np.zeros(1, np.float32)])
+    eb = np.concatenate([with_exp(e, 4) for e in range(98, 102)] + [with_exp(e, 4) for e in range(156, 162)] + [np.float32([0.01, 0.0100001, 1.0, 3.0])])
+    ga, gb = np.meshgrid(ea, eb)
+    a = np.concatenate([a, ga.ravel().astype(np.float32)]); b = np.concatenate([b, gb.ravel().astype(np.float32)])
+    qc, qe, ad = ctx.division_chain(a, b)
+    adm = ad.astype(bool)
+    assert np.array_equal(qe.view(np.uint32), (a.astype(np.float32) / b.astype(np.float32)).view(np.uint32)), "the GPU's own __fdiv_rn is the IEEE quotient"
+    bad = adm & (qc.view(np.uint32) != qe.view(np.uint32))
+    assert not bad.any(), f"{int(bad.sum())} admitted pairs differ, e.g. {a[bad][:3]} / {b[bad][:3]}"
+    assert adm.mean() > 0.5                                # the guards admit the bulk of the sample
+    typical = (a >= 1e-12) & (a <= 1e6) & (b >= 0.01) & (b <= 1e6)
+    assert adm[typical].all(), "values of the size the data terms produce take the fast path"
+    # rejected by construction
+    rej_a = np.float32([-0.0, -1.0, 2.0 ** -100, 2.0 ** 60, np.inf])
+    _, _, ad2 = ctx.division_chain(rej_a, np.full(rej_a.size, 1.0, np.float32))
+    assert not ad2.any()
+    _, _, ad3 = ctx.division_chain(np.float32([1.0, 1.0]), np.float32([2.0 ** 40, 2.0 ** -30]))
+    assert not ad3.any()
