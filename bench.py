@@ -37,24 +37,74 @@ CLOCK_GHZ = 2.4              # peak engine clock the issue-rate and latency-floo
 
 
 def assemble_valu_per_pixel_term():
-    """VALU instructions one pixel spends per data term in k_assemble_images, from the SQ counter pass of the newest profile round that has it
-    (profiles/<tag>_sq.json: SQ_INSTS_VALU of the kernel x 64 lanes / pixels / terms)"""
-    for tag in ("r03", "r02"):
+    """VALU instructions one pixel spends per data term in k_assemble_images (staging, filters, term arithmetic, epilogue -- everything the kernel issues),
+    from the SQ counter pass of the newest profile round that has it: SQ_INSTS_VALU / SQ_WAVES (both counters sample the same subset of the launch's waves, so
+    their ratio is per wave; rounds 1-3 divided the raw instruction count by ALL pixels and reported 440 where a wave really issues ~1950 for its 64 pixels x 2
+    terms) / 2 terms.  Returns (instructions, source, share of SIMD time with a VALU instruction in flight when the kernel runs alone)."""
+    for tag in ("r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
-                v = json.load(f).get("assemble_valu_inst_per_pixel_term")
+                j = json.load(f)
+            v = j.get("assemble_valu_inst_per_wave")
+            v = v / 2.0 if v else None
+            if not v and tag == "r03":
+                v = 1957.0 / 2.0                         # profiles/r03_sq_by_kernel.csv: 372131681 / 190151
             if v:
                 act = None
                 try:
-                    with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
-                        ks = json.load(f).get("kernels", {})
-                    act = max(x["valu_active_frac"] for k, x in ks.items() if "k_assemble_images" in k)
-                except (OSError, ValueError, KeyError):
+                    act = max(x["valu_active_frac"] for k, x in j.get("kernels", {}).items() if "k_assemble_images" in k)
+                except (ValueError, KeyError):
                     pass
                 return float(v), "profiles/%s_sq.json" % tag, act
         except (OSError, ValueError):
             continue
     return None, None, None
+
+
+def sor_launch_waves(kernel, nb):
+    """waves of the mean SOR launch of the bench workload (5 levels): windows x bands x groups x waves per workgroup, from the chain kernel's shape
+    k_sor_chain<FA, NA, FB, NB, ...> (NA + NB compute waves + 2 I/O waves; groups = K / (FA NA + FB NB); bands = ceil((h + K - 1) / 64), sor.hip)"""
+    import re
+    m = re.search(r"k_sor_chain<\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)", kernel)
+    if not m:
+        return None
+    fa, na, fb, nb_ = (int(x) for x in m.groups())
+    kg = fa * na + fb * nb_
+    if kg <= 0 or SWEEPS % kg:
+        return None
+    hs, h = [], H
+    w = W
+    for _ in range(LAYERS):
+        hs.append(h)
+        w, h = int(np.floor(np.float32(w) * np.float32(0.9))), int(np.floor(np.float32(h) * np.float32(0.9)))
+    bands = np.mean([(hh + SWEEPS - 1 + 63) // 64 for hh in hs])
+    return nb * bands * (SWEEPS // kg) * (na + nb_ + 2)
+
+
+def limiter(kernel, batch, streams):
+    """What the solver kernel waits for -- a statement measured for ONE configuration (k_sor_chain<3,5,3,0,...>, 64 windows per launch: what-if builds of
+    DESIGN.md 5.1b, profiles/r03_chain_whatif.txt) and printed only for it; any other shape or batch gets the plain label."""
+    if "k_sor_chain<3,5,3,0" in kernel.replace(" ", "") and batch == 64:
+        return ("wave issue rate: one 7-wave workgroup per CU (its operand ring fills the LDS), five compute waves on four SIMDs each issuing one instruction per "
+                "4-8 cycles; a build whose I/O waves only walk the barriers needs 0.94 of the launch, one without operand loads 0.97 (DESIGN.md 5.1b)")
+    if batch <= 8:
+        return "dependency latency: W + H + 2K hyperplane steps of ~14 dependent packed operations each, plus the start-up skew of the bands (DESIGN.md 5.1b)"
+    return "dependency latency / wave issue rate (not measured for this shape and batch size)"
+
+
+def sor_valu_per_wave(kernel):
+    """(VALU instructions per wave of the SOR kernel, waves per workgroup, source) from the newest SQ pass whose kernel shape is the one that ran."""
+    def norm(k):
+        return k.replace("void ", "").replace("sfa::", "").split("(")[0].replace(" ", "")
+    for tag in ("r04", "r03"):
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
+                j = json.load(f)
+            if j.get("kernel") and norm(j["kernel"]) == norm(kernel) and j.get("sor_valu_inst_per_wave"):
+                return float(j["sor_valu_inst_per_wave"]), "profiles/%s_sq.json" % tag
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def synth_window(seed, w=W, h=H, n=3):
@@ -236,7 +286,7 @@ def measured_traffic(batch, kernel=None):
     so the committed measurement of the same command is reported, and only when it was taken at this batch size.
     Returns (bytes per launch, source, valu_busy) -- valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (SIMDs x kernel cycles) of the SOR kernel
     when the SQ pass of the same round is there (profiles/<tag>_sq.json), else None."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", tag + "_traffic.json")
         try:
             with open(path) as f:
@@ -638,6 +688,7 @@ def main():
     strong = strong5 = None
     if not args.no_strong and not args.path_only:
         strong = config4_strong(ctxs, dev, world, rank, dist, xdev)
+        strong5 = config5_strong(ctxs, dev, world, rank, dist, xdev)
     if rank == 0:
         total = mpix_iters * args.steps * world
         value = total / elapsed_max
@@ -654,34 +705,44 @@ def main():
                                    "symmetric window, modified-L1 penalties, thresholds off",
                        "frame_windows_per_gpu": B, "streams": S, "windows_per_launch": BL, "mpix_iters_per_step_per_gpu": round(mpix_iters, 3), "sor_order": "lexicographic (reference-identical)",
                        "parallelism": f"frame-window data parallel x{world}" + ("" if backend == "nccl" or world == 1 else f" (REHEARSAL over {backend}: ranks share {ndev} GPU(s))")},
-            # What bounds the solver: NOT bandwidth.  A kernel that fuses the sweeps of a band re-reads little, so the 8(d) byte model
-            # (44 K + 12 bytes per pixel: every sweep re-reads its operands) gives frac > 1.  Few windows per launch: the launch is as long as the dependency
-            # chain of the reference's raster order (W + H + 2K hyperplane steps at the finest level, each a chain of ~14 dependent packed operations + one DPP
-            # shift, ~150 cycles, plus the start-up skew of the bands).  Many windows (the bench's 64 per launch): the issue rate of the compute waves --
-            # one workgroup per CU (its operand ring fills the LDS), five compute waves, each issuing an instruction every 5-8 cycles: a build whose I/O waves
-            # only walk the barriers needs 94 % of the real kernel's time, one without operand loads 97 %.  `frac` stays the 8(d) figure;
-            # the physical picture is in hbm_physical / traffic_over_compulsory, the latency picture in the sor_1024x436_* entries.
-            "roofline": {"bound": "dependency-latency (wave issue rate at this batch size: compute-only build = 0.94 of the launch; DESIGN.md 5.1b)", "kernel": sor_kernel + " -- the shape the library picked for %d windows per launch" % BL,
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            # The solver kernel against the HBM roof.  `achieved` = the bytes the fused solve has to move (every operand entry read once, the iterate read and
+            # written once: 48 B per pixel and solve -- DESIGN.md 5.1) / the live launch duration; `frac` = that / peak, a true fraction.  SURVEY 8(d)'s byte model
+            # charges 44 K + 12 bytes per pixel because it re-reads the operands in every sweep; a kernel that keeps 15 sweeps of a band in LDS moves far fewer, so
+            # that figure exceeds the peak and is carried as `algorithmic_gbs_8d` / `algorithmic_8d_over_peak`, NOT as a fraction of anything.  The kernel is not
+            # bandwidth bound at all: `limiter` says what it waits for, `valu_issue_floor_frac` how close it is to that roof.
+            "roofline": {"bound": "hbm", "kernel": sor_kernel + " -- the shape the library picked for %d windows per launch" % BL,
+                         "achieved": round(compulsory / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(compulsory / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if avg_launch_s > 0 else None, "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
-                         "algorithmic_bytes_per_launch": round(sor_bytes / max(n_sor, 1)),
+                         "algorithmic_bytes_per_launch": round(compulsory),
+                         "algorithmic_bytes_note": "48 B per pixel and solve (2 x 16 B operand entries + 8 B iterate in + 8 B out), mean over the launches of all 5 levels",
                          "traffic_source": traffic_src,
                          "hbm_physical": (round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_s > 0 else None),
-                         "compulsory_bytes_per_launch": round(compulsory),
                          "traffic_over_compulsory": (round(traffic / compulsory, 2) if traffic and compulsory > 0 else None),
-                         "valu_issue_frac": valu_busy,
+                         "algorithmic_gbs_8d": round(achieved, 1), "algorithmic_8d_over_peak": round(achieved / HBM_PEAK_GBS, 3),
+                         "algorithmic_8d_note": "SURVEY 8(d): (44 K + 12) B per pixel and solve, every sweep re-reading its operands; above the peak because the kernel fuses the sweeps",
+                         "limiter": limiter(sor_kernel, BL, S),
+                         "valu_active_frac": valu_busy,
                          "steps_critical_level0": W + H + 2 * SWEEPS,
                          "alu_latency_floor_us_per_step": round(150.0 / CLOCK_GHZ / 1e3, 4),
-                         "note": "over the timed region (launches of all streams; with streams > 1 a launch shares the GPU with the other groups' kernels, so its duration is longer than alone): sum of (44*K+12)*w*h*batch ALGORITHMIC bytes of every SOR launch (all 5 levels) / sum of HIP-event durations",
+                         "note": "over the timed region (launches of all streams; with streams > 1 a launch shares the GPU with the other groups' kernels, so its duration is longer than alone): sums over every SOR launch (all 5 levels) / sum of HIP-event durations",
                          },
             "sor_share_of_step": round(sor_ms / S / (elapsed * 1e3), 4),
             "seconds_per_window": {"mean": round(float(window_seconds.mean()), 6), "max": round(float(window_seconds.max()), 6), "n": int(window_seconds.size)},
         }
+        vpw, vpw_src = sor_valu_per_wave(sor_kernel)
+        if vpw and n_sor:
+            # VALU issue floor of the solver: instructions per wave (SQ counters) x waves of the mean launch x 2 cycles per wave64 instruction on a SIMD-32
+            # (MI355X_MICROARCH.md; a wave alone on its SIMD -- this kernel's regime, one 7-wave workgroup per CU -- issues one per 4-5) / 1024 SIMDs
+            waves = sor_launch_waves(sor_kernel, BL) or 0.0
+            floor_s = vpw * waves * 2.0 / (1024.0 * CLOCK_GHZ * 1e9)
+            out["roofline"]["valu_issue_floor_frac"] = round(floor_s / avg_launch_s, 4)
+            out["roofline"]["valu_issue_floor_note"] = "%.0f VALU instructions per wave (%s) x %.0f waves per launch x 2 cycles / (1024 SIMDs x %.1f GHz) / avg_launch" % (vpw, vpw_src, waves, CLOCK_GHZ)
+
         def sor_entry(batch, n, ms, by, kernel=None):
             steps = W + H + 2 * SWEEPS
-            e = {"batch": batch, "avg_launch_ms": round(ms / n, 4), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
-                 "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            e = {"batch": batch, "avg_launch_ms": round(ms / n, 4), "algorithmic_gbs_8d": round(by / (ms * 1e-3) / 1e9, 1),
+                 "hbm_frac_compulsory": round(48.0 * W * H * batch * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "mpix_iters_per_s": round(W * H * SWEEPS * batch * n / 1e6 / (ms * 1e-3), 1),
                  "us_per_solve": round(ms / n * 1e3 / batch, 1),
                  # the launch against the length of the dependency chain: microseconds per hyperplane step, and how many times the ALU-latency floor that is
@@ -696,23 +757,25 @@ def main():
         if sor16:
             out["roofline"]["sor_1024x436_batch16"] = sor_entry(16, sor16[0], sor16[1], sor16[2], sor16[3])
         # second kernel of the step: the data-term assembly (about 40 % of it).  VALU bound: wave instructions issued per second against the chip's
-        # issue rate (256 CUs x 4 SIMDs, one wave instruction per 4 cycles).  Instructions per pixel and term from the SQ counter pass of the same
+        # issue rate (256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles).  Instructions per pixel and term from the SQ counter pass of the same
         # kernel (profiles/), duration live from HIP events around every launch of the timed region.
         if n_asm:
             ipt, ipt_src, valu_active = assemble_valu_per_pixel_term()
-            peak_issue = 256 * 4 * CLOCK_GHZ * 1e9 / 4.0
+            peak_issue = 256 * 4 * CLOCK_GHZ * 1e9 / 2.0         # a SIMD-32 issues a wave64 VALU instruction over 2 cycles (MI355X_MICROARCH.md): 1229 G/s
             ach = (ipt * asm_px / 64.0) / (asm_ms * 1e-3) if ipt else None
             out["roofline_assemble"] = {"kernel": "k_assemble_images<8,512,4>", "bound": "valu", "launches": n_asm, "avg_launch_ms": round(asm_ms / n_asm, 4),
                                         "pixel_terms_per_launch": round(asm_px / n_asm), "valu_instructions_per_pixel_term": ipt, "source": ipt_src,
                                         "achieved": (round(ach / 1e9, 2) if ach else None), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s",
                                         "frac": (round(ach / peak_issue, 4) if ach else None),
-                                        # the SIMDs' own view from the same counter pass: share of their time with a VALU instruction in flight when the kernel runs
-                                        # alone (divisions, square roots and reciprocals occupy a SIMD for more than the 4 cycles the issue model charges)
+                                        # the SIMDs' own view from the same counter pass: SQ_ACTIVE_INST_VALU x 4 / SIMD cycles when the kernel runs alone.  The counter
+                                        # charges a quad-cycle (4 cycles) per wave instruction where the SIMD-32 needs 2, so it reads about twice the issue-slot use
                                         "valu_active_frac_alone": valu_active,
                                         "share_of_step": round(asm_ms / S / (elapsed * 1e3), 4),
                                         "note": "launch durations are those inside the timed region, where the other stream's kernels share the GPU (alone: about half)"}
         if strong is not None:
             out["config4_strong"] = strong
+        if strong5 is not None:
+            out["config5_strong"] = strong5
         try:
             lat, sor1, rb = one_window_latency(ctx)
             out["latency_one_window_ms"] = round(lat, 3)

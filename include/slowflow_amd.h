@@ -225,6 +225,13 @@ int  sfa_sor_batch_upload(sfa_sor_batch *sb, int b, const float *du, const float
 int  sfa_sor_batch_run(sfa_sor_batch *sb, int iterations, float omega);   /* prepare + solve + finish, async */
 int  sfa_sor_batch_download(sfa_sor_batch *sb, int b, float *du, float *dv, int stride);
 
+/* ---- test hook: the bound of the solver's in-kernel waits --------------------------------------------------------------------------
+ * Every wait of one workgroup for another inside the SOR kernels is bounded (2^22 polls); a wait that gives up poisons the launch, every other wait
+ * of the launch gives up at its next look at the error word, the kernel drains, and the entry point returns SFA_ERR_TIMEOUT.  `spins` > 0 shortens
+ * that bound for this context (1: any wait that is not satisfied at once gives up) so that the path can be exercised; 0 restores the default.
+ * A context that has returned SFA_ERR_TIMEOUT stays usable: progress words, tickets and the error word are reset by the next launch. */
+int  sfa_ctx_set_wait_bound(sfa_ctx *ctx, unsigned spins);
+
 /* ---- test hook: the division of the normalised data terms --------------------------------------------------------------------
  * The cfg-default instance of the fused assembly kernel forms the quotients r^2 / n and t / n of variational_aux_mt.cpp:240-250, 333-347, 479-490, 556-572
  * with the hardware's correctly-rounded chain and ONE refined reciprocal per denominator, behind range guards (kernels.hip: recip_of / div_by / num_ok).

@@ -104,6 +104,17 @@ try:
         sqj["kernel"] = sor_k[0]
     # the data-term assembly kernel: VALU instructions one pixel spends per data term = wave instructions x 64 lanes / (pixels x terms) of a launch
     # (bench configuration: 5 levels, 2 terms, `batch` windows per launch; the mean over the launches of all levels against the mean level size)
+    # per-wave instruction counts (SQ_INSTS_* / SQ_WAVES summed over all dispatches of the kernel: independent of how many windows a dispatch carried)
+    def per_wave(k, name):
+        return sum(sq[k][name]) / sum(sq[k]["SQ_WAVES"]) if sq[k].get(name) and sq[k].get("SQ_WAVES") and sum(sq[k]["SQ_WAVES"]) else None
+    if sor_k and per_wave(sor_k[0], "SQ_INSTS_VALU"):
+        sqj["sor_valu_inst_per_wave"] = round(per_wave(sor_k[0], "SQ_INSTS_VALU"), 1)
+        sqj["sor_lds_inst_per_wave"] = round(per_wave(sor_k[0], "SQ_INSTS_LDS") or 0, 1)
+    asm_all = [k for k in sq if "k_assemble_images" in k and sq[k].get("SQ_INSTS_VALU") and sq[k].get("SQ_WAVES")]
+    if asm_all:
+        sqj["assemble_valu_inst_per_wave"] = round(sum(sum(sq[k]["SQ_INSTS_VALU"]) for k in asm_all) / sum(sum(sq[k]["SQ_WAVES"]) for k in asm_all), 1)
+        sqj["assemble_lds_inst_per_wave"] = round(sum(sum(sq[k]["SQ_INSTS_LDS"]) for k in asm_all) / sum(sum(sq[k]["SQ_WAVES"]) for k in asm_all), 1)
+        sqj["assemble_per_wave_note"] = "a wave = 64 pixels of a 64 x 8 tile x all data terms of the level (2 in the bench configuration), staging and epilogue included"
     asm_k = [k for k in sq if "k_assemble_images" in k and sq[k].get("SQ_INSTS_VALU")]
     if asm_k:
         LV = [(1024, 436), (921, 392), (828, 352), (745, 316), (670, 284)]

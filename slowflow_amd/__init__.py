@@ -70,7 +70,7 @@ EXPORTS = [
     "sfa_sequence_create", "sfa_sequence_destroy", "sfa_sequence_upload", "sfa_sequence_download", "sfa_sequence_normalize",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_upload_resident", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters", "sfa_job_device_bytes",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
-    "sfa_division_chain", "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
+    "sfa_division_chain", "sfa_ctx_set_wait_bound", "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
 ]
 
 _lib = None
@@ -299,6 +299,10 @@ class Context:
         name = C.create_string_buffer(160)
         self._ck(lib().sfa_profile_read_kernels(self.h, C.byref(n), C.byref(ms), C.byref(px), name, 160), "sfa_profile_read_kernels")
         return n.value, ms.value, px.value, name.value.decode()
+
+    def set_wait_bound(self, spins):
+        """test hook: bound of the solver's in-kernel waits in polls (0 = the default of 2^22); see include/slowflow_amd.h"""
+        self._ck(lib().sfa_ctx_set_wait_bound(self.h, C.c_uint(int(spins))), "sfa_ctx_set_wait_bound")
 
     def division_chain(self, a, b):
         """(q_chain, q_exact, admitted) of the shared-reciprocal division test hook (include/slowflow_amd.h: sfa_division_chain)"""

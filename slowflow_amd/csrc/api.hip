@@ -541,6 +541,12 @@ int sfa_profile_read(sfa_ctx *c, int *n, double *ms_total, double *bytes_total) 
     c->sor_bytes = 0;
     return SFA_OK;
 }
+int sfa_ctx_set_wait_bound(sfa_ctx *c, unsigned spins) {
+    if (!c) return SFA_ERR_ARG;
+    SFA_HIP(c, hipMemcpyAsync(c->d_err + 1, &spins, sizeof spins, hipMemcpyHostToDevice, c->stream));
+    SFA_HIP(c, hipStreamSynchronize(c->stream));
+    return SFA_OK;
+}
 int sfa_timer_start(sfa_ctx *c) {
     if (!c) return SFA_ERR_ARG;
     SFA_HIP(c, hipEventRecord(c->t0, c->stream));

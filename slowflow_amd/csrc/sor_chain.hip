@@ -357,14 +357,18 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // bounded wait for one progress word through the flags descriptor; `dead` (uniform): a wait has given up, never wait again
 __device__ __forceinline__ unsigned chain_wait(__amdgpu_buffer_rsrc_t rF, unsigned voff, unsigned soff, unsigned target, unsigned *err, bool &dead) {
-    unsigned spins = 0;
+    unsigned spins = 0, limit = kSpinLimit;
     for (;;) {
         const unsigned v = __builtin_amdgcn_readfirstlane(bload4_sc1(rF, voff, soff));
         if (v >= target || dead) return v;
+        if (spins == 0) {                                   // slow path only: err[1] != 0 shortens the bound (test hook sfa_ctx_set_wait_bound)
+            const unsigned o = ld_flag(err + 1);
+            if (o) limit = o;
+        }
         __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0) {
+        if ((++spins & 1023u) == 0 || spins > limit) {
             const unsigned e = ld_flag(err);
-            if (e || spins > kSpinLimit) {
+            if (e || spins > limit) {
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dead = true;
                 return v;

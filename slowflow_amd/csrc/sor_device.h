@@ -105,14 +105,18 @@ __device__ __forceinline__ void bstore8(__amdgpu_buffer_rsrc_t r, unsigned voff,
 
 // bounded relaxed poll of one progress word (wave-uniform); returns the value seen (>= target) or 0xffffffff on give-up
 __device__ __forceinline__ unsigned wait_ge(const unsigned *p, unsigned target, unsigned *err) {
-    unsigned spins = 0;
+    unsigned spins = 0, limit = kSpinLimit;
     for (;;) {
         const unsigned v = ld_flag(p);
         if (v >= target) return v;
+        if (spins == 0) {                                   // slow path only: err[1] != 0 shortens the bound (test hook sfa_ctx_set_wait_bound)
+            const unsigned o = ld_flag(err + 1);
+            if (o) limit = o;
+        }
         __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0) {
+        if ((++spins & 1023u) == 0 || spins > limit) {
             const unsigned e = ld_flag(err);
-            if (e || spins > kSpinLimit) {
+            if (e || spins > limit) {
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return 0xffffffffu;
             }
