@@ -26,6 +26,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -145,6 +146,19 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     }
     if (start_f > end_f) return 0;
 
+    // the two output files of jet j, and whether the jet still has work (-resume skips existing flows, :712-716 / :934-938)
+    auto flow_files = [&](unsigned j, string &fwd, string &bwd) {
+        const int f = j * steps;
+        fwd = sintel ? fmt2(params.output + format_flow + ".flo", start + f * skip, 0) : fmt1(params.output + format_flow + ".flo", start + f * skip);
+        bwd = sintel ? fmt2(params.output + format_flow + "_back.flo", start + f * skip + steps * skip, 0)
+                     : fmt1(params.output + format_flow + "_back.flo", start + f * skip + steps * skip);
+    };
+    auto jet_pending = [&](unsigned j) {
+        if (!opt.resume_frame) return true;
+        string fwd, bwd;
+        flow_files(j, fwd, bwd);
+        return !file_exists(fwd) || !file_exists(bwd);
+    };
     // ---- deep_matching 1 (:744-863): the flow is initialised by EpicFlow's interpolation (epic.h) of DeepMatching matches along SED edges.  The reference starts
     //      both tools with system() (MATLAB + a binary, third-party); this build reads their outputs from the reference's own locations and says so if they are missing.
     const bool enable_dm = params.parameter<bool>("deep_matching");
@@ -153,6 +167,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     if (enable_dm) {
         if (params.parameter<float>("dm_scale", "1.0") != 1.0f) { std::cerr << "deep_matching with dm_scale != 1 is not supported: provide matches and edges at the frames' resolution" << std::endl; return 2; }
         for (unsigned j = start_j; j < end_j; j++) {
+            if (!jet_pending(j)) continue;                                           // -resume: a jet whose two flows exist is skipped below and needs no inputs
             const int a = (int)params.sequence_start + (int)j * steps * skip, b = a + ref * skip;
             const string need[4] = {edges_file(a), edges_file(b), matches_file(a, b), matches_file(b, a)};
             for (const string &f : need)
@@ -361,9 +376,8 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     std::vector<Window> todo;
     for (unsigned j = start_j; j < end_j; j++) {
         const int f = j * steps;
-        const string fwd = sintel ? fmt2(params.output + format_flow + ".flo", start + f * skip, 0) : fmt1(params.output + format_flow + ".flo", start + f * skip);
-        const string bwd = sintel ? fmt2(params.output + format_flow + "_back.flo", start + f * skip + steps * skip, 0)
-                                  : fmt1(params.output + format_flow + "_back.flo", start + f * skip + steps * skip);
+        string fwd, bwd;
+        flow_files(j, fwd, bwd);
         if (!opt.resume_frame || !file_exists(fwd)) todo.push_back(Window(j, false, fwd));
         else std::cout << "Forward flow from frame " << start + f << " to " << start + f * skip + steps * skip << " already exist!" << std::endl;
         if (!opt.resume_frame || !file_exists(bwd)) todo.push_back(Window(j, true, bwd));
@@ -420,7 +434,57 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         const int device = device_of(wp.gpu);
         sfa_ctx *ctx = nullptr;
         if (sfa_ctx_create(device, &ctx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; return; }
+        sfa_ctx *ectx = nullptr;                                                     // the EpicFlow helper's context (deep_matching 1 only)
+        if (enable_dm && sfa_ctx_create(device, &ectx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; sfa_ctx_destroy(ctx); return; }
         ParameterList tp(params);                                                    // one copy per thread (:708)
+        // EpicFlow's interpolation of the matches of one window (:801-863 / :960-1004), per single frame step.  It runs on a helper thread with a context of its
+        // own (the library's contexts are thread-compatible, not thread-safe), one batch ahead of the refinement: while the GPU refines batch n the host prepares
+        // the initial flows of batch n + 1 (round 3 ran it inside the worker thread, in front of every batch -- ADVICE r2)
+        struct EpicInit { image_t *wx = nullptr, *wy = nullptr; int rc = SFA_OK; };
+        auto epic_init = [&](const Window &wd, sfa_ctx *ctx, EpicInit &out) {
+            int rc = SFA_OK;
+            image_t *iwx = nullptr, *iwy = nullptr;
+            const int f = wd.jet * steps;
+            {
+                const int a = (int)params.sequence_start + f * skip, b = a + ref * skip;
+                const color_image_t *un_ref = seq[wd.backward ? f + 2 * ref : f + ref];      // un_im[ref] / un_im_back[ref]: the window's reference frame, not normalised
+                epic_matches mt;
+                epic_edges ed;
+                epic_params_t ep;
+                epic_params_default(&ep);
+                ep.pref_nn = 25; ep.nn = 160; ep.coef_kernel = 1.1f;         // :271-275
+                if (!read_matches((wd.backward ? matches_file(b, a) : matches_file(a, b)).c_str(), mt) ||
+                    !read_edges((wd.backward ? edges_file(b) : edges_file(a)).c_str(), width, height, ed)) rc = SFA_ERR_ARG;
+                else {
+                    // the reference hands epic() un_seq: the frame after img.convertTo(CV_8U, norm), i.e. rounded to nearest and saturated to 0..255,
+                    // 16-bit samples scaled by 1/255 first (slow_flow.cpp:472-474, :578-586) -- not the float frame the refinement reads
+                    const int fi = wd.backward ? f + 2 * ref : f + ref;
+                    color_image_t *un8 = color_image_new(un_ref->width, un_ref->height);
+                    {
+                        const float norm = seq_maxval[fi] > 255 ? 1.0f / 255 : 1.0f;
+                        const size_t n3 = (size_t)3 * un_ref->stride * un_ref->height;
+                        for (size_t i = 0; i < n3; i++) {
+                            const float v = nearbyintf(un_ref->c1[i] * norm);              // cvRound: to nearest, ties to even
+                            un8->c1[i] = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);       // saturate_cast<uchar>
+                        }
+                    }
+                    color_image_t *lab = rgb_to_lab(un8);
+                    color_image_delete(un8);
+                    iwx = image_new(width, height); iwy = image_new(width, height);
+                    image_erase(iwx); image_erase(iwy);
+                    const int er = epic(ctx, iwx, iwy, lab, mt, ed, &ep);
+                    color_image_delete(lab);
+                    if (er < 0) rc = SFA_ERR_HIP;
+                    else if (er > 0) { image_erase(iwx); image_erase(iwy); }  // no usable match: start from zero like deep_matching 0
+                    image_mul_scalar(iwx, 1.0f / steps);                    // :842-843
+                    image_mul_scalar(iwy, 1.0f / steps);
+                    if (rc == SFA_OK && params.verbosity(WRITE_FILES) && !wd.backward)     // :845-858
+                        png_write((params.output + "tmp/frame_" + std::to_string(a) + "_INIT.png").c_str(), flowColorImg(iwx, iwy, 0));
+                }
+                if (rc != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << "EpicFlow initialisation of jet " << wd.jet << " failed" << std::endl; }
+            }
+            out.wx = iwx; out.wy = iwy; out.rc = rc;
+        };
         // forward and backward windows share one lockstep job (the channel weights are per window) unless the backward solver runs with
         // different parameters ("method forward", :1019-1020): then one pass per direction
         for (int dirpass = 0; dirpass < (backward_forward_only ? 2 : 1) && !failed; dirpass++) {
@@ -433,8 +497,21 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
             sfa_job *job = nullptr;
             int job_nb = 0;
             int rc = SFA_OK;
+            auto batch_inits = [&](size_t b0) {
+                const int nb = (int)std::min((size_t)batch, mine.size() - b0);
+                std::vector<EpicInit> v(nb);
+                for (int e = 0; e < nb; e++) epic_init(todo[mine[b0 + e]], ectx, v[e]);
+                return v;
+            };
+            std::future<std::vector<EpicInit>> next_inits;
+            if (enable_dm) next_inits = std::async(std::launch::async, batch_inits, (size_t)0);
             for (size_t b0 = 0; b0 < mine.size() && rc == SFA_OK && !failed; b0 += batch) {
                 const int nb = (int)std::min((size_t)batch, mine.size() - b0);
+                std::vector<EpicInit> inits;
+                if (enable_dm) {
+                    inits = next_inits.get();
+                    if (b0 + batch < mine.size()) next_inits = std::async(std::launch::async, batch_inits, b0 + batch);
+                }
                 const auto t0 = std::chrono::steady_clock::now();
                 if (!job || job_nb != nb) {
                     if (job) sfa_job_destroy(job);
@@ -450,53 +527,15 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                     std::vector<int> idx(F);
                     for (int k = 0; k < F; k++) idx[k] = (wd.backward ? f + 3 * steps - k : f + k) - (int)start_f;
                     const float *chw[3] = {channel_weights->c1, channel_weights->c2, channel_weights->c3};
-                    image_t *iwx = nullptr, *iwy = nullptr;
-                    if (enable_dm) {                                                 // :801-863 / :960-1004: EpicFlow's interpolation of the matches, per single frame step
-                        const int a = (int)params.sequence_start + f * skip, b = a + ref * skip;
-                        const color_image_t *un_ref = seq[wd.backward ? f + 2 * ref : f + ref];      // un_im[ref] / un_im_back[ref]: the window's reference frame, not normalised
-                        epic_matches mt;
-                        epic_edges ed;
-                        epic_params_t ep;
-                        epic_params_default(&ep);
-                        ep.pref_nn = 25; ep.nn = 160; ep.coef_kernel = 1.1f;         // :271-275
-                        if (!read_matches((wd.backward ? matches_file(b, a) : matches_file(a, b)).c_str(), mt) ||
-                            !read_edges((wd.backward ? edges_file(b) : edges_file(a)).c_str(), width, height, ed)) rc = SFA_ERR_ARG;
-                        else {
-                            // the reference hands epic() un_seq: the frame after img.convertTo(CV_8U, norm), i.e. rounded to nearest and saturated to 0..255,
-                            // 16-bit samples scaled by 1/255 first (slow_flow.cpp:472-474, :578-586) -- not the float frame the refinement reads
-                            const int fi = wd.backward ? f + 2 * ref : f + ref;
-                            color_image_t *un8 = color_image_new(un_ref->width, un_ref->height);
-                            {
-                                const float norm = seq_maxval[fi] > 255 ? 1.0f / 255 : 1.0f;
-                                const size_t n3 = (size_t)3 * un_ref->stride * un_ref->height;
-                                for (size_t i = 0; i < n3; i++) {
-                                    const float v = nearbyintf(un_ref->c1[i] * norm);              // cvRound: to nearest, ties to even
-                                    un8->c1[i] = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);       // saturate_cast<uchar>
-                                }
-                            }
-                            color_image_t *lab = rgb_to_lab(un8);
-                            color_image_delete(un8);
-                            iwx = image_new(width, height); iwy = image_new(width, height);
-                            image_erase(iwx); image_erase(iwy);
-                            const int er = epic(ctx, iwx, iwy, lab, mt, ed, &ep);
-                            color_image_delete(lab);
-                            if (er < 0) rc = SFA_ERR_HIP;
-                            else if (er > 0) { image_erase(iwx); image_erase(iwy); }  // no usable match: start from zero like deep_matching 0
-                            image_mul_scalar(iwx, 1.0f / steps);                    // :842-843
-                            image_mul_scalar(iwy, 1.0f / steps);
-                            if (rc == SFA_OK && params.verbosity(WRITE_FILES) && !wd.backward)     // :845-858
-                                png_write((params.output + "tmp/frame_" + std::to_string(a) + "_INIT.png").c_str(), flowColorImg(iwx, iwy, 0));
-                        }
-                        if (rc != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << "EpicFlow initialisation of jet " << wd.jet << " failed" << std::endl; }
-                    }
+                    image_t *iwx = enable_dm ? inits[e].wx : nullptr, *iwy = enable_dm ? inits[e].wy : nullptr;
+                    if (enable_dm && inits[e].rc != SFA_OK) rc = inits[e].rc;
                     // only the forward solver gets the channel weights (:876 vs :1018); without raw weighting they are all ones (:597-598), which is
                     // what a NULL pointer means to the library (x * 1.0f is exact: same bits, three planes less to read per pixel)
                     if (rc == SFA_OK)
                         rc = sfa_job_upload_resident(job, e, seq_dev[wp.gpu], idx.data(), F, iwx ? iwx->data : nullptr, iwy ? iwy->data : nullptr, seq[start_f]->stride,
                                                      (wd.backward || !raw) ? nullptr : chw);
-                    if (iwx) image_delete(iwx);
-                    if (iwy) image_delete(iwy);
                 }
+                for (EpicInit &ei : inits) { if (ei.wx) image_delete(ei.wx); if (ei.wy) image_delete(ei.wy); }
                 if (rc == SFA_OK) rc = sfa_job_run(job);
                 std::vector<std::shared_ptr<WindowResult>> results;
                 for (int e = 0; e < nb && rc == SFA_OK; e++) {
@@ -536,8 +575,11 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                               << " finished! (GPU " << wp.gpu << " = device " << device << ", " << secs / nb << " s per window in a batch of " << nb << ")" << std::endl;
                 }
             }
+            if (next_inits.valid())                                                  // left early: the batch prepared ahead is not used
+                for (EpicInit &ei : next_inits.get()) { if (ei.wx) image_delete(ei.wx); if (ei.wy) image_delete(ei.wy); }
             if (job) sfa_job_destroy(job);
         }
+        if (ectx) sfa_ctx_destroy(ectx);
         sfa_ctx_destroy(ctx);
     };
     const auto t_compute = std::chrono::steady_clock::now();
