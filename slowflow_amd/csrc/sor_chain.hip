@@ -141,8 +141,15 @@ struct ChainLds {
     // sweep kappa of stage w reads, at its local step s, the row of step s + w - 2 kappa, kappa lanes down.  OPW entries per row: KG - 1 entries of the
     // band above (IN wave), then the 64 of this band (first stage); OPR rows: a row is last read 3 (NW - 1) + 2 (KG - 1) + 3 steps after the first
     // stage used it, and its slot is rewritten (IN wave: the entries of the band above) up to 5 steps before the first stage gets there again
-    static constexpr int OPW = 64 + S::KG - 1, OPROWB = OPW * 16, OPR = 3 * (S::NW - 1) + 2 * (S::KG - 1) + 10, OPPLANE = OPR * OPROWB;
+    // Depth: with barrier lockstep (stage w runs chunk I - LEAD - w in interval I, the IN wave writes the band-above entries of chunk c at interval c + AH = LEAD - 1 + c)
+    // row r is last read -- stage NW - 1, sweep KG - 1, for its step r - NW + 2 KG - 2 -- in interval LEAD + NW - 1 + floor((r + 2 KG - 2 - NW) / 4)
+    // = LEAD - 1 + floor((r + 3 NW + 2 KG - 2) / 4), and its slot is first rewritten (IN wave, row r + OPR) in interval LEAD - 1 + floor((r + OPR) / 4): strictly later for
+    // every r iff OPR >= 3 NW + 2 KG + 2 = 3 (NW - 1) + 2 (KG - 1) + 9.  One spare row where it fits (OPR10); the six-stage shapes of 15 sweeps (3,3,3,2,2,2) fit the
+    // 160 KB only at the minimum.
+    static constexpr int OPW = 64 + S::KG - 1, OPROWB = OPW * 16, OPRMIN = 3 * (S::NW - 1) + 2 * (S::KG - 1) + 9;
     static constexpr int ops0 = (dummy0 + DUMMY + 15) & ~15;
+    static constexpr bool OPR10 = ops0 + 2 * (OPRMIN + 1) * OPROWB + 32 <= 160 * 1024;
+    static constexpr int OPR = OPR10 ? OPRMIN + 1 : OPRMIN, OPPLANE = OPR * OPROWB;
     static constexpr bool OPRING = SFA_CHAIN_OPRING && S::KG <= 16 && ops0 + 2 * OPPLANE + 32 <= 160 * 1024;
     static constexpr int ticket = ops0 + (OPRING ? 2 * OPPLANE : 0);
     static constexpr int total = ticket + 16;
@@ -836,6 +843,8 @@ static const ChainShapeInfo kChainShapes[] = {
     {8, 3, 2, 3, 0, 2},      // 2 stages of 3                  KG = 6
     {9, 5, 6, 5, 0, 2},      // 6 stages of 5                  KG = 30: a whole band per workgroup (large batches)
     {10, 3, 10, 3, 0, 2},    // 10 stages of 3                 KG = 30
+    {11, 3, 3, 2, 3, 2},     // 3 stages of 3 + 3 of 2         KG = 15: with the I/O waves 8 waves, two per SIMD, at most 5 sweeps on a SIMD (5 x 3: 6)
+    {12, 2, 3, 3, 3, 2},     // 3 stages of 2 + 3 of 3         KG = 15
 };
 
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
@@ -853,8 +862,12 @@ int chain_ch() { return kChainCH; }
 void chain_kernel_name(int id, int NG, char *buf, size_t n) {
     for (const ChainShapeInfo &s : kChainShapes)
         if (s.id == id) {
-            snprintf(buf, n, "k_sor_chain<%d,%d,%d,%d,%d,%d,%d,%d,%d> (%d stages of %d sweeps, %d groups per band)", s.FA, s.NA, s.FB, s.NB_, kChainCH, s.PD, kChainAH, kChainPL, kChainPUBD,
-                     s.NA + s.NB_, s.FA, NG);
+            if (s.NB_ && s.FB != s.FA)
+                snprintf(buf, n, "k_sor_chain<%d,%d,%d,%d,%d,%d,%d,%d,%d> (%d stages of %d + %d of %d sweeps, %d groups per band)", s.FA, s.NA, s.FB, s.NB_, kChainCH, s.PD, kChainAH,
+                         kChainPL, kChainPUBD, s.NA, s.FA, s.NB_, s.FB, NG);
+            else
+                snprintf(buf, n, "k_sor_chain<%d,%d,%d,%d,%d,%d,%d,%d,%d> (%d stages of %d sweeps, %d groups per band)", s.FA, s.NA, s.FB, s.NB_, kChainCH, s.PD, kChainAH, kChainPL, kChainPUBD,
+                         s.NA + s.NB_, s.FA, NG);
             return;
         }
     snprintf(buf, n, "k_sor_chain shape %d", id);
@@ -871,6 +884,8 @@ int chain_shift(int id) {
         case 8: return shape_shift<3, 2, 3, 0>();
         case 9: return shape_shift<5, 6, 5, 0>();
         case 10: return shape_shift<3, 10, 3, 0>();
+        case 11: return shape_shift<3, 3, 2, 3>();
+        case 12: return shape_shift<2, 3, 3, 3>();
     }
     return 0;
 }
@@ -918,6 +933,8 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
         case 8: return chain_launch_shape<3, 2, 3, 0, 2>(c, a, nwg);
         case 9: return chain_launch_shape<5, 6, 5, 0, 2>(c, a, nwg);
         case 10: return chain_launch_shape<3, 10, 3, 0, 2>(c, a, nwg);
+        case 11: return chain_launch_shape<3, 3, 2, 3, 2>(c, a, nwg);
+        case 12: return chain_launch_shape<2, 3, 3, 3, 2>(c, a, nwg);
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }
 }

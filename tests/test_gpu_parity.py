@@ -225,7 +225,7 @@ def test_sor_golden(ctx, w, h):
         assert np.array_equal(s["dv"][:, :w], G[f"sor_{w}x{h}_K{K}_dv"][:, :w])
 
 
-@pytest.mark.parametrize("nb,shape", [(1, "k_sor_chain<1,5,1,0"), (8, "k_sor_chain<1,5,1,0"), (16, "k_sor_chain<3,5,3,0"), (64, "k_sor_chain<3,5,3,0")])
+@pytest.mark.parametrize("nb,shape", [(1, "k_sor_chain<1,5,1,0"), (8, "k_sor_chain<1,5,1,0"), (16, "k_sor_chain<3,3,2,3"), (64, "k_sor_chain<3,3,2,3")])
 def test_default_solver_shape_and_its_bits(ctx, oracle, nb, shape):
     """what the library launches by default at 1024x436 x 30 for 1 / 8 / 16 / 64 systems per launch (round 3: the chain kernel with the operand ring at every
     batch size -- five stages of one sweep up to 96 bands per launch, five stages of three above), and that the first and the last system of the launch are
@@ -282,7 +282,9 @@ SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH":
                 # sor_chain.hip (few windows per launch): groups of stages per workgroup + I/O wave; a shape whose sweeps per group do not divide K
                 # falls back to the kernels above
                 "chain_1x3": {"SFA_SOR_CHAIN": "1"}, "chain_2x3": {"SFA_SOR_CHAIN": "2"}, "chain_3x5": {"SFA_SOR_CHAIN": "3"}, "chain_2x5": {"SFA_SOR_CHAIN": "5"},
-                "chain_1x5": {"SFA_SOR_CHAIN": "6"}, "chain_3x2": {"SFA_SOR_CHAIN": "8"}, "chain_5x6": {"SFA_SOR_CHAIN": "9"}, "chain_3x10": {"SFA_SOR_CHAIN": "10"}}
+                "chain_1x5": {"SFA_SOR_CHAIN": "6"}, "chain_3x2": {"SFA_SOR_CHAIN": "8"}, "chain_5x6": {"SFA_SOR_CHAIN": "9"}, "chain_3x10": {"SFA_SOR_CHAIN": "10"},
+                # six stages of mixed width (15 sweeps per group: K = 15, 30; other K fall back): the operand ring at its minimum depth
+                "chain_3x3_2x3": {"SFA_SOR_CHAIN": "11"}, "chain_2x3_3x3": {"SFA_SOR_CHAIN": "12"}}
 
 
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))

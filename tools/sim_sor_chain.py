@@ -35,7 +35,10 @@ def start_shift(S):
     tv0 = (NW + 1) * ring; tvw = 2 * CH * (FMAX + 1) * 8; es0 = tv0 + NW * tvw; esw = 2 * (FMAX - 1 if FMAX > 1 else 1) * CH * 8
     dummy0 = es0 + NW * esw; dummy = 64 * 8 + esw
     ops0 = (dummy0 + dummy + 15) & ~15
-    opplane = (3 * (NW - 1) + 2 * (KG - 1) + 10) * (64 + KG - 1) * 16
+    oprowb = (64 + KG - 1) * 16
+    oprmin = 3 * (NW - 1) + 2 * (KG - 1) + 9                       # ChainLds::OPRMIN; one spare row where it fits
+    opr = oprmin + 1 if ops0 + 2 * (oprmin + 1) * oprowb + 32 <= 160 * 1024 else oprmin
+    opplane = opr * oprowb
     opring = KG <= 16 and ops0 + 2 * opplane + 32 <= 160 * 1024
     return (2 if KG <= 10 else 4) if opring else 0
 
