@@ -55,6 +55,21 @@ def pmc(d, counter):
     return per
 
 
+# the two dominant kernels ALONE (pass 6: one stream, nothing else on the GPU), by launch size: grid = windows x tiles (assembly) / workgroups (solver)
+try:
+    rows1 = list(csv.DictReader(open(find(f"{tag}_stats1", "kernel_trace.csv"))))
+    acc1 = collections.defaultdict(list)
+    for r in rows1:
+        k = r["Kernel_Name"].split("(")[0]
+        if "k_assemble_images" in k or "k_sor_chain" in k:
+            acc1[(k, int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    with open(os.path.join(out, f"{tag}_alone_by_level.csv"), "w") as f:
+        f.write("kernel,grid_threads,dispatches,avg_us,min_us,max_us\n")
+        for (k, g), v in sorted(acc1.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
+            f.write(f"\"{k}\",{g},{len(v)},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f}\n")
+except FileNotFoundError:
+    pass
+
 fetch, write = pmc(f"{tag}_fetch", "FETCH_SIZE"), pmc(f"{tag}_write", "WRITE_SIZE")
 res = {"batch": batch, "batch_note": "windows per SOR launch (bench.py: --batch / --streams)", "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B by rocprofv3; x2 on FETCH_SIZE per MI355X_MICROARCH.md (gfx950)",
        "kernels": {}}
