@@ -30,6 +30,13 @@ def cfg5(p):
     for pen in (p.robust_color, p.robust_grad, p.robust_reg): pen.id=2; pen.eps=0.05
     return p
 
-run("config 4 share (cfg schedule, thresholds may stop iterations early)", 1024, 436, 5, 16, cfg_schedule)
-run("config 3 stand-in (cfg schedule)", 2560, 1440, 5, 4, cfg_schedule)
-run("config 5 (2048x2048, 6 levels, Lorentzian, 5 outer x 30 sweeps)", 2048, 2048, 3, 8, cfg5)
+if __name__ == "__main__":
+    only = sys.argv[1:] or ["4", "3", "5"]
+    if "4" in only:
+        run("config 4 share (cfg schedule, thresholds may stop iterations early)", 1024, 436, 5, 16, cfg_schedule)
+    if "3" in only:
+        run("config 3 stand-in (cfg schedule)", 2560, 1440, 5, 4, cfg_schedule)
+        run("config 3 stand-in (cfg schedule)", 2560, 1440, 5, 8, cfg_schedule)
+    if "5" in only:
+        run("config 5 (2048x2048, 6 levels, Lorentzian, 5 outer x 30 sweeps)", 2048, 2048, 3, 8, cfg5)
+        run("config 5 (2048x2048, 6 levels, Lorentzian, 5 outer x 30 sweeps)", 2048, 2048, 3, 32, cfg5)
