@@ -589,8 +589,8 @@ __device__ __forceinline__ float div_by(float a, const Recip &d) {
 // V_DIV_SCALE_F32).  The guards below admit   b in [2^-27, 2^33)   (the data terms' denominators are sums of squares + 0.01: only the upper bound can fail) and
 // a = +0  or  a in [2^-87, 2^53)   (for a = +0 the chain returns +0 like the division): exponent differences stay within (-121, 81).  The squared residuals
 // are checked per pixel; the second numerator, the weight t = mask weight * (rho delta / 3 or rho gamma / 3) * psi'(s), is in range whenever the scalars are
-// (launch_assemble_images: hd, hg in [2^-16, 2^16], data_norm in [2^-8, 2^8], eps in [2^-20, 2^20]; the mask weights are 0, 1, 1 / data_norm or 1 / (2 data_norm),
-// s < 6 * 2^53 / 0.01 by the first guard, so t = +0 or 2^-58 < t < 2^43) -- AssembleArgs::chain_ok, evaluated on the host.  A wave in which any live lane fails a guard takes the __fdiv_rn path for that group of quotients (wave-uniform branch): same bits either way,
+// (launch_assemble_images, modified L1: hd, hg in [2^-16, 2^16], data_norm in [2^-8, 2^8], eps in [2^-20, 2^20]; the mask weights are 0, 1, 1 / data_norm or 1 / (2 data_norm),
+// s < 6 * 2^53 / 0.01 by the first guard, so t = +0 or 2^-58 < t < 2^43; Lorentzian: hd, hg >= 2^-12 and eps in [2^-10, 2^10] give 2^-85 < t < 2^43) -- AssembleArgs::chain_ok, evaluated on the host.  A wave in which any live lane fails a guard takes the __fdiv_rn path for that group of quotients (wave-uniform branch): same bits either way,
 // checked on the GPU over the boundary cases (tests/test_gpu_parity.py::test_shared_reciprocal_division_is_ieee).  SFA_EXACT_DIV_ONLY (build flag): always the slow path.
 __device__ __forceinline__ bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
 __device__ __forceinline__ unsigned num_key(float a) { return __float_as_uint(a) - 1u; }                 // +0 -> 0xffffffff, otherwise monotone in a >= 0
@@ -972,9 +972,9 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
 // Column borders: the staged planes carry REPLICATED columns outside the image, so the clamped taps of image.c:501-516
 // become fixed LDS offsets.  Row borders use folded coefficients (different expressions, image.c:433-457): rows are
 // wave-uniform here, so that is a scalar branch.
-// FAST: the cfg's defaults as compile-time constants (normalised data term, modified-L1 penalties, no channel weights): the same arithmetic with the
+// FAST = 1: the cfg's defaults as compile-time constants (normalised data term, modified-L1 penalties, no channel weights): the same arithmetic with the
 // penalty switch and the weight planes folded away -- fewer live registers, no spills (a spill reload is a vector-memory instruction, and a wait for it is a
-// wait for every DMA issued before it).
+// wait for every DMA issued before it).  FAST = 2: the same with Lorentzian penalties for both data terms (BASELINE config 5).  FAST = 0: everything at run time.
 // timing-only what-if builds (-DSFA_X_AI=bits, wrong results by construction, never shipped; tools/README.md): 1 no image DMA, 2 no conversion pass,
 // 4 no stage 1, 8 single reads instead of the second-derivative taps, 16 no term arithmetic, 32 no epilogue DMA, 64 no operand stores, 128 no prologue / mask loads
 #ifndef SFA_X_AI
@@ -988,7 +988,7 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
 #endif
 #define SFA_PRIO(p) do { if (SFA_PRIO_STAGE) __builtin_amdgcn_s_setprio(p); } while (0)
 struct XcdTiles { int nx, ny, chunk; };      // tile columns, tile rows, ceil(tiles of the launch / 8)
-template <int TY, int NT, int MINB, bool ZUV, bool FAST, bool XT>
+template <int TY, int NT, int MINB, bool ZUV, int FAST, bool XT>
 __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, const float *__restrict__ base, float *__restrict__ a11, float *__restrict__ a12,
                                                               float *__restrict__ a22, float *__restrict__ b1, float *__restrict__ b2,
                                                               const float *__restrict__ du, const float *__restrict__ dv, const float *__restrict__ uu,
@@ -1041,7 +1041,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     const int x = x0 + DT_H + tx;
     const int dt_norm = FAST ? 1 : a.dt_norm;
     PenaltyDev pcolor = a.color, pgrad = a.grad;
-    if (FAST) { pcolor.id = 1; pgrad.id = 1; }
+    if (FAST) { pcolor.id = FAST; pgrad.id = FAST; }
     Acc A[NP];
     float u[NP], v[NP], wk[NP][3], fwd[NP], bwd[NP], oc[NP];
     bool ok[NP];
@@ -1295,8 +1295,8 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 for (int ch = 0; ch < 3; ch++) {
                     A[k].a11 += p.ix[ch] + p.ixx[ch] + m; A[k].a12 += p.iy[ch] + p.ixy[ch]; A[k].a22 += p.iz[ch] + p.iyy[ch]; A[k].b1 += p.ixz[ch]; A[k].b2 += p.iyz[ch];
                 }
-            } else if (T.is_ref) term_ref<ZUV, FAST>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad, a.chain_ok != 0);
-            else          term_succ<ZUV, FAST>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad, a.chain_ok != 0);
+            } else if (T.is_ref) term_ref<ZUV, FAST != 0>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad, a.chain_ok != 0);
+            else          term_succ<ZUV, FAST != 0>(A[k], p, m, u[k], v[k], T.hd, T.hg, T.s, dt_norm, pcolor, pgrad, a.chain_ok != 0);
         }
     }
     // row strides chosen for the anti-diagonal read-out below (entry 64*rl + dl of a 65-wide row puts the TY rows of a diagonal into one bank group:
@@ -1380,11 +1380,15 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
     // the cfg's defaults (slow_flow_dataterm 1, modified-L1 penalties -- every id select_robust_function maps to the default class,
     // variational_aux_mt.cpp:909-925 --, no channel weights) take the instance with those choices folded in
     auto is_modl1 = [](int id) { return id != 0 && id != 2 && id != 3 && id != 4; };
-    const bool fast = a.dt_norm == 1 && is_modl1(a.color.id) && is_modl1(a.grad.id) && !a.chw && !getenv("SFA_ASSEMBLE_GENERIC");
-    {   // the shared-reciprocal divisions' precondition on the scalars (see recip_of / div_by)
+    const bool foldable = a.dt_norm == 1 && !a.chw && !getenv("SFA_ASSEMBLE_GENERIC");
+    const int fast = !foldable ? 0 : (is_modl1(a.color.id) && is_modl1(a.grad.id)) ? 1 : (a.color.id == 2 && a.grad.id == 2) ? 2 : 0;
+    {   // the shared-reciprocal divisions' precondition on the scalars (see recip_of / div_by): t = mask weight * hd (hg) * psi'(s) must be +0 or in [2^-87, 2^53).
+        // modified L1: psi' = 1 / (2 sqrt(s + eps^2)) in (2^-33, 2^19] for eps in [2^-20, 2^20] and s < 2^63; Lorentzian: psi' = 1 / (2 eps^2 + s) in (2^-64, 2^19] for eps
+        // in [2^-10, 2^10]; the mask weight is 0, 1, 1 / data_norm or 1 / (2 data_norm).
         auto in = [](float v, float lo, float hi) { return v >= lo && v <= hi; };
-        bool okp = fast && in(a.data_norm, 1.0f / 256, 256.0f) && in(a.color.eps, 1.0f / 1048576, 1048576.0f) && in(a.grad.eps, 1.0f / 1048576, 1048576.0f);
-        for (int t = 0; t < a.n && okp; t++) okp = (a.t[t].hd == 0.0f || in(a.t[t].hd, 1.0f / 65536, 65536.0f)) && (a.t[t].hg == 0.0f || in(a.t[t].hg, 1.0f / 65536, 65536.0f));
+        const float elo = fast == 2 ? 1.0f / 1024 : 1.0f / 1048576, ehi = fast == 2 ? 1024.0f : 1048576.0f, hlo = fast == 2 ? 1.0f / 4096 : 1.0f / 65536;
+        bool okp = fast != 0 && in(a.data_norm, 1.0f / 256, 256.0f) && in(a.color.eps, elo, ehi) && in(a.grad.eps, elo, ehi);
+        for (int t = 0; t < a.n && okp; t++) okp = (a.t[t].hd == 0.0f || in(a.t[t].hd, hlo, 65536.0f)) && (a.t[t].hg == 0.0f || in(a.t[t].hg, hlo, 65536.0f));
         a.chain_ok = okp && !getenv("SFA_EXACT_DIV") ? 1 : 0;
     }
     const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + 8 - 1) / 8, g.nb);
@@ -1401,8 +1405,8 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
     } while (0)
     // 64 x 8 tiles, 512 threads, 128 VGPRs (two blocks per CU).  Measured and dropped: 64 x 16 with two pixels per thread (209 VGPRs, one block per CU: slower),
     // 8 x 256 threads, 16 x 1024 threads (spills at its 128-register cap)
-    if (a.zero_duv) { if (fast) SFA_LAUNCH_AI(true, true); else SFA_LAUNCH_AI(true, false); }
-    else            { if (fast) SFA_LAUNCH_AI(false, true); else SFA_LAUNCH_AI(false, false); }
+    if (a.zero_duv) { if (fast == 1) SFA_LAUNCH_AI(true, 1); else if (fast == 2) SFA_LAUNCH_AI(true, 2); else SFA_LAUNCH_AI(true, 0); }
+    else            { if (fast == 1) SFA_LAUNCH_AI(false, 1); else if (fast == 2) SFA_LAUNCH_AI(false, 2); else SFA_LAUNCH_AI(false, 0); }
 #undef SFA_LAUNCH_AI
     if (prof) {
         (void)hipEventRecord(c->ev2[c->ev2_used + 1], c->stream);
