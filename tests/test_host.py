@@ -276,6 +276,10 @@ def test_driver_rejects_out_of_scope_inputs(host_build, tmp_path):
     cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t1\nstart\t1\nraw\t0\ndeep_matching\t1\n" % (tmp_path, tmp_path))
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg)], capture_output=True, text=True)
     assert r.returncode == 2 and "deep_matching" in r.stderr
+    # the limits that are narrower than the reference's: matches at another resolution than the frames' (dm_scale != 1) are refused by name, not misread
+    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t1\nstart\t1\nraw\t0\ndeep_matching\t1\ndm_scale\t0.5\n" % (tmp_path, tmp_path))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg)], capture_output=True, text=True)
+    assert r.returncode == 2 and "dm_scale" in r.stderr
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(tmp_path / "missing.cfg")], capture_output=True, text=True)
     assert r.returncode != 0 and "Couldn't find" in r.stderr
 
