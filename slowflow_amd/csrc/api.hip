@@ -165,6 +165,20 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     unsigned long long active = L.nb >= 64 ? ~0ull : ((1ull << L.nb) - 1);
     const unsigned long long all = active;
     Geo g = L.geo(active);
+    // The reference's per-iteration lines (variational_mt.cpp:404-405, 431-432: "inner it i avg change a,b" / "outer it i avg change a,b" under verbosity(VER_CMD)).
+    // Printing them needs the norms on the host after every iteration -- a synchronisation per iteration --, so it is off unless SFA_VERBOSE_CHANGES is set (the C++
+    // class and the driver set it when the cfg's `verbose` asks for it).  Batches print one line per window that still iterates, in window order.
+    const bool verbose = getenv("SFA_VERBOSE_CHANGES") != nullptr;
+    auto print_changes = [&](const char *what, int it, unsigned long long who) {
+        if (hipMemcpyAsync(c->h_red, c->d_red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
+        const double n = (double)L.w * L.h;
+        for (int b = 0; b < L.nb; b++)
+            if ((who >> b) & 1) {
+                if (L.nb > 1) printf("[window %d] ", b);
+                printf("%s %d\tavg change %g,%g\n", what, it, (double)(float)(c->h_red[2 * b] / n), (double)(float)(c->h_red[2 * b + 1] / n));
+            }
+        fflush(stdout);
+    };
 
     // occlusions: 0, or -1 with one_direction / occlusion reasoning (:216-220)
     {
@@ -296,6 +310,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 } else
                     launch_update_inner(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), L.plane(P_DU), L.plane(P_DV), L.plane(P_ODU),
                                         L.plane(P_ODV), red);                                               // :371-402
+                if (verbose) print_changes("\tinner it", inner, in_active);                                  // :404-405
                 if (use_thres_in && inner + 1 < p.niter_inner) {
                     SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                     SFA_HIP(c, hipStreamSynchronize(c->stream));
@@ -314,6 +329,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 go.active = active & ~outer_done;
                 launch_update_outer(c, go, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);                      // :412-429
             }
+            if (verbose) print_changes("outer it", outer, active);                                            // :431-432
             const bool last_iter = (alter == p.niter_alter - 1 && outer == p.niter_outer - 1);
             if (use_thres_out || last_iter) launch_outer_threshold(c, g, red, use_thres_out ? p.thres_outer : 0.0f);   // :431-436
             if (use_thres_out) {

@@ -161,6 +161,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     };
     // ---- deep_matching 1 (:744-863): the flow is initialised by EpicFlow's interpolation (epic.h) of DeepMatching matches along SED edges.  The reference starts
     //      both tools with system() (MATLAB + a binary, third-party); this build reads their outputs from the reference's own locations and says so if they are missing.
+    if (params.verbosity(VER_CMD)) setenv("SFA_VERBOSE_CHANGES", "1", 1);       // the library prints the reference's "inner it / outer it ... avg change" lines (variational_mt.cpp:404-405, 431-432)
     const bool enable_dm = params.parameter<bool>("deep_matching");
     auto edges_file = [&](int frame_number) { return params.output + "tmp/edges_" + std::to_string(frame_number) + ".dat"; };                    // :740-741
     auto matches_file = [&](int a, int b) { return params.output + "tmp/matches_" + std::to_string(a) + "_" + std::to_string(b) + ".dat"; };    // :742-743

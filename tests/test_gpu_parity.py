@@ -1476,3 +1476,26 @@ def test_poisoned_solve_returns_timeout_and_the_context_keeps_working(oracle):
         job.close()
     finally:
         c.close()
+
+
+def test_verbose_change_lines(oracle, capfd, monkeypatch):
+    """the reference prints "inner it i avg change a,b" / "outer it i avg change a,b" per iteration under verbosity(VER_CMD) (variational_mt.cpp:404-405, 431-432); the
+    library prints the same lines when SFA_VERBOSE_CHANGES is set (the C++ class and the driver set it from the cfg's `verbose`), and the last outer line carries the
+    change norms the call returns"""
+    w, h = 67, 45
+    frames, af, sf = normalized_frames(oracle, w, h, 3)
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=3, niter_inner=2)
+    monkeypatch.setenv("SFA_VERBOSE_CHANGES", "1")
+    c = sfa.Context(0)
+    try:
+        wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
+        ch, _ = c.compute_one_level(ps, wx, wy, [c_(f) for f in frames], w)
+    finally:
+        c.close()
+    out = capfd.readouterr().out.splitlines()
+    inner = [l for l in out if l.startswith("\tinner it ")]
+    outer = [l for l in out if l.startswith("outer it ")]
+    assert len(inner) == 6 and len(outer) == 3, out
+    assert inner[0].startswith("\tinner it 0\tavg change ") and outer[2].startswith("outer it 2\tavg change ")
+    a, b = (float(x) for x in outer[2].split("avg change ")[1].split(","))
+    assert abs(a - ch[0]) <= 1e-5 * abs(ch[0]) + 1e-12 and abs(b - ch[1]) <= 1e-5 * abs(ch[1]) + 1e-12
