@@ -243,8 +243,24 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         for (auto &t : up) t.join();
         release_sequences();
     };
-    auto frames_are = [&](unsigned f0, unsigned f1) {      // frames [f0, f1) are final: publish the size once, then the frames
-        { std::lock_guard<std::mutex> l(ready_mu); if (!size_known) { width = seq[f0]->width; height = seq[f0]->height; size_known = true; } for (unsigned f = f0; f < f1; f++) frame_ready[f] = 1; }
+    // frames [f0, f1) are final: publish the size once, then the frames.  Every frame is held against the published size BEFORE it is marked ready: the uploaders copy
+    // width x height of the published size out of each frame's buffer, so a smaller frame in the middle of the sequence would be read beyond its end; it is
+    // left unpublished and reported through `size_mismatch` instead (the uploaders are then released by abort_ingest)
+    string size_mismatch;
+    auto frames_are = [&](unsigned f0, unsigned f1) {
+        {
+            std::lock_guard<std::mutex> l(ready_mu);
+            if (!size_known) { width = seq[f0]->width; height = seq[f0]->height; size_known = true; }
+            for (unsigned f = f0; f < f1; f++) {
+                if (seq[f]->width != width || seq[f]->height != height) {
+                    if (size_mismatch.empty())
+                        size_mismatch = "frames of different sizes: frame " + std::to_string(f) + " of the sequence is " + std::to_string(seq[f]->width) + "x" + std::to_string(seq[f]->height) + ", the sequence " +
+                                        std::to_string(width) + "x" + std::to_string(height);
+                    continue;
+                }
+                frame_ready[f] = 1;
+            }
+        }
         ready_cv.notify_all();
     };
 
@@ -300,6 +316,8 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         pool.wait_all();
     }
     if (!load_error.empty()) { std::cerr << load_error << std::endl; abort_ingest(); return 3; }
+    { std::lock_guard<std::mutex> l(ready_mu); if (!size_mismatch.empty()) load_error = size_mismatch; }
+    if (!load_error.empty()) { std::cerr << load_error << std::endl; abort_ingest(); return 3; }
     const double decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (preprocess && scale != 1) {                                                  // blur + resize against aliasing (:550-553), on the GPU
         sfa_ctx *ingest_ctx = nullptr;
@@ -312,7 +330,12 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         }
         sfa_ctx_destroy(ingest_ctx);
     }
-    if (!upload_while_decoding) frames_are(start_f, end_f);
+    if (!upload_while_decoding) {
+        frames_are(start_f, end_f);
+        std::lock_guard<std::mutex> l(ready_mu);
+        load_error = size_mismatch;
+    }
+    if (!load_error.empty()) { std::cerr << load_error << std::endl; abort_ingest(); return 3; }
     for (unsigned f = start_f; f < end_f; f++) seq_back[frames - 1 - f] = seq[f];    // :590-591
     if (seq[start_f]->width != width || seq[start_f]->height != height) { std::cerr << "frames of different sizes" << std::endl; abort_ingest(); return 3; }
     color_image_t *channel_weights = color_image_new(width, height);                 // :597-598 (all ones without raw weighting)

@@ -391,6 +391,24 @@ def write_pgm(path, img):           # img: (h,w) float 0..255
 
 
 @pytest.mark.gpu
+def test_driver_refuses_a_frame_of_another_size(host_build, tmp_path):
+    """a smaller frame in the middle of the sequence: the uploaders copy the published size out of every frame's buffer, so the frame must be caught before it is
+    marked ready -- whichever frame finishes decoding first"""
+    from synth import texture_frame
+    w, h, jets, steps = 96, 64, 3, 1
+    nframes = 1 + (jets + 2) * steps
+    for k in range(nframes):
+        ww, hh = (80, 48) if k == 3 else (w, h)
+        write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), np.clip(np.round(texture_frame(ww, hh, k)[:, :, :ww]), 0, 255))
+    cfg = tmp_path / "run.cfg"
+    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\n"
+                   "slow_flow_S\t2\nslow_flow_layers\t1\nslow_flow_niter_alter\t1\nslow_flow_niter_outer\t1\nslow_flow_occlusion_reasoning\t0\ngpus\t1\n" % (tmp_path, tmp_path, jets))
+    for _ in range(3):                                            # the decode order varies from run to run
+        r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 3 and "different sizes" in r.stderr, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_driver_multi_gpu_path_rehearsed_on_one_card(host_build, tmp_path):
     """the driver's N-GPU path (a resident, normalised sequence per GPU; `gpu_streams` workers per GPU; windows dealt out by plan_workers) cannot run on
     this one-GPU box as written, so it is rehearsed: `gpu_oversubscribe 1` maps GPU g to device g mod devices.  Three virtual GPUs x 2 workers must
