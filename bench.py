@@ -83,16 +83,16 @@ def sor_launch_waves(kernel, nb):
 
 def limiter(kernel, batch, streams):
     """What the solver kernel waits for -- a statement measured for ONE configuration (k_sor_chain<3,5,3,0,...>, 64 windows per launch: what-if builds of
-    DESIGN.md 5.1b, profiles/r03_chain_whatif.txt) and printed only for it; any other shape or batch gets the plain label."""
+    DESIGN.md 5.1, profiles/r03_chain_whatif.txt) and printed only for it; any other shape or batch gets the plain label."""
     k = kernel.replace(" ", "")
     if "k_sor_chain<3,3,2,3" in k and batch >= 16:
         return ("wave issue rate: one 8-wave workgroup per CU (its operand ring fills the LDS), six compute waves of 3,3,3,2,2,2 sweeps two to a SIMD -- the SIMDs that "
-                "carry 5 sweeps set the pace (the 5 x 3 shape of round 3, 6 sweeps on one SIMD, was within 6 % of its compute-only build: DESIGN.md 5.1b)")
+                "carry 5 sweeps set the pace (the 5 x 3 shape of round 3, 6 sweeps on one SIMD, was within 6 % of its compute-only build: DESIGN.md 5.1)")
     if "k_sor_chain<3,5,3,0" in k and batch == 64:
         return ("wave issue rate: one 7-wave workgroup per CU (its operand ring fills the LDS), five compute waves on four SIMDs each issuing one instruction per "
-                "4-8 cycles; a build whose I/O waves only walk the barriers needs 0.94 of the launch, one without operand loads 0.97 (DESIGN.md 5.1b)")
+                "4-8 cycles; a build whose I/O waves only walk the barriers needs 0.94 of the launch, one without operand loads 0.97 (DESIGN.md 5.1)")
     if batch <= 8:
-        return "dependency latency: W + H + 2K hyperplane steps of ~14 dependent packed operations each, plus the start-up skew of the bands (DESIGN.md 5.1b)"
+        return "dependency latency: W + H + 2K hyperplane steps of ~14 dependent packed operations each, plus the start-up skew of the bands (DESIGN.md 5.1)"
     return "dependency latency / wave issue rate (not measured for this shape and batch size)"
 
 
