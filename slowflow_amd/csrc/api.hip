@@ -189,7 +189,12 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     for (int s = 0; s < ref; s++) data_norm += p.rho[s] + p.omega[s];
 
     launch_dpsis(c, g, L.plane(P_DPSIS), L.frame(ref), L.es, 5.0f, p.norm_avg, p.norm_std, p.hbit);           // :257
-    launch_copy_planes(c, g, L.plane(P_UU), L.plane(P_WX), 2, L.es, L.es);                                    // :260-261 (wx,wy and uu,vv adjacent)
+    // uu = wx + du, vv = wy + dv (:396-397), and wx <- uu, wy <- vv at the end of every outer iteration (:428-429).  With ONE inner iteration and the fused update
+    // (k_update_outer_x) the two pairs of planes always hold the same values when anybody reads them: smoothness and assembly then read wx, wy, and the update
+    // writes 16 instead of 32 bytes per pixel.
+    const bool uv_alias = L.fused && p.sor_order != 1 && !getenv("SFA_NO_DIRECT_OPERANDS") && p.niter_inner == 1 && !getenv("SFA_NO_UV_ALIAS");
+    float *const UU = uv_alias ? L.plane(P_WX) : L.plane(P_UU), *const VV = uv_alias ? L.plane(P_WY) : L.plane(P_VV);
+    if (!uv_alias) launch_copy_planes(c, g, L.plane(P_UU), L.plane(P_WX), 2, L.es, L.es);                     // :260-261 (wx,wy and uu,vv adjacent)
 
     // which terms are active (:343-361), in the reference's call order
     AssembleArgs aa;
@@ -277,7 +282,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 if (!first_zero) {
                     launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                // :329-330
                 }
-                launch_smoothness(c, gi, p.smoothing, L.plane(P_SH), L.plane(P_SV), L.plane(P_UU), L.plane(P_VV), L.plane(P_DPSIS), p.alpha,
+                launch_smoothness(c, gi, p.smoothing, L.plane(P_SH), L.plane(P_SV), UU, VV, L.plane(P_DPSIS), p.alpha,
                                   pen(p.robust_reg));                                                       // :333
                 // the fused assembly can leave the solver's operands directly (no a11 .. b2 planes, no prepare pass) when the
                 // whole batch is solved in one launch
@@ -286,7 +291,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 if (direct) SFA_TRY(sor_operand_target(c, sorws, gi, p.niter_solver, &aa.op));
                 if (L.fused)
                     launch_assemble_images(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
-                                           L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV), L.plane(P_OCC));   // :293-365
+                                           L.plane(P_DV), UU, VV, L.plane(P_SH), L.plane(P_SV), L.plane(P_OCC));   // :293-365
                 else
                     launch_assemble(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
                                     L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV));   // :336-365
@@ -301,7 +306,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 }
                 if (direct && inner + 1 == p.niter_inner) {
                     // last inner iteration: nothing reads its inner norms or du/dv; the flow update and the outer update run as one pass
-                    launch_update_outer_x(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, red);   // :396-397 + :412-429
+                    launch_update_outer_x(c, gi, uv_alias ? nullptr : L.plane(P_UU), uv_alias ? nullptr : L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, red);   // :396-397 + :412-429
                     outer_done = in_active;
                 } else if (direct) {
                     const bool keep = inner + 1 < p.niter_inner;      // du, dv are read again only by a further inner iteration

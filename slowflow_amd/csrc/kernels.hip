@@ -1521,7 +1521,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ u
                     const float u = ox + d, v = oy + e;                                   // :396-397
                     sa += (double)fabsf(u - ox);                                         // :415-419
                     sb += (double)fabsf(v - oy);
-                    uu[o] = u; vv[o] = v;
+                    if (uu) { uu[o] = u; vv[o] = v; }                                     // (null: the caller reads wx, wy in their place -- one inner iteration)
                     wx[o] = u; wy[o] = v;                                                 // :428-429
                 }
         }
