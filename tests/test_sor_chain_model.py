@@ -20,7 +20,8 @@ def _sim(mode, slack):
     return m
 
 
-CASES = [(40, 70, 12, (2, 3, 2, 0), 1), (50, 130, 9, (1, 3, 1, 0), 2), (45, 100, 14, (4, 1, 3, 1), 1), (33, 150, 12, (3, 2, 3, 0), 1), (37, 200, 10, (2, 5, 2, 0), 1)]
+CASES = [(40, 70, 12, (2, 3, 2, 0), 1), (50, 130, 9, (1, 3, 1, 0), 2), (45, 100, 14, (4, 1, 3, 1), 1), (33, 150, 12, (3, 2, 3, 0), 1), (37, 200, 10, (2, 5, 2, 0), 1),
+         (41, 140, 30, (3, 3, 2, 3), 1), (36, 90, 15, (2, 3, 3, 3), 2)]          # round 4: the six-stage shapes of mixed width (3,3,3,2,2,2 is the default from 97 bands on)
 
 
 @pytest.mark.parametrize("mode", ["raw", "war"])
