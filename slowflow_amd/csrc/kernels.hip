@@ -1393,7 +1393,8 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
     }
     const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + 8 - 1) / 8, g.nb);
     // the XCD-contiguous tile order (see the kernel) from 8 workgroups per XCD on; SFA_ASM_XCD=0: the plain grid, for A/B measurements
-    static const bool xcd_env = !getenv("SFA_ASM_XCD") || atoi(getenv("SFA_ASM_XCD")) != 0;
+    const char *xcd_e = getenv("SFA_ASM_XCD");
+    const bool xcd_env = !xcd_e || atoi(xcd_e) != 0;
     const long ntiles = (long)grid_.x * grid_.y * grid_.z;
     const bool xcd = xcd_env && ntiles >= 64 && ntiles < (1l << 30);
     const XcdTiles xt{(int)grid_.x, (int)grid_.y, (int)((ntiles + 7) / 8)};

@@ -1499,3 +1499,30 @@ def test_verbose_change_lines(oracle, capfd, monkeypatch):
     assert inner[0].startswith("\tinner it 0\tavg change ") and outer[2].startswith("outer it 2\tavg change ")
     a, b = (float(x) for x in outer[2].split("avg change ")[1].split(","))
     assert abs(a - ch[0]) <= 1e-5 * abs(ch[0]) + 1e-12 and abs(b - ch[1]) <= 1e-5 * abs(ch[1]) + 1e-12
+
+
+@pytest.mark.parametrize("pen", [1, 2])
+def test_assembly_instances_and_tile_orders_give_the_same_bits(ctx, oracle, monkeypatch, pen):
+    """The fused assembly kernel's variants -- the folded instances (modified L1 / Lorentzian) against the run-time instance (SFA_ASSEMBLE_GENERIC), the
+    shared-reciprocal divisions against __fdiv_rn only (SFA_EXACT_DIV), the XCD-contiguous tile order against the plain grid (SFA_ASM_XCD=0) -- on a batch whose
+    launch is large enough for the XCD order (9 windows of 300x200: 675 tiles), S = 3 with to-reference terms, sizes off the tile grid: one set of bits."""
+    w, h, nb = 300, 200, 9
+    frames, af, sf = normalized_frames(oracle, w, h, 5, seed=21)
+    kw = dict(robust_color=(pen, 0.05 if pen == 2 else 0.001, 0.5), robust_grad=(pen, 0.05 if pen == 2 else 0.001, 0.5))
+    _, ps = mk_params(oracle, S=3, rho=[1, 0.5], omega=[0.5, 2], norm_avg=af, norm_std=sf, niter_outer=2, layers=2, **kw)
+    outs = {}
+    for name, env in (("default", {}), ("generic", {"SFA_ASSEMBLE_GENERIC": "1"}), ("exact_div", {"SFA_EXACT_DIV": "1"}), ("plain_grid", {"SFA_ASM_XCD": "0"})):
+        for k in ("SFA_ASSEMBLE_GENERIC", "SFA_EXACT_DIV", "SFA_ASM_XCD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        job = sfa.Job(ctx, ps, w, h, nb)
+        for b in range(nb):
+            job.upload(b, [c_(np.roll(f, 3 * b, axis=2)) for f in frames])
+        job.run()
+        outs[name] = [job.download(b)[:2] for b in (0, 4, 8)]
+        job.close()
+    for name in ("generic", "exact_div", "plain_grid"):
+        for (ax, ay), (bx, by) in zip(outs["default"], outs[name]):
+            assert np.array_equal(ax, bx) and np.array_equal(ay, by), name
+    assert not np.array_equal(outs["default"][0][0], outs["default"][1][0])                 # the windows do differ
