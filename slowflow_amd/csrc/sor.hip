@@ -969,9 +969,10 @@ static int chain_choice(int K, int nb, int NBands) {
         const int bands = nb * NBands;
         // Round 4: shape 11 (six stages of 3,3,3,2,2,2 sweeps: with the two I/O waves eight waves, two per SIMD, at most 5 sweeps on a SIMD where 5 x 3 puts 6)
         //   16 windows 582 -> 523, 32: 859 -> 770, 64: 1515 -> 1408 (shape 12 = 2,2,2,3,3,3: 553 / 813 / 1470).
-        static const int few[] = {6, 1, 2, 5, 3, 0}, many[] = {11, 3, 5, 2, 6, 1, 0};
+        //   shape 16 = shape 6 with one-interval poll / publication lags (sor_chain.hip kChainShapes): faster up to four windows, slower from eight on
+        static const int lone[] = {16, 6, 1, 2, 5, 3, 0}, few[] = {6, 1, 2, 5, 3, 0}, many[] = {11, 3, 5, 2, 6, 1, 0};
         int KG, NW, FMAX;
-        for (const int *cand = bands <= 96 ? few : many; *cand; cand++)
+        for (const int *cand = bands <= 32 ? lone : bands <= 96 ? few : many; *cand; cand++)
             if (chain_shape(*cand, K, &KG, &NW, &FMAX)) { id = *cand; break; }
     }
     int KG, NW, FMAX;

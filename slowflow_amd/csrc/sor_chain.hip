@@ -833,18 +833,23 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
 #endif
 constexpr int kChainCH = 4, kChainAH = SFA_CHAIN_AH, kChainPL = SFA_CHAIN_PL, kChainPUBD = SFA_CHAIN_PUBD;
 
-struct ChainShapeInfo { int id, FA, NA, FB, NB_, PD; };
+// PL: intervals between a poll of the producers' progress words and the look at its result; PUBD: intervals between a store and the progress word that covers it.
+// Both are correct at any value >= 1 (a poll that has not returned is waited for; the publication sits behind a counted vmcnt wait over PUBD * T instructions) and
+// trade latency against stalls: 2 / 2 everywhere until round 4; 1 / 1 for the lone-solve shape (one window 276 -> 265 us) and the six-stage shape (64 windows 1398 -> 1379 us,
+// 16: 529 -> 514), NOT for 1 x 5 at 8-12 windows (+2 .. +12 %): id 16 is 1 x 5 with 1 / 1 and serves launches of up to 32 bands.
+struct ChainShapeInfo { int id, FA, NA, FB, NB_, PD, PL, PUBD; };
 static const ChainShapeInfo kChainShapes[] = {
-    {1, 1, 3, 1, 0, 4},      // 3 stages of 1 sweep            KG = 3
-    {2, 2, 3, 2, 0, 2},      // 3 stages of 2                  KG = 6
-    {3, 3, 5, 3, 0, 2},      // 5 stages of 3                  KG = 15
-    {5, 2, 5, 2, 0, 2},      // 5 stages of 2                  KG = 10
-    {6, 1, 5, 1, 0, 4},      // 5 stages of 1                  KG = 5
-    {8, 3, 2, 3, 0, 2},      // 2 stages of 3                  KG = 6
-    {9, 5, 6, 5, 0, 2},      // 6 stages of 5                  KG = 30: a whole band per workgroup (large batches)
-    {10, 3, 10, 3, 0, 2},    // 10 stages of 3                 KG = 30
-    {11, 3, 3, 2, 3, 2},     // 3 stages of 3 + 3 of 2         KG = 15: with the I/O waves 8 waves, two per SIMD, at most 5 sweeps on a SIMD (5 x 3: 6)
-    {12, 2, 3, 3, 3, 2},     // 3 stages of 2 + 3 of 3         KG = 15
+    {1, 1, 3, 1, 0, 4, 2, 2},      // 3 stages of 1 sweep            KG = 3
+    {2, 2, 3, 2, 0, 2, 2, 2},      // 3 stages of 2                  KG = 6
+    {3, 3, 5, 3, 0, 2, 2, 2},      // 5 stages of 3                  KG = 15
+    {5, 2, 5, 2, 0, 2, 2, 2},      // 5 stages of 2                  KG = 10
+    {6, 1, 5, 1, 0, 4, 2, 2},      // 5 stages of 1                  KG = 5
+    {8, 3, 2, 3, 0, 2, 2, 2},      // 2 stages of 3                  KG = 6
+    {9, 5, 6, 5, 0, 2, 2, 2},      // 6 stages of 5                  KG = 30: a whole band per workgroup (large batches)
+    {10, 3, 10, 3, 0, 2, 2, 2},    // 10 stages of 3                 KG = 30
+    {11, 3, 3, 2, 3, 2, 1, 1},     // 3 stages of 3 + 3 of 2         KG = 15: with the I/O waves 8 waves, two per SIMD, at most 5 sweeps on a SIMD (5 x 3: 6)
+    {12, 2, 3, 3, 3, 2, 2, 2},     // 3 stages of 2 + 3 of 3         KG = 15
+    {16, 1, 5, 1, 0, 4, 1, 1},     // 5 stages of 1, one-interval poll / publication lags: the lone solve
 };
 
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
@@ -864,9 +869,9 @@ void chain_kernel_name(int id, int NG, char *buf, size_t n) {
         if (s.id == id) {
             if (s.NB_ && s.FB != s.FA)
                 snprintf(buf, n, "k_sor_chain<%d,%d,%d,%d,%d,%d,%d,%d,%d> (%d stages of %d + %d of %d sweeps, %d groups per band)", s.FA, s.NA, s.FB, s.NB_, kChainCH, s.PD, kChainAH,
-                         kChainPL, kChainPUBD, s.NA, s.FA, s.NB_, s.FB, NG);
+                         s.PL, s.PUBD, s.NA, s.FA, s.NB_, s.FB, NG);
             else
-                snprintf(buf, n, "k_sor_chain<%d,%d,%d,%d,%d,%d,%d,%d,%d> (%d stages of %d sweeps, %d groups per band)", s.FA, s.NA, s.FB, s.NB_, kChainCH, s.PD, kChainAH, kChainPL, kChainPUBD,
+                snprintf(buf, n, "k_sor_chain<%d,%d,%d,%d,%d,%d,%d,%d,%d> (%d stages of %d sweeps, %d groups per band)", s.FA, s.NA, s.FB, s.NB_, kChainCH, s.PD, kChainAH, s.PL, s.PUBD,
                          s.NA + s.NB_, s.FA, NG);
             return;
         }
@@ -885,6 +890,7 @@ int chain_shift(int id) {
         case 9: return shape_shift<5, 6, 5, 0>();
         case 10: return shape_shift<3, 10, 3, 0>();
         case 11: return shape_shift<3, 3, 2, 3>();
+        case 16: return shape_shift<1, 5, 1, 0>();
         case 12: return shape_shift<2, 3, 3, 3>();
     }
     return 0;
@@ -892,7 +898,7 @@ int chain_shift(int id) {
 int chain_flag_stride() { return kFlagStride; }
 int chain_ah() { return kChainAH; }
 
-template <int FA, int NA, int FB, int NB_, int PD>
+template <int FA, int NA, int FB, int NB_, int PD, int PL = kChainPL, int PUBD = kChainPUBD>
 static int chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
     using S = ChainShape<FA, NA, FB, NB_>;
     using L = ChainLds<S, kChainCH>;
@@ -904,14 +910,14 @@ static int chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
     const bool tracked = c->device >= 0 && c->device < 64;
     const unsigned long long bit = tracked ? 1ull << c->device : 0ull;
     if (lds > 64 * 1024 && !(attr_set.load(std::memory_order_relaxed) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, PL, PUBD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return set_error(c, SFA_ERR_HIP, "k_sor_chain<%d,%d,%d,%d>: %zu bytes of LDS per workgroup refused on device %d: %s", FA, NA, FB, NB_, lds, c->device,
                              hipGetErrorString(e));
         attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, kChainPL, kChainPUBD>), dim3(nwg), dim3((S::NW + 2) * 64), lds, c->stream, a);
+    hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, PL, PUBD>), dim3(nwg), dim3((S::NW + 2) * 64), lds, c->stream, a);
     return SFA_OK;
 }
 
@@ -933,7 +939,8 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
         case 8: return chain_launch_shape<3, 2, 3, 0, 2>(c, a, nwg);
         case 9: return chain_launch_shape<5, 6, 5, 0, 2>(c, a, nwg);
         case 10: return chain_launch_shape<3, 10, 3, 0, 2>(c, a, nwg);
-        case 11: return chain_launch_shape<3, 3, 2, 3, 2>(c, a, nwg);
+        case 11: return chain_launch_shape<3, 3, 2, 3, 2, 1, 1>(c, a, nwg);
+        case 16: return chain_launch_shape<1, 5, 1, 0, 4, 1, 1>(c, a, nwg);
         case 12: return chain_launch_shape<2, 3, 3, 3, 2>(c, a, nwg);
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }

@@ -284,7 +284,9 @@ SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH":
                 "chain_1x3": {"SFA_SOR_CHAIN": "1"}, "chain_2x3": {"SFA_SOR_CHAIN": "2"}, "chain_3x5": {"SFA_SOR_CHAIN": "3"}, "chain_2x5": {"SFA_SOR_CHAIN": "5"},
                 "chain_1x5": {"SFA_SOR_CHAIN": "6"}, "chain_3x2": {"SFA_SOR_CHAIN": "8"}, "chain_5x6": {"SFA_SOR_CHAIN": "9"}, "chain_3x10": {"SFA_SOR_CHAIN": "10"},
                 # six stages of mixed width (15 sweeps per group: K = 15, 30; other K fall back): the operand ring at its minimum depth
-                "chain_3x3_2x3": {"SFA_SOR_CHAIN": "11"}, "chain_2x3_3x3": {"SFA_SOR_CHAIN": "12"}}
+                "chain_3x3_2x3": {"SFA_SOR_CHAIN": "11"}, "chain_2x3_3x3": {"SFA_SOR_CHAIN": "12"},
+                # 1 x 5 with one-interval poll / publication lags (the lone-solve default; 11 runs with them too)
+                "chain_1x5_lags1": {"SFA_SOR_CHAIN": "16"}}
 
 
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))

@@ -11,12 +11,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _sim(mode, slack):
-    os.environ["SIM_MODE"], os.environ["SIM_SLACK"] = mode, str(slack)
-    spec = importlib.util.spec_from_file_location(f"sim_sor_chain_{mode}_{slack}", os.path.join(ROOT, "tools", "sim_sor_chain.py"))
+def _sim(mode, slack, pubd=2):
+    os.environ["SIM_MODE"], os.environ["SIM_SLACK"], os.environ["SIM_PUBD"] = mode, str(slack), str(pubd)
+    spec = importlib.util.spec_from_file_location(f"sim_sor_chain_{mode}_{slack}_{pubd}", os.path.join(ROOT, "tools", "sim_sor_chain.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    os.environ.pop("SIM_MODE"); os.environ.pop("SIM_SLACK")
+    os.environ.pop("SIM_MODE"); os.environ.pop("SIM_SLACK"); os.environ.pop("SIM_PUBD")
     return m
 
 
@@ -34,5 +34,22 @@ def test_chain_protocol_model_reproduces_the_oracle(mode, w, h, K, shape, nb):
 
 def test_chain_protocol_thresholds_are_tight():
     m = _sim("raw", 1)
+    bad, _ = m.run(40, 70, 12, m.Shape(2, 3, 2, 0), 1)
+    assert bad > 0
+
+
+@pytest.mark.parametrize("mode", ["raw", "war"])
+@pytest.mark.parametrize("w,h,K,shape,nb", [(41, 140, 30, (3, 3, 2, 3), 1), (50, 130, 10, (1, 5, 1, 0), 2), (40, 70, 12, (2, 3, 2, 0), 1)])
+def test_chain_protocol_model_with_one_interval_of_publication_delay(mode, w, h, K, shape, nb):
+    """round 4: the default shapes for one to four windows (1 x 5) and from 13 windows on (3,3,3,2,2,2) are launched with PUBD = 1 -- the progress word covers
+    the stores of the previous interval (a counted vmcnt wait over T instead of 2 T memory instructions); the consumers' thresholds are in published counts and do
+    not change"""
+    m = _sim(mode, 0, pubd=1)
+    bad, _ = m.run(w, h, K, m.Shape(*shape), nb)
+    assert bad == 0
+
+
+def test_chain_protocol_thresholds_are_tight_with_one_interval_too():
+    m = _sim("raw", 1, pubd=1)
     bad, _ = m.run(40, 70, 12, m.Shape(2, 3, 2, 0), 1)
     assert bad > 0

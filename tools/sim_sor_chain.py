@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 f32 = np.float32
-CH, AH, PUBD = 4, 2, 2
+CH, AH = 4, 2
+PUBD = int(os.environ.get("SIM_PUBD", "2"))     # intervals between a store and the progress word that covers it: 2, or 1 for the shapes launched with <..., PL = 1, PUBD = 1>
 LEAD = AH + 1
 OOB = None
 # visibility model: "raw" = stores land as late, loads sample as early as the protocol allows (read-after-write hazards);

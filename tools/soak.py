@@ -16,7 +16,7 @@ for k in range(3): p.norm_avg[k]=float("%g"%avg[k]); p.norm_std[k]=float("%g"%st
 jobs=[sfa.Job(c,p,bench.W,bench.H,B) for c in ctxs]
 for g,job in enumerate(jobs):
     for b in range(B): job.upload(b,wins[(b+g)%4])
-probe=[0,1,B//2,B-1]
+probe=sorted(set(min(b,B-1) for b in (0,1,B//2,B-1)))
 ref=[None,None]; bad=[0,0]; err=[None,None]
 def work(g):
     try:
