@@ -972,7 +972,7 @@ static int chain_choice(int K, int nb, int NBands) {
         //   shape 16 = shape 6 with one-interval poll / publication lags (sor_chain.hip kChainShapes): faster up to four windows, slower from eight on
         static const int lone[] = {16, 6, 1, 2, 5, 3, 0}, few[] = {6, 1, 2, 5, 3, 0}, many[] = {11, 3, 5, 2, 6, 1, 0};
         int KG, NW, FMAX;
-        for (const int *cand = bands <= 32 ? lone : bands <= 96 ? few : many; *cand; cand++)
+        for (const int *cand = bands <= 32 ? lone : bands <= 84 ? few : many; *cand; cand++)          // 80 bands: 1 x 5 424 / 294 us (1024x436 / 670x284), six stages 488 / 327; 88-100: 512 / 371 against 492 / 333
             if (chain_shape(*cand, K, &KG, &NW, &FMAX)) { id = *cand; break; }
     }
     int KG, NW, FMAX;

@@ -225,11 +225,12 @@ def test_sor_golden(ctx, w, h):
         assert np.array_equal(s["dv"][:, :w], G[f"sor_{w}x{h}_K{K}_dv"][:, :w])
 
 
-@pytest.mark.parametrize("nb,shape", [(1, "k_sor_chain<1,5,1,0"), (8, "k_sor_chain<1,5,1,0"), (16, "k_sor_chain<3,3,2,3"), (64, "k_sor_chain<3,3,2,3")])
+@pytest.mark.parametrize("nb,shape", [(1, "k_sor_chain<1,5,1,0,4,4,2,1,1"), (4, "k_sor_chain<1,5,1,0,4,4,2,1,1"), (8, "k_sor_chain<1,5,1,0,4,4,2,2,2"), (11, "k_sor_chain<3,3,2,3,4,2,2,1,1"),
+                                      (16, "k_sor_chain<3,3,2,3"), (64, "k_sor_chain<3,3,2,3")])
 def test_default_solver_shape_and_its_bits(ctx, oracle, nb, shape):
-    """what the library launches by default at 1024x436 x 30 for 1 / 8 / 16 / 64 systems per launch (round 3: the chain kernel with the operand ring at every
-    batch size -- five stages of one sweep up to 96 bands per launch, five stages of three above), and that the first and the last system of the launch are
-    the raster-order oracle's bits"""
+    """what the library launches by default at 1024x436 x 30 (8 bands per system) for 1 ... 64 systems per launch -- the chain kernel with the operand ring at every
+    batch size: five stages of one sweep up to 84 bands per launch (with one-interval poll / publication lags up to 32 bands), six stages of 3,3,3,2,2,2 sweeps
+    above (round 4) -- and that the first and the last system of the launch are the raster-order oracle's bits"""
     w, h, K = 1024, 436, 30
     rng = np.random.default_rng(100 + nb)
     systems = [sor_system(rng, w, h) for _ in range(2)]
