@@ -996,18 +996,21 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                                                               const float *__restrict__ occ, Geo g, XcdTiles xt) {
     constexpr int TR = TY + 2 * DT_H, AT_R1 = TY + 4, NR = NT / 64, NP = TY / NR;
     // one LDS block: staged planes during the terms, the operand tile of the solver afterwards
-    constexpr int NM = TR * DT_W, N1 = AT_R1 * AT_W1;
+    // Ix, Iy planes (halo 2 in y) share M's COLUMN geometry since round 4 (index j = column x0 + j, 72 wide): stage 1 then works on M's own aligned quads and reads
+    // its column taps as aligned 16-byte rows (they were 2 x 8 bytes at half the LDS rate on planes shifted by two columns)
+    constexpr int AW1 = DT_W;
+    constexpr int NM = TR * DT_W, N1 = AT_R1 * AW1;
     // terms are staged two at a time (one exposed global-load latency and one barrier less per pair)
     __shared__ __attribute__((aligned(16))) float lds[12 * NM + 6 * N1];
     float(*sM2)[NM] = reinterpret_cast<float(*)[NM]>(lds);                      // [2 terms][3 ch] M  = (I1+I2)/2, halo 4 (rows x DT_W)
     float(*sZ2)[NM] = reinterpret_cast<float(*)[NM]>(lds + 6 * NM);             // [2 terms][3 ch] Iz = I1-I2, same geometry (aligned 16-byte rows)
-    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM);             // Ix, Iy of the term in work: halo 2 (rows x AT_W1)
+    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM);             // Ix, Iy of the term in work: halo 2 (rows x AW1)
     float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM + 3 * N1);
     // the smoothness-side operands of the epilogue (uu, vv, sh, sv with a halo of one) take the place of the M planes once the last term's Ix, Iy exist
     constexpr int GR = TY + 2, NGQ = 4 * GR * (DT_W / 4), NGF = 4 * GR * DT_W;
     static_assert(NGF <= 6 * NM, "the epilogue's operand planes replace the M planes");
     static_assert(NGF + TY * (67 * 8 + 69 * 2) <= 12 * NM + 6 * N1, "operand tile must fit the staging block");
-    static_assert(DT_W % 4 == 0 && AT_W1 % 4 == 0 && NM % 4 == 0 && N1 % 4 == 0, "16-byte LDS rows");
+    static_assert(DT_W % 4 == 0 && AW1 % 4 == 0 && NM % 4 == 0 && N1 % 4 == 0, "16-byte LDS rows");
 #ifdef SFA_ASM_TIMING
     unsigned long long at_acc[14] = {0}, at_t = __builtin_readcyclecounter();
 #endif
@@ -1065,7 +1068,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         }
         if (!(SFA_X_AI & 128)) oc[k] = occ[eb + o];                                   // k_mask_weight
     }
-    constexpr int QM = DT_W / 4, Q1 = AT_W1 / 4;                     // float4 quads per staged row
+    constexpr int QM = DT_W / 4, Q1 = AW1 / 4;                       // float4 quads per staged row
     // global -> LDS by DMA like the image quads: rows y-1 .. y+TY of the four planes, the 18 aligned quads that cover columns x0 .. x0+71.  Quads outside
     // the planes are skipped; the border rules of the gather never read them.
     const bool need_g = a.do_laplacian || a.op.sa;
@@ -1170,7 +1173,8 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             auto convert = [&](const float4 &va, const float4 &vb, int lds_off) {
                 *reinterpret_cast<float4 *>(lds + lds_off + 4 * item) =
                     make_float4(0.5f * (vb.x + va.x), 0.5f * (vb.y + va.y), 0.5f * (vb.z + va.z), 0.5f * (vb.w + va.w));        // variational_mt.cpp:120
-                *reinterpret_cast<float4 *>(lds + 6 * NM + lds_off + 4 * item) = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);   // :122
+                if (ly >= 2 && ly < TR - 2)                         // Iz is read two rows around the tile only (M four: Ix, Iy exist on the halo-2 rows)
+                    *reinterpret_cast<float4 *>(lds + 6 * NM + lds_off + 4 * item) = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);   // :122
             };
             const float4 a0 = fetch(T0.i1_off, 0), b0 = fetch(T0.i2_off, 6 * NM);
             if (npair == 2) {
@@ -1186,39 +1190,41 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         __syncthreads();                                           // staged planes complete / the previous term is done with Ix, Iy
         AT_MARK(6);
         SFA_PRIO(SFA_PRIO_STAGE);
-        // stage 1: Ix, Iy on the halo-2 region, four columns per item (two aligned quads of M per tap row)
+        // stage 1: Ix, Iy on the halo-2 rows, one aligned quad of M's columns per item.  The row taps of the quad's four columns are the 8 values around it (the two
+        // outermost quads of a row reach into the neighbouring rows' ends: their outer two columns are never read by anybody), the column taps four aligned quads
         for (int item = threadIdx.x; item < ((SFA_X_AI & 4) ? 0 : AT_R1 * 3 * Q1); item += NT) {
             const int q = item % Q1, ch = (item / Q1) % 3, ly = item / (3 * Q1);
-            const int gy = y0 + 2 + ly, gx = x0 + 2 + 4 * q;
+            const int gy = y0 + 2 + ly, gx = x0 + 4 * q;
             if (gy < 0 || gy >= g.h) continue;
             const float *M = sM[ch];
-            const int c = (ly + 2) * DT_W + 4 * q;                 // M index of column gx - 2
-            float m[5][8];                                          // rows gy-2 .. gy+2, columns gx-2 .. gx+5
+            const int c = (ly + 2) * DT_W + 4 * q;                 // M index of column gx
             const bool y_in = gy >= 2 && gy + 2 < g.h;
-#pragma unroll
-            for (int r = 0; r < 5; r++) {
-                if (r != 2 && !y_in) continue;
-                const float4 lo = *reinterpret_cast<const float4 *>(M + c + (r - 2) * DT_W), hi = *reinterpret_cast<const float4 *>(M + c + (r - 2) * DT_W + 4);
-                m[r][0] = lo.x; m[r][1] = lo.y; m[r][2] = lo.z; m[r][3] = lo.w; m[r][4] = hi.x; m[r][5] = hi.y; m[r][6] = hi.z; m[r][7] = hi.w;
+            float m2[8];                                            // row gy, columns gx-2 .. gx+5
+            {
+                const float2 lo = *reinterpret_cast<const float2 *>(M + c - 2), hi = *reinterpret_cast<const float2 *>(M + c + 4);
+                const float4 mid = *reinterpret_cast<const float4 *>(M + c);
+                m2[0] = lo.x; m2[1] = lo.y; m2[2] = mid.x; m2[3] = mid.y; m2[4] = mid.z; m2[5] = mid.w; m2[6] = hi.x; m2[7] = hi.y;
             }
             float X[4], Y[4];
             if (gx >= 0 && gx + 3 < g.w) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) X[e] = tap5(m[2][e], m[2][e + 1], m[2][e + 2], m[2][e + 3], m[2][e + 4]);            // :127
+                for (int e = 0; e < 4; e++) X[e] = tap5(m2[e], m2[e + 1], m2[e + 2], m2[e + 3], m2[e + 4]);                      // :127
             } else {                                                // X(clamp(x), y) for the columns outside the image
 #pragma unroll
-                for (int e = 0; e < 4; e++) X[e] = d5x_in<DT_W>(M, c + 2 + e + (clampi(gx + e, 0, g.w - 1) - (gx + e)));
+                for (int e = 0; e < 4; e++) X[e] = d5x_in<DT_W>(M, c + e + (clampi(gx + e, 0, g.w - 1) - (gx + e)));
             }
-            if (y_in) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) Y[e] = tap5(m[0][e + 2], m[1][e + 2], m[2][e + 2], m[3][e + 2], m[4][e + 2]);        // :128
+            if (y_in) {                                             // tap5's own order of operations, one aligned row of the quad's columns at a time  (:128)
+                const float4 r0 = *reinterpret_cast<const float4 *>(M + c - 2 * DT_W), r1 = *reinterpret_cast<const float4 *>(M + c - DT_W);
+                const float4 r3 = *reinterpret_cast<const float4 *>(M + c + DT_W), r4 = *reinterpret_cast<const float4 *>(M + c + 2 * DT_W);
+                Y[0] = tap5(r0.x, r1.x, m2[2], r3.x, r4.x); Y[1] = tap5(r0.y, r1.y, m2[3], r3.y, r4.y);
+                Y[2] = tap5(r0.z, r1.z, m2[4], r3.z, r4.z); Y[3] = tap5(r0.w, r1.w, m2[5], r3.w, r4.w);
             } else {
                 const TileAcc m4{M, x0, y0};
 #pragma unroll
                 for (int e = 0; e < 4; e++) Y[e] = d5y(m4, clampi(gx + e, 0, g.w - 1), gy, g.h);
             }
-            *reinterpret_cast<float4 *>(&sX[ch][ly * AT_W1 + 4 * q]) = make_float4(X[0], X[1], X[2], X[3]);
-            *reinterpret_cast<float4 *>(&sY[ch][ly * AT_W1 + 4 * q]) = make_float4(Y[0], Y[1], Y[2], Y[3]);
+            *reinterpret_cast<float4 *>(&sX[ch][ly * AW1 + 4 * q]) = make_float4(X[0], X[1], X[2], X[3]);
+            *reinterpret_cast<float4 *>(&sY[ch][ly * AW1 + 4 * q]) = make_float4(Y[0], Y[1], Y[2], Y[3]);
         }
         AT_MARK(7);
         __syncthreads();
@@ -1231,7 +1237,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             const int y = y0 + DT_H + ty + NR * k;
             if (y >= g.h) break;
             const bool y_in = y >= 2 && y + 2 < g.h;
-            const int c = (ty + NR * k + 2) * AT_W1 + (tx + 2);   // halo-2 planes (Ix, Iy)
+            const int c = (ty + NR * k + 2) * AW1 + (tx + 4);     // halo-2 rows (Ix, Iy), M's columns
             const int cz = (ty + NR * k + 4) * DT_W + (tx + 4);   // halo-4 plane (Iz)
             Px p;
 #pragma unroll
@@ -1252,9 +1258,9 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                     const float *X = sX[ch] + c, *Y = sY[ch] + c, *Z = sZ[ch] + cz;
 #pragma unroll
                     for (int j = 0; j < 5; j++) xr[ch][j] = X[j - 2];
-                    xc[ch][0] = X[-2 * AT_W1]; xc[ch][1] = X[-AT_W1]; xc[ch][2] = X[AT_W1]; xc[ch][3] = X[2 * AT_W1];
+                    xc[ch][0] = X[-2 * AW1]; xc[ch][1] = X[-AW1]; xc[ch][2] = X[AW1]; xc[ch][3] = X[2 * AW1];
 #pragma unroll
-                    for (int j = 0; j < 5; j++) yc[ch][j] = Y[(j - 2) * AT_W1];
+                    for (int j = 0; j < 5; j++) yc[ch][j] = Y[(j - 2) * AW1];
 #pragma unroll
                     for (int j = 0; j < 5; j++) zr[ch][j] = Z[j - 2];
                     zc[ch][0] = Z[-2 * DT_W]; zc[ch][1] = Z[-DT_W]; zc[ch][2] = Z[DT_W]; zc[ch][3] = Z[2 * DT_W];
@@ -1278,13 +1284,13 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 const int xc_ = x < g.w ? x : g.w - 1;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const Tile2Acc X{sX[ch], x0 + 2, y0 + 2}, Y{sY[ch], x0 + 2, y0 + 2};
+                    const Tile1Acc X{sX[ch], x0, y0 + 2}, Y{sY[ch], x0, y0 + 2};               // (DT_W wide, like M)
                     const TileAcc Z{sZ[ch], x0, y0};
                     p.ixy[ch] = d5y(X, xc_, y, g.h);
                     p.iyy[ch] = d5y(Y, xc_, y, g.h);
                     p.iyz[ch] = d5y(Z, xc_, y, g.h);
                     p.ix[ch] = sX[ch][c]; p.iy[ch] = sY[ch][c]; p.iz[ch] = sZ[ch][cz];
-                    p.ixx[ch] = d5x_in<AT_W1>(sX[ch], c);                              // :129
+                    p.ixx[ch] = d5x_in<AW1>(sX[ch], c);                                // :129
                     p.ixz[ch] = d5x_in<DT_W>(sZ[ch], cz);                              // :132
                 }
             }
