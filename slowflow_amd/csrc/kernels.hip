@@ -1237,8 +1237,18 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             const int y = y0 + DT_H + ty + NR * k;
             if (y >= g.h) break;
             const bool y_in = y >= 2 && y + 2 < g.h;
-            const int c = (ty + NR * k + 2) * AW1 + (tx + 4);     // halo-2 rows (Ix, Iy), M's columns
-            const int cz = (ty + NR * k + 4) * DT_W + (tx + 4);   // halo-4 plane (Iz)
+            // The lane's column is made opaque once per term: every tap address below is then computed inside the term loop from ONE register (the planes
+            // above 64 KB -- Iy, part of Ix -- are out of reach of a 16-bit LDS offset from the block's start, and left to itself the compiler kept ~45 registers
+            // of per-plane, per-clamped-row addresses of both the interior and the border path live across the whole term loop: tools/isa_live.py), and the
+            // interior path's reads are offsets from a base in the middle of the block (cb: the Iz planes' start + the pixel), all below 48 KB
+            int txl = tx;
+            asm volatile("" : "+v"(txl));
+            const int c = (ty + NR * k + 2) * AW1 + (txl + 4);    // halo-2 rows (Ix, Iy), M's columns
+            const int cz = (ty + NR * k + 4) * DT_W + (txl + 4);  // halo-4 plane (Iz)
+            static_assert(AW1 == DT_W, "cz = c + 2 rows");
+            int cb = 6 * NM + c;
+            asm volatile("" : "+v"(cb));
+            const float *const pX = lds + cb + 6 * NM, *const pY = pX + 3 * N1, *const pZ = lds + cb + 3 * ub * NM + 2 * DT_W;   // sX[0] + c, sY[0] + c, sZ[0] + cz
             Px p;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) p.wk[ch] = FAST ? 1.0f : wk[k][ch];
@@ -1255,7 +1265,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 // Two channels' taps in flight at most (all three at once: 69 registers of taps, spills at this kernel's 128).
                 float xr[3][5], xc[3][4], yc[3][5], zr[3][5], zc[3][4];
                 auto read_taps = [&](int ch) {
-                    const float *X = sX[ch] + c, *Y = sY[ch] + c, *Z = sZ[ch] + cz;
+                    const float *X = pX + ch * N1, *Y = pY + ch * N1, *Z = pZ + ch * NM;
 #pragma unroll
                     for (int j = 0; j < 5; j++) xr[ch][j] = X[j - 2];
                     xc[ch][0] = X[-2 * AW1]; xc[ch][1] = X[-AW1]; xc[ch][2] = X[AW1]; xc[ch][3] = X[2 * AW1];
@@ -1281,7 +1291,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 __builtin_amdgcn_sched_barrier(0);
                 filters(1); filters(2);
             } else {
-                const int xc_ = x < g.w ? x : g.w - 1;
+                const int xl = x0 + DT_H + txl, xc_ = xl < g.w ? xl : g.w - 1;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     const Tile1Acc X{sX[ch], x0, y0 + 2}, Y{sY[ch], x0, y0 + 2};               // (DT_W wide, like M)
