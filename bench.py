@@ -767,7 +767,7 @@ def main():
             ipt, ipt_src, valu_active = assemble_valu_per_pixel_term()
             peak_issue = 256 * 4 * CLOCK_GHZ * 1e9 / 2.0         # a SIMD-32 issues a wave64 VALU instruction over 2 cycles (MI355X_MICROARCH.md): 1229 G/s
             ach = (ipt * asm_px / 64.0) / (asm_ms * 1e-3) if ipt else None
-            out["roofline_assemble"] = {"kernel": "k_assemble_images<8,512,4>", "bound": "valu", "launches": n_asm, "avg_launch_ms": round(asm_ms / n_asm, 4),
+            out["roofline_assemble"] = {"kernel": "k_assemble_images<8,512,6>", "bound": "valu", "launches": n_asm, "avg_launch_ms": round(asm_ms / n_asm, 4),
                                         "pixel_terms_per_launch": round(asm_px / n_asm), "valu_instructions_per_pixel_term": ipt, "source": ipt_src,
                                         "achieved": (round(ach / 1e9, 2) if ach else None), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s",
                                         "frac": (round(ach / peak_issue, 4) if ach else None),

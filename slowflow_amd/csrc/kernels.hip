@@ -987,6 +987,13 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
 #define SFA_PRIO_STAGE 1
 #endif
 #define SFA_PRIO(p) do { if (SFA_PRIO_STAGE) __builtin_amdgcn_s_setprio(p); } while (0)
+// Terms staged per round: 1 (48 KB of LDS: three blocks per CU = six waves per SIMD, for which the kernel stays within 80 registers -- the default since the
+// tap addresses stopped occupying 45 of them) or 2 (rounds 2-4: a pair shares one DMA wait and one barrier and an image both terms use is fetched once, but
+// 76 KB of LDS allow two blocks per CU only).  Measured, 64 windows, mean of the levels: 1 083 -> 990 us per launch
+#ifndef SFA_ASM_PAIR
+#define SFA_ASM_PAIR 0
+#endif
+constexpr int kAsmPair = SFA_ASM_PAIR, kAsmMinWaves = SFA_ASM_PAIR ? 4 : 6;
 struct XcdTiles { int nx, ny, chunk; };      // tile columns, tile rows, ceil(tiles of the launch / 8)
 template <int TY, int NT, int MINB, bool ZUV, int FAST, bool XT>
 __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, const float *__restrict__ base, float *__restrict__ a11, float *__restrict__ a12,
@@ -1001,15 +1008,16 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     constexpr int AW1 = DT_W;
     constexpr int NM = TR * DT_W, N1 = AT_R1 * AW1;
     // terms are staged two at a time (one exposed global-load latency and one barrier less per pair)
-    __shared__ __attribute__((aligned(16))) float lds[12 * NM + 6 * N1];
+    constexpr int ZOFF = kAsmPair ? 6 * NM : 3 * NM, XOFF = 2 * ZOFF;           // start of the Iz planes, of the Ix planes
+    __shared__ __attribute__((aligned(16))) float lds[XOFF + 6 * N1];
     float(*sM2)[NM] = reinterpret_cast<float(*)[NM]>(lds);                      // [2 terms][3 ch] M  = (I1+I2)/2, halo 4 (rows x DT_W)
-    float(*sZ2)[NM] = reinterpret_cast<float(*)[NM]>(lds + 6 * NM);             // [2 terms][3 ch] Iz = I1-I2, same geometry (aligned 16-byte rows)
-    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM);             // Ix, Iy of the term in work: halo 2 (rows x AW1)
-    float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + 12 * NM + 3 * N1);
+    float(*sZ2)[NM] = reinterpret_cast<float(*)[NM]>(lds + ZOFF);               // [2 terms][3 ch] Iz = I1-I2, same geometry (aligned 16-byte rows)
+    float(*sX)[N1] = reinterpret_cast<float(*)[N1]>(lds + XOFF);                // Ix, Iy of the term in work: halo 2 (rows x AW1)
+    float(*sY)[N1] = reinterpret_cast<float(*)[N1]>(lds + XOFF + 3 * N1);
     // the smoothness-side operands of the epilogue (uu, vv, sh, sv with a halo of one) take the place of the M planes once the last term's Ix, Iy exist
     constexpr int GR = TY + 2, NGQ = 4 * GR * (DT_W / 4), NGF = 4 * GR * DT_W;
-    static_assert(NGF <= 6 * NM, "the epilogue's operand planes replace the M planes");
-    static_assert(NGF + TY * (67 * 8 + 69 * 2) <= 12 * NM + 6 * N1, "operand tile must fit the staging block");
+    static_assert(NGF <= ZOFF, "the epilogue's operand planes replace the M planes");
+    static_assert(NGF + TY * (67 * 8 + 69 * 2) <= XOFF + 6 * N1, "operand tile must fit the staging block");
     static_assert(DT_W % 4 == 0 && AW1 % 4 == 0 && NM % 4 == 0 && N1 % 4 == 0, "16-byte LDS rows");
 #ifdef SFA_ASM_TIMING
     unsigned long long at_acc[14] = {0}, at_t = __builtin_readcyclecounter();
@@ -1088,7 +1096,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     float mk2[2][NP];                                                  // the raw warp masks of the staged pair of terms
     for (int t = 0; t < a.n; t++) {
         const Term &T = a.t[t];
-        const int ub = t & 1;                                      // staging buffer of this term
+        const int ub = kAsmPair ? t & 1 : 0;                       // staging buffer of this term
         float(*sM)[NM] = sM2 + 3 * ub;
         float(*sZ)[NM] = sZ2 + 3 * ub;
         if (ub == 0) {
@@ -1103,7 +1111,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         // M / Iz planes of buffer 0, those of the next term into buffer 1; a set's quad order == its LDS order, so a wave-instruction's 64 quads
         // land on 64 consecutive 16-byte slots.  An image that both terms use (the reference frame: I2 of the backward pair is I1 of the forward
         // pair) is fetched once.  A second pass converts in place.
-        const int npair = t + 1 < a.n ? 2 : 1;
+        const int npair = kAsmPair && t + 1 < a.n ? 2 : 1;
         constexpr int NSQ = 3 * TR * QM, NSI = (NSQ + 63) / 64;        // quads / wave-instructions per image set
         const Term &T0 = a.t[t], &T1 = a.t[t + npair - 1];
         // the masks of both terms: issued in front of the DMA, looked at behind its wait
@@ -1117,7 +1125,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         const int from_a = npair == 2 ? (T1.i1_off == T0.i1_off ? 0 : T1.i1_off == T0.i2_off ? 1 : 2) : 0;
         const int from_b = npair == 2 ? (T1.i2_off == T0.i1_off ? 0 : T1.i2_off == T0.i2_off ? 1 : 2) : 0;
         const long set_src[4] = {T0.i1_off, T0.i2_off, T1.i1_off, T1.i2_off};
-        const int set_dst[4] = {0, 6 * NM, 3 * NM, 9 * NM};
+        const int set_dst[4] = {0, ZOFF, 3 * NM, ZOFF + 3 * NM};
         // one wave-instruction per part and set; a part's quad -> (row, channel) arithmetic is the same for every set, so it runs once per part (it was a
         // third of this phase's instructions when it ran per set), and the address is a wave-uniform base per set + one 32-bit lane offset
         const float *set_base[4];
@@ -1174,12 +1182,12 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 *reinterpret_cast<float4 *>(lds + lds_off + 4 * item) =
                     make_float4(0.5f * (vb.x + va.x), 0.5f * (vb.y + va.y), 0.5f * (vb.z + va.z), 0.5f * (vb.w + va.w));        // variational_mt.cpp:120
                 if (ly >= 2 && ly < TR - 2)                         // Iz is read two rows around the tile only (M four: Ix, Iy exist on the halo-2 rows)
-                    *reinterpret_cast<float4 *>(lds + 6 * NM + lds_off + 4 * item) = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);   // :122
+                    *reinterpret_cast<float4 *>(lds + ZOFF + lds_off + 4 * item) = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);   // :122
             };
-            const float4 a0 = fetch(T0.i1_off, 0), b0 = fetch(T0.i2_off, 6 * NM);
+            const float4 a0 = fetch(T0.i1_off, 0), b0 = fetch(T0.i2_off, ZOFF);
             if (npair == 2) {
                 const float4 a1 = from_a == 0 ? a0 : from_a == 1 ? b0 : fetch(T1.i1_off, 3 * NM);
-                const float4 b1 = from_b == 0 ? a0 : from_b == 1 ? b0 : fetch(T1.i2_off, 9 * NM);
+                const float4 b1 = from_b == 0 ? a0 : from_b == 1 ? b0 : fetch(T1.i2_off, ZOFF + 3 * NM);
                 convert(a1, b1, 3 * NM);
             }
             convert(a0, b0, 0);
@@ -1246,9 +1254,9 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             const int c = (ty + NR * k + 2) * AW1 + (txl + 4);    // halo-2 rows (Ix, Iy), M's columns
             const int cz = (ty + NR * k + 4) * DT_W + (txl + 4);  // halo-4 plane (Iz)
             static_assert(AW1 == DT_W, "cz = c + 2 rows");
-            int cb = 6 * NM + c;
+            int cb = ZOFF + c;
             asm volatile("" : "+v"(cb));
-            const float *const pX = lds + cb + 6 * NM, *const pY = pX + 3 * N1, *const pZ = lds + cb + 3 * ub * NM + 2 * DT_W;   // sX[0] + c, sY[0] + c, sZ[0] + cz
+            const float *const pX = lds + cb + (XOFF - ZOFF), *const pY = pX + 3 * N1, *const pZ = lds + cb + 3 * ub * NM + 2 * DT_W;   // sX[0] + c, sY[0] + c, sZ[0] + cz
             Px p;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) p.wk[ch] = FAST ? 1.0f : wk[k][ch];
@@ -1417,8 +1425,8 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
     const dim3 grid1_(8u * (unsigned)xt.chunk, 1, 1);
 #define SFA_LAUNCH_AI(ZUV_, FAST_)                                                                                                                      \
     do {                                                                                                                                                \
-        if (xcd) hipLaunchKernelGGL((k_assemble_images<8, 512, 4, ZUV_, FAST_, true>), grid1_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
-        else hipLaunchKernelGGL((k_assemble_images<8, 512, 4, ZUV_, FAST_, false>), grid_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
+        if (xcd) hipLaunchKernelGGL((k_assemble_images<8, 512, kAsmMinWaves, ZUV_, FAST_, true>), grid1_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
+        else hipLaunchKernelGGL((k_assemble_images<8, 512, kAsmMinWaves, ZUV_, FAST_, false>), grid_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
     } while (0)
     // 64 x 8 tiles, 512 threads, 128 VGPRs (two blocks per CU).  Measured and dropped: 64 x 16 with two pixels per thread (209 VGPRs, one block per CU: slower),
     // 8 x 256 threads, 16 x 1024 threads (spills at its 128-register cap)
