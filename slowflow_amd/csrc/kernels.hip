@@ -1114,13 +1114,6 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         const int npair = kAsmPair && t + 1 < a.n ? 2 : 1;
         constexpr int NSQ = 3 * TR * QM, NSI = (NSQ + 63) / 64;        // quads / wave-instructions per image set
         const Term &T0 = a.t[t], &T1 = a.t[t + npair - 1];
-        // the masks of both terms: issued in front of the DMA, looked at behind its wait
-#pragma unroll
-        for (int k = 0; k < NP; k++) {
-            const size_t o = (size_t)(y0 + DT_H + ty + NR * k) * g.pitch + x;
-            mk2[0][k] = ok[k] && !(SFA_X_AI & 128) ? base[eb + T0.mask_off + o] : 0.0f;
-            mk2[1][k] = ok[k] && !(SFA_X_AI & 128) ? base[eb + T1.mask_off + o] : 0.0f;
-        }
         // where the next term's I1 / I2 come from: 0 this term's I1, 1 this term's I2, 2 own fetch
         const int from_a = npair == 2 ? (T1.i1_off == T0.i1_off ? 0 : T1.i1_off == T0.i2_off ? 1 : 2) : 0;
         const int from_b = npair == 2 ? (T1.i2_off == T0.i1_off ? 0 : T1.i2_off == T0.i2_off ? 1 : 2) : 0;
@@ -1144,6 +1137,15 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
                 if (own_a) dma16s(set_base[2], po, ld + 4u * set_dst[2]);
                 if (own_b) dma16s(set_base[3], po, ld + 4u * set_dst[3]);
             }
+        }
+        // the masks of the staged terms: issued BEHIND the DMA (the asm statements above are memory barriers to the compiler), looked at behind the one wait.
+        // In front of it their destination registers were reused as the don't-care high half of a 64-bit multiply-add in the issue loop, and the wait-count
+        // pass answered with an `s_waitcnt vmcnt(0)` inside the loop: a full memory round trip before the first DMA piece (12 % of the wave time in the phase stamps)
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const size_t o = (size_t)(y0 + DT_H + ty + NR * k) * g.pitch + x;
+            mk2[0][k] = ok[k] && !(SFA_X_AI & 128) ? base[eb + T0.mask_off + o] : 0.0f;
+            mk2[1][k] = npair == 2 ? (ok[k] && !(SFA_X_AI & 128) ? base[eb + T1.mask_off + o] : 0.0f) : mk2[0][k];
         }
         AT_MARK(2);
         // everything issued so far has landed behind this wait: the DMA pieces and the prologue's / the masks' loads (tied to it through the operand list,

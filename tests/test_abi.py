@@ -102,3 +102,16 @@ def test_counted_publish_covers_the_edge_store():
         pytest.skip("hipcc not available")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_publish_vmcnt.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "counted publishes cover their edge store" in r.stdout, r.stdout + r.stderr
+
+
+def test_no_wait_inside_the_dma_issue_of_the_assembly_kernel():
+    """Round 4: twice a register of the DMA issue loop's address arithmetic had a load pending (the prologue's, then the masks') and the compiler's wait-count
+    pass put an `s_waitcnt vmcnt(0)` in front of the first piece -- a whole memory round trip in every staging round, 4-30 % of the kernel.  Checked on the ISA
+    of every instance (tools/isa_dma_waits.py compiles kernels.hip with the product's flags)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_dma_waits.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "no wait inside any DMA issue phase" in r.stdout, r.stdout + r.stderr

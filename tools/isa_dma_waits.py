@@ -1,0 +1,36 @@
+"""Build-time check of k_assemble_images: no `s_waitcnt vmcnt` may sit between the first and the last `global_load_lds` of a staging round (the DMA pieces
+are issued untracked; a compiler-made wait between them -- a register of the address arithmetic with a load pending -- exposes a memory round trip per piece).
+usage: isa_dma_waits.py [file.s [kernel substring]]      without a listing, kernels.hip is compiled to one with the product's flags; exit code 1 if any
+instance has such a wait"""
+import os, re, subprocess, sys, tempfile
+if len(sys.argv) > 1:
+    lines = open(sys.argv[1]).read().split("\n")
+else:
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slowflow_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "kernels.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+                        "-Wno-unused-function", "-S", "--cuda-device-only", os.path.join(csrc, "kernels.hip"), "-o", out], check=True, capture_output=True)
+        lines = open(out).read().split("\n")
+pat = sys.argv[2] if len(sys.argv) > 2 else "k_assemble_images"
+bad = 0
+starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\S*:", l) and pat in l]
+for st in starts:
+    end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    ins = [l.split(";")[0].strip() for l in lines[st:end]]
+    ins = [t for t in ins if t and not t.startswith(".")]          # labels and directives dropped: program order of the listing
+    # a staging round = the instructions from the s_barrier (or kernel start) in front of a global_load_lds to the last global_load_lds before the next s_barrier
+    bars = [-1] + [i for i, t in enumerate(ins) if t.startswith("s_barrier")] + [len(ins)]
+    dma, waits = [], []
+    for lo, hi in zip(bars, bars[1:]):
+        d = [i for i in range(lo + 1, hi) if ins[i].startswith("global_load_lds")]
+        if not d: continue
+        dma += d
+        waits += [f"{i}: {ins[i]}" for i in range(lo + 1, d[-1]) if ins[i].startswith("s_waitcnt") and "vmcnt" in ins[i]]
+    print(f"{lines[st][:70]:70s} {len(dma):3d} DMA instructions, vmcnt waits between them: {len(waits)}")
+    for w in waits: print("      ", w)
+    # the fully general instance (ZUV = false, FAST = 0: run-time penalties, channel weights, 2-4 spill reloads -- vector-memory instructions themselves) is
+    # reported, not counted: no configuration of BASELINE.json runs it
+    if "ELb0ELi0ELb" not in lines[st]: bad += len(waits)
+print("no wait inside any DMA issue phase" if not bad else f"{bad} waits inside DMA issue phases")
+sys.exit(1 if bad else 0)

@@ -51,3 +51,7 @@ if len(sys.argv)>4:
         # previous def
         pd=next((k for k in range(i,-1,-1) if r in acc[k][0]),None)
         print(f"v{r}: def@{pd} {ins[pd] if pd is not None else ''}   || use@{nu} {ins[nu] if nu is not None else ''}")
+# the pressure profile: live registers every 100 instructions and the peak
+pk=max(range(len(ins)),key=lambda i:len(liv[i]))
+print("peak", len(liv[pk]), "at", pk, ins[pk])
+print(" ".join(f"{i}:{len(liv[i])}" for i in range(0,len(ins),100)))
