@@ -996,7 +996,10 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
 #ifndef SFA_ASM_PAIR
 #define SFA_ASM_PAIR 0
 #endif
-constexpr int kAsmPair = SFA_ASM_PAIR, kAsmMinWaves = SFA_ASM_PAIR ? 4 : 6;
+#ifndef SFA_ASM_TY
+#define SFA_ASM_TY 8
+#endif
+constexpr int kAsmPair = SFA_ASM_PAIR, kAsmMinWaves = SFA_ASM_PAIR ? 4 : 6, kAsmTY = SFA_ASM_TY, kAsmNT = 64 * SFA_ASM_TY;      // tile rows, threads (one row per wave)
 struct XcdTiles { int nx, ny, chunk; };      // tile columns, tile rows, ceil(tiles of the launch / 8)
 template <int TY, int NT, int MINB, bool ZUV, int FAST, bool XT>
 __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, const float *__restrict__ base, float *__restrict__ a11, float *__restrict__ a12,
@@ -1462,7 +1465,7 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
         for (int t = 0; t < a.n && okp; t++) okp = (a.t[t].hd == 0.0f || in(a.t[t].hd, hlo, 65536.0f)) && (a.t[t].hg == 0.0f || in(a.t[t].hg, hlo, 65536.0f));
         a.chain_ok = okp && !getenv("SFA_EXACT_DIV") ? 1 : 0;
     }
-    const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + 8 - 1) / 8, g.nb);
+    const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + kAsmTY - 1) / kAsmTY, g.nb);
     // the XCD-contiguous tile order (see the kernel) from 8 workgroups per XCD on; SFA_ASM_XCD=0: the plain grid, for A/B measurements
     const char *xcd_e = getenv("SFA_ASM_XCD");
     const bool xcd_env = !xcd_e || atoi(xcd_e) != 0;
@@ -1472,8 +1475,8 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
     const dim3 grid1_(8u * (unsigned)xt.chunk, 1, 1);
 #define SFA_LAUNCH_AI(ZUV_, FAST_)                                                                                                                      \
     do {                                                                                                                                                \
-        if (xcd) hipLaunchKernelGGL((k_assemble_images<8, 512, kAsmMinWaves, ZUV_, FAST_, true>), grid1_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
-        else hipLaunchKernelGGL((k_assemble_images<8, 512, kAsmMinWaves, ZUV_, FAST_, false>), grid_, dim3(512), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
+        if (xcd) hipLaunchKernelGGL((k_assemble_images<kAsmTY, kAsmNT, kAsmMinWaves, ZUV_, FAST_, true>), grid1_, dim3(kAsmNT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
+        else hipLaunchKernelGGL((k_assemble_images<kAsmTY, kAsmNT, kAsmMinWaves, ZUV_, FAST_, false>), grid_, dim3(kAsmNT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
     } while (0)
     // 64 x 8 tiles, 512 threads, 128 VGPRs (two blocks per CU).  Measured and dropped: 64 x 16 with two pixels per thread (209 VGPRs, one block per CU: slower),
     // 8 x 256 threads, 16 x 1024 threads (spills at its 128-register cap)

@@ -19,14 +19,15 @@ for st in starts:
     end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))
     ins = [l.split(";")[0].strip() for l in lines[st:end]]
     ins = [t for t in ins if t and not t.startswith(".")]          # labels and directives dropped: program order of the listing
-    # a staging round = the instructions from the s_barrier (or kernel start) in front of a global_load_lds to the last global_load_lds before the next s_barrier
-    bars = [-1] + [i for i, t in enumerate(ins) if t.startswith("s_barrier")] + [len(ins)]
-    dma, waits = [], []
-    for lo, hi in zip(bars, bars[1:]):
-        d = [i for i in range(lo + 1, hi) if ins[i].startswith("global_load_lds")]
-        if not d: continue
-        dma += d
-        waits += [f"{i}: {ins[i]}" for i in range(lo + 1, d[-1]) if ins[i].startswith("s_waitcnt") and "vmcnt" in ins[i]]
+    # an issue phase = global_load_lds instructions less than GAP instructions apart, plus the LEAD instructions in front of the first one (the address
+    # arithmetic of the piece, where both waits of round 4 sat); basic-block placement does not matter to this window
+    GAP, LEAD = 40, 14
+    dma = [i for i, t in enumerate(ins) if t.startswith("global_load_lds")]
+    waits, prev = [], None
+    for i in dma:
+        lo = prev + 1 if prev is not None and i - prev < GAP else max(0, i - LEAD)
+        waits += [f"{k}: {ins[k]}" for k in range(lo, i) if ins[k].startswith("s_waitcnt") and "vmcnt" in ins[k]]
+        prev = i
     print(f"{lines[st][:70]:70s} {len(dma):3d} DMA instructions, vmcnt waits between them: {len(waits)}")
     for w in waits: print("      ", w)
     # the fully general instance (ZUV = false, FAST = 0: run-time penalties, channel weights, 2-4 spill reloads -- vector-memory instructions themselves) is
