@@ -112,7 +112,9 @@ struct ChannelWeights { const float *dev = nullptr; long pl = 0, es = 0; int pit
 static const float *pair_image(const Level &L, int s, int sp1) { return (s + sp1 - L.ref == 0) ? L.frame(s + sp1) : L.warp(s, sp1); }
 
 // get_derivatives (variational_mt.cpp:87-166).  Fused form: only the warps; the filters run inside the assembly kernel.
-static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, const Geo &g, const bool need_toref[2 * SFA_MAX_REF]) {
+// with_smoothness: compute_smoothness (:333) of the same flow field leaves in the same pass (the caller's next step, fused form with one inner iteration); returns
+// whether it did
+static bool get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, const Geo &g, const bool need_toref[2 * SFA_MAX_REF], bool with_smoothness = false) {
     const int ref = L.ref;
     WarpJobs J;
     J.n = 0;
@@ -121,7 +123,9 @@ static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, con
         if (s - ref != 0) J.job[J.n++] = WarpJob{L.frame(s) - L.base, L.warp(s, 0) - L.base, s < ref ? L.mask(s) - L.base : -1L, s - ref};
         if (s - ref + 1 != 0) J.job[J.n++] = WarpJob{L.frame(s + 1) - L.base, L.warp(s, 1) - L.base, s < ref ? -1L : L.mask(s) - L.base, s - ref + 1};
     }
-    launch_warp_jobs(c, g, J, L.base, L.plane(P_WX), L.plane(P_WY));
+    const bool smoothed = with_smoothness && L.fused &&
+                          launch_warp_smooth(c, g, J, L.base, L.plane(P_WX), L.plane(P_WY), p.smoothing, L.plane(P_SH), L.plane(P_SV), L.plane(P_DPSIS), p.alpha, pen(p.robust_reg));
+    if (!smoothed) launch_warp_jobs(c, g, J, L.base, L.plane(P_WX), L.plane(P_WY));
     for (int s = p.one_direction ? ref : 0; s < 2 * ref; s++) {
         if (L.fused) continue;
         const float *w_s = pair_image(L, s, 0), *w_sp1 = pair_image(L, s, 1);
@@ -132,6 +136,7 @@ static void get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, con
             else         launch_deriv_stack(c, g, L.stack(s, 1), L.frame(ref), w_sp1, L.es, L.es);               // :143-144
         }
     }
+    return smoothed;
 }
 
 // compute_one_level (variational_mt.cpp:169-493) for all batch elements in lockstep.
@@ -252,7 +257,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
         active = all;
         g.active = active;
         if (use_thres_out && alter > 0) launch_set_mask(c, all);
-        get_derivatives(c, L, p, g, need_toref);                                                            // :266
+        bool smoothed = get_derivatives(c, L, p, g, need_toref, uv_alias);                                  // :266 (+ :333 of the first outer iteration)
         if (alter > 0 && p.occlusion_reasoning && !p.one_direction) SFA_TRY(optimize_occlusions(c, L, p, g, cut_scratch));   // :269-272
         if (alter > 0 && p.occlusion_reasoning && occ_log)                                                  // :275-285
             launch_copy_planes(c, g, occ_log + (long)alter * L.pl, L.plane(P_OCC), 1, (long)p.niter_alter * L.pl, L.es);
@@ -265,7 +270,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             }
             if (dbg) fprintf(stderr, "level %dx%d alter %d outer %d known active %d\n", L.w, L.h, alter, outer, __builtin_popcountll(active));
             g.active = active;
-            if (outer > 0) get_derivatives(c, L, p, g, need_toref);                                         // :289-290
+            if (outer > 0) smoothed = get_derivatives(c, L, p, g, need_toref, uv_alias);                    // :289-290 (+ :333)
             if (!L.fused) launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);   // :293-320
             // in the direct form the first inner iteration never touches du / dv / old du / old dv: they are zeros by construction.
             // Windows that already met a threshold stay in the lockstep launches as passengers: every kernel skips them (Geo::active and
@@ -282,8 +287,9 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 if (!first_zero) {
                     launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                // :329-330
                 }
-                launch_smoothness(c, gi, p.smoothing, L.plane(P_SH), L.plane(P_SV), UU, VV, L.plane(P_DPSIS), p.alpha,
-                                  pen(p.robust_reg));                                                       // :333
+                if (!(smoothed && inner == 0))                      // (uv_alias: one inner iteration, UU / VV are wx / wy -- what the fused pass read)
+                    launch_smoothness(c, gi, p.smoothing, L.plane(P_SH), L.plane(P_SV), UU, VV, L.plane(P_DPSIS), p.alpha,
+                                      pen(p.robust_reg));                                                   // :333
                 // the fused assembly can leave the solver's operands directly (no a11 .. b2 planes, no prepare pass) when the
                 // whole batch is solved in one launch
                 aa.op = SorOperandOut();

@@ -79,15 +79,16 @@ __global__ void k_warp(float *__restrict__ dst3, float *__restrict__ mask, const
     }
 }
 // all warps of one get_derivatives call in a single launch (grid z = window x job)
+template <bool ALLJ>
 __global__ void k_warp_jobs(WarpJobs J, float *__restrict__ base, const float *__restrict__ wx, const float *__restrict__ wy, Geo g) {
-    const int b = blockIdx.z / J.n, j0 = blockIdx.z % J.n;
+    const int b = ALLJ ? blockIdx.z : blockIdx.z / J.n, j0 = ALLJ ? 0 : blockIdx.z % J.n;
     if (!elem_active(g, b)) return;
     const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
     if (x >= g.w || y >= g.h) return;
     const long eb = b * g.es;
     const size_t o = (size_t)y * g.pitch + x;
     const float fx0 = wx[eb + o], fy0 = wy[eb + o];
-    for (int j = j0; j <= j0; j++) {
+    for (int j = j0; j <= (ALLJ ? J.n - 1 : j0); j++) {
         const int factor = J.job[j].factor;
         const float *src3 = base + eb + J.job[j].src_off;
         float *dst3 = base + eb + J.job[j].dst_off;
@@ -111,7 +112,12 @@ __global__ void k_warp_jobs(WarpJobs J, float *__restrict__ base, const float *_
     }
 }
 void launch_warp_jobs(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base, const float *wx, const float *wy) {
-    if (J.n > 0) hipLaunchKernelGGL(k_warp_jobs, grid2d(g, J.n), block2d(), 0, c->stream, J, base, wx, wy, g);
+    if (J.n <= 0) return;
+    // all jobs of a pixel in one thread (the flow is read once; 262 -> 250 us per 64-window launch) unless SFA_WARP_ALLJ=0 (one job per grid z, rounds 1-4)
+    const char *allj_e = getenv("SFA_WARP_ALLJ");
+    const bool allj = !allj_e || atoi(allj_e);
+    if (allj) hipLaunchKernelGGL(k_warp_jobs<true>, grid2d(g), block2d(), 0, c->stream, J, base, wx, wy, g);
+    else hipLaunchKernelGGL(k_warp_jobs<false>, grid2d(g, J.n), block2d(), 0, c->stream, J, base, wx, wy, g);
 }
 void launch_warp(sfa_ctx *c, const Geo &g, float *dst3, float *mask, const float *src3, const float *wx, const float *wy, int factor, long src_es) {
     hipLaunchKernelGGL(k_warp, grid2d(g), block2d(), 0, c->stream, dst3, mask, src3, wx, wy, g, factor, src_es);
@@ -393,6 +399,111 @@ void launch_smoothness(sfa_ctx *c, const Geo &g, int method, float *sh, float *s
     }
     dim3 grid((g.pitch + BX - 1) / BX, (g.h + BY - 1) / BY, g.nb);
     hipLaunchKernelGGL(k_smoothness, grid, block2d(), 0, c->stream, method, sh, sv, uu, vv, dpsis, g, alpha, reg);
+}
+
+// get_derivatives' warps (variational_mt.cpp:100-109) and compute_smoothness (:333) of the same flow field in one pass: both read wx, wy of every pixel, the
+// smoothness kernel alone is bound by its two IEEE square-root / division chains per pixel (2.8 TB/s) and the warp by its traffic -- together the arithmetic runs
+// under the gathers and the flow tile is read once.  Same per-pixel operations as k_smoothness_tiled and k_warp_jobs (bit-identical: test_fused_warp_smoothness).
+__global__ void __launch_bounds__(256) k_warp_smooth(WarpJobs J, float *__restrict__ base, int method, float *__restrict__ sh, float *__restrict__ sv,
+                                                     const float *__restrict__ uu_, const float *__restrict__ vv_, const float *__restrict__ dps_, Geo g, float alpha,
+                                                     PenaltyDev reg) {
+    __shared__ float tU[SM_R * SM_W], tV[SM_R * SM_W], tD[SM_R * SM_W];
+    const int b = blockIdx.z;
+    if (!elem_active(g, b)) return;
+    const int x0 = blockIdx.x * SM_X - 1, y0 = blockIdx.y * SM_Y - 1;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const long eb = b * g.es;
+    const float *pu = uu_ + eb, *pv = vv_ + eb, *pd = dps_ + eb;
+    for (int i = tid; i < SM_R * SM_W; i += 256) {
+        const int gx = x0 + i % SM_W, gy = y0 + i / SM_W;
+        if (gx >= 0 && gx < g.w && gy >= 0 && gy < g.h) {
+            const size_t o = (size_t)gy * g.pitch + gx;
+            tU[i] = pu[o]; tV[i] = pv[o]; tD[i] = pd[o];
+        }
+    }
+    __syncthreads();
+    const SmTile uu{tU, x0, y0}, vv{tV, x0, y0}, dps{tD, x0, y0};
+    const int w = g.w, h = g.h;
+    const int x = x0 + 1 + threadIdx.x;
+    sh += eb; sv += eb;
+    for (int k = 0; k < SM_Y / 4; k++) {
+        const int y = y0 + 1 + threadIdx.y + 4 * k;
+        if (x >= g.pitch || y >= h) continue;
+        const size_t o = (size_t)y * g.pitch + x;
+        if (x >= w) { sh[o] = 0.0f; sv[o] = 0.0f; continue; }        // padding lanes stay zero
+        // ---- the warps of this pixel: the gathers of the first two jobs are issued here, the smoothness arithmetic runs while they are in flight ---------
+        const float fx0 = uu(x, y), fy0 = vv(x, y);
+        auto gather = [&](int j, float(&out)[3]) {
+            const int factor = J.job[j].factor;
+            const float *src3 = base + eb + J.job[j].src_off;
+            const float xx = x + factor * fx0;                              // :735
+            const float yy = y + factor * fy0;
+            const int xi = (int)floorf(xx), yi = (int)floorf(yy);
+            const float dx = xx - xi, dy = yy - yi;
+            if (J.job[j].mask_off >= 0) base[eb + J.job[j].mask_off + o] = (xx >= 0 && xx <= g.w - 1 && yy >= 0 && yy <= g.h - 1) ? 1.0f : 0.0f;   // :742
+            const int x1 = clampi(xi, 0, g.w - 1), x2 = clampi(xi + 1, 0, g.w - 1);
+            const int y1 = clampi(yi, 0, g.h - 1), y2 = clampi(yi + 1, 0, g.h - 1);
+            const float ax = 1.0f - dx, ay = 1.0f - dy;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float *sp = src3 + ch * g.pl;
+                out[ch] = sp[(size_t)y1 * g.pitch + x1] * ax * ay + sp[(size_t)y1 * g.pitch + x2] * dx * ay
+                        + sp[(size_t)y2 * g.pitch + x1] * ax * dy + sp[(size_t)y2 * g.pitch + x2] * dx * dy;               // :748-753
+            }
+        };
+        auto put = [&](int j, const float(&out)[3]) {
+            float *dst3 = base + eb + J.job[j].dst_off;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) dst3[ch * g.pl + o] = out[ch];
+        };
+        float out0[3] = {0, 0, 0}, out1[3] = {0, 0, 0};
+        gather(0, out0);
+        if (J.n > 1) gather(1, out1);
+        // ---- compute_smoothness ----------------------------------------------------------------------------------------------------------------------
+        float outh = 0.0f, outv = 0.0f;
+        if (x < w - 1) {
+            const float ux1 = uu(x + 1, y) - uu(x, y), vx1 = vv(x + 1, y) - vv(x, y);     // :27-28
+            float t = 0.0f, t2 = 0.0f;
+            if (method == 1) {
+                t = 0.5f * (d3y(uu, x, y, h) + d3y(uu, x + 1, y, h));                      // :57
+                t2 = 0.5f * (d3y(vv, x, y, h) + d3y(vv, x + 1, y, h));
+            }
+            t = ux1 * ux1 + t * t;                                                       // :61-64
+            t2 = vx1 * vx1 + t2 * t2;
+            t = t + t2;
+            outh = (dps(x, y) + dps(x + 1, y)) * alpha * psi_scalar(reg, t);              // :66
+        }
+        if (y < h - 1) {
+            const float uy1 = uu(x, y + 1) - uu(x, y), vy1 = vv(x, y + 1) - vv(x, y);     // :35-36
+            float t = 0.0f, t2 = 0.0f;
+            if (method == 1) {
+                t = 0.5f * (d3x(uu, x, y, w) + d3x(uu, x, y + 1, w));                      // :80
+                t2 = 0.5f * (d3x(vv, x, y, w) + d3x(vv, x, y + 1, w));
+            }
+            t = uy1 * uy1 + t * t;                                                       // :84-87
+            t2 = vy1 * vy1 + t2 * t2;
+            t = t + t2;
+            outv = (dps(x, y) + dps(x, y + 1)) * alpha * psi_scalar(reg, t);              // :89
+        }
+        sh[o] = outh;                                                                    // :68 zero last column
+        sv[o] = outv;                                                                    // :92 zero last row
+        put(0, out0);
+        if (J.n > 1) put(1, out1);
+        for (int j = 2; j < J.n; j++) {                                                  // S >= 3: the further jobs one after the other
+            float o3[3];
+            gather(j, o3);
+            put(j, o3);
+        }
+    }
+}
+// false: not this combination (the caller then launches the two kernels)
+bool launch_warp_smooth(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base, const float *wx, const float *wy, int method, float *sh, float *sv,
+                        const float *dpsis, float alpha, PenaltyDev reg) {
+    const bool off = getenv("SFA_NO_WARP_SMOOTH") != nullptr;      // (read per launch: the parity test switches it inside one process)
+    if (off || method > 1 || J.n <= 0) return false;
+    hipLaunchKernelGGL(k_warp_smooth, dim3((g.pitch + SM_X - 1) / SM_X, (g.h + SM_Y - 1) / SM_Y, g.nb), dim3(64, 4), 0, c->stream, J, base, method, sh, sv, wx, wy,
+                       dpsis, g, alpha, reg);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -112,6 +112,8 @@ struct PenaltyDev { int id; float eps, trunc; };
 struct WarpJob { long src_off, dst_off, mask_off; int factor; };
 struct WarpJobs { WarpJob job[4 * SFA_MAX_REF]; int n; };
 void launch_warp_jobs(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base, const float *wx, const float *wy);
+bool launch_warp_smooth(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base, const float *wx, const float *wy, int method, float *sh, float *sv,
+                        const float *dpsis, float alpha, PenaltyDev reg);   // the warps + compute_smoothness of the same flow in one pass; false: not this combination
 void launch_warp(sfa_ctx *c, const Geo &g, float *dst3, float *mask, const float *src3, const float *wx, const float *wy, int factor,
                  long src_es /* batch stride of src3 (frames) */);
 void launch_deriv_stack(sfa_ctx *c, const Geo &g, float *out24, const float *I1, const float *I2, long es1, long es2);

@@ -1064,6 +1064,26 @@ def test_fused_pyramid_step_is_blur_then_resize(ctx, oracle, monkeypatch, w, h, 
     assert np.array_equal(valid(out[0][0], w), valid(out[1][0], w)) and np.array_equal(valid(out[0][1], w), valid(out[1][1], w))
 
 
+@pytest.mark.parametrize("w,h,S,smoothing", [(130, 98, 2, 1), (67, 45, 3, 1), (200, 150, 2, 0), (1024, 436, 2, 1)])
+def test_fused_warp_smoothness_is_the_two_kernels(ctx, oracle, monkeypatch, w, h, S, smoothing):
+    """k_warp_smooth (the warps of get_derivatives and compute_smoothness of the same flow field in one pass; S = 3: six warps, four of them behind the
+    smoothness arithmetic) gives the bits of k_warp_jobs + k_smoothness_tiled -- whole runs agree exactly -- and so does the one-job-per-grid-z form of the warps"""
+    frames, af, sf = normalized_frames(oracle, w, h, 2 * S - 1, seed=37)
+    _, ps = mk_params(oracle, S=S, rho=[1] * (S - 1), omega=[0] * (S - 1), norm_avg=af, norm_std=sf, niter_outer=3, layers=2, smoothing=smoothing)
+    out = []
+    for env in ({}, {"SFA_NO_WARP_SMOOTH": "1"}, {"SFA_NO_WARP_SMOOTH": "1", "SFA_WARP_ALLJ": "0"}):
+        for k in ("SFA_NO_WARP_SMOOTH", "SFA_WARP_ALLJ"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
+        ctx.variational(ps, wx, wy, [c_(f) for f in frames], w, None)
+        out.append((wx, wy))
+    for o in out[1:]:
+        assert np.array_equal(valid(out[0][0], w), valid(o[0], w)) and np.array_equal(valid(out[0][1], w), valid(o[1], w))
+    assert np.abs(valid(out[0][0], w)).max() > 0
+
+
 @pytest.mark.parametrize("sigma", [0.3, 0.5, 0.8, 1.7])
 def test_variational_with_presmoothing(ctx, oracle, sigma):
     """cfg `sigma` > 0: level 0 is presmoothed with gaussian_filter + the generic / 3-tap / 5-tap convolutions of image.c (the oracle's
