@@ -20,7 +20,8 @@ def pmc(d):
     return acc
 fe, wr, sq = pmc(f"{tag}_c5_fetch"), pmc(f"{tag}_c5_write"), pmc(f"{tag}_c5_sq")
 # algorithmic bytes per pixel of the launch's level (fp32 planes; S = 2: two data terms) for the kernels where the figure is defined
-ALG = {"k_warp_jobs": ("2 warps x (2 flow + 3 gather + 3 store + 1 mask) x 4 B", 72.0), "k_smoothness_tiled": ("uu, vv, dpsis in; sh, sv out", 20.0),
+ALG = {"k_warp_jobs": ("2 flow + 2 warps x (3 gather + 3 store + 1 mask) x 4 B", 64.0), "k_smoothness_tiled": ("uu, vv, dpsis in; sh, sv out", 20.0),
+       "k_warp_smooth": ("the warps (64 B) + dpsis in; sh, sv out, the flow read once", 76.0),
        "k_update_outer_x": ("du, dv, wx, wy in; uu, vv, wx, wy out", 32.0), "k_assemble_images": ("3 frames x 3 ch + 2 masks + occ, uu, vv, sh, sv in; 40 B of solver operands out", 104.0),
        "k_sor_chain": ("fused 30-sweep solve: 2 x 16 B operands + 8 B iterate in + 8 B out (SURVEY 8(d) per-sweep model: 1332 B)", 48.0), "k_dpsis": ("3 ch in, 1 plane out", 16.0)}
 plain = open(os.path.join(go, f"{tag}_c5_plain.txt")).read().strip().splitlines()[-1]
