@@ -773,7 +773,9 @@ def main():
                                         "frac": (round(ach / peak_issue, 4) if ach else None),
                                         # the SIMDs' own view from the same counter pass: SQ_ACTIVE_INST_VALU x 4 / SIMD cycles when the kernel runs alone.  The counter
                                         # charges a quad-cycle (4 cycles) per wave instruction where the SIMD-32 needs 2, so it reads about twice the issue-slot use
-                                        "valu_active_frac_alone": valu_active,
+                                        # (six waves per SIMD: the raw ratio passes 1 -- carried as a ratio, and halved as the issue-slot use at 2 cycles per instruction)
+                                        "valu_quadcycle_ratio_alone": valu_active,
+                                        "valu_issue_slot_frac_alone": (round(valu_active / 2.0, 4) if valu_active else None),
                                         "share_of_step": round(asm_ms / S / (elapsed * 1e3), 4),
                                         "note": "launch durations are those inside the timed region, where the other stream's kernels share the GPU (alone: about half)"}
         if strong is not None:

@@ -73,6 +73,6 @@ def test_two_ranks_for_real_on_one_gpu():
         if isinstance(o, dict):
             for k, v in o.items():
                 yield from fracs(v, path + "/" + k)
-        elif path.rsplit("/", 1)[-1] == "frac" and o is not None:
+        elif "frac" in path.rsplit("/", 1)[-1] and isinstance(o, (int, float)):      # `frac` and every *_frac* key
             yield path, o
     assert all(0 <= v <= 1 for _, v in fracs(out)), list(fracs(out))

@@ -1,4 +1,4 @@
-# the round's final records in ONE box (boxes differ by 3-5 %): run from the repo root on the GPU box;  bash tools/_final.sh [bench-only]
+# the round's final records in ONE box (boxes differ by 3-5 %): run from the repo root on the GPU box;  bash tools/final_records.sh [bench-only]
 set -e
 mkdir -p gpurun_out/r04_summary
 if [ "$1" != "bench-only" ]; then
