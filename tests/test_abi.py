@@ -115,3 +115,15 @@ def test_no_wait_inside_the_dma_issue_of_the_assembly_kernel():
         pytest.skip("hipcc not available")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_dma_waits.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "no wait inside any DMA issue phase" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_assembly_kernel_keeps_three_blocks_per_cu():
+    """Round 4: the data-term kernel's 15 % came from a third block per CU (79 registers, 48 KB of LDS).  tools/check_asm_occupancy.py reads the compiler's own
+    resource report for every instance of kernels.hip built with the product's flags."""
+    import shutil
+    import subprocess
+    import sys
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_occupancy.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "three blocks per CU for every folded instance" in r.stdout, r.stdout + r.stderr
