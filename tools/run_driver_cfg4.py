@@ -35,6 +35,8 @@ with open(cfg,"w") as f:
             "slow_flow_niter_solver\t30\nslow_flow_sor_omega\t1.9\nslow_flow_occlusion_reasoning\t1\nslow_flow_occlusion_penalty\t0.1\nslow_flow_occlusion_alpha\t0.1\n"
             "slow_flow_rho_0\t1\nslow_flow_rho_1\t1\nslow_flow_omega_0\t0\nslow_flow_omega_1\t2\nslow_flow_alpha\t4.0\nslow_flow_gamma\t6.0\nslow_flow_delta\t1.0\n"
             "slow_flow_thres_outer\t1e-5\nslow_flow_thres_inner\t1e-5\nslow_flow_output_occlusions\t0\n")
+    for key, env in (("gpu_batch", "SFA_DRV_BATCH"), ("gpu_streams", "SFA_DRV_STREAMS")):      # experiments: the driver's lockstep batch / groups per GPU
+        if os.environ.get(env): f.write("%s\t%s\n" % (key, os.environ[env]))
 t0=time.perf_counter()
 r=subprocess.run([os.path.join(ROOT,"slowflow_amd","host","slow_flow"),cfg,"-overwrite"],capture_output=True,text=True)
 dt=time.perf_counter()-t0
