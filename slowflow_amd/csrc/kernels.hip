@@ -1924,6 +1924,9 @@ void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl,
 // against 1.9x at 8); the source footprint (+ blur radius, replicated at the image border) is staged in LDS,
 // blurred along rows, then along columns, and sampled bilinearly -- the same operations in the same order as k_gauss_h,
 // k_gauss_v, k_resize, without the two intermediate images.
+#ifndef SFA_PYR_GROUP
+#define SFA_PYR_GROUP 4
+#endif
 template <int R>
 __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int dw, int dh, int dpitch, long dpl, long des, const float *__restrict__ src, int sw, int sh,
                                                   int spitch, long spl, long ses, int nplanes, double scale_x, double scale_y, Taps t, int CM, int RM, int td) {
@@ -1946,24 +1949,37 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
         const int NQ = (CS + off + 3) / 4;
         int j = tid / NQ, qa = tid % NQ;
         const int dj = 256 / NQ, dq = 256 % NQ;
+        // a thread's items four at a time: every global load of the group is issued before the first value is scattered (one item at a time -- load, wait,
+        // four LDS stores the next load could not pass -- a thread's 4-5 items were as many memory round trips in a row)
+        constexpr int G = SFA_PYR_GROUP;
         while (j < RS) {
-            const float *row = s + (size_t)clampi(my0 - r + j, 0, sh - 1) * spitch;
-            const int gx = sxa + 4 * qa;
-            float v[4];
-            if (gx >= 0 && gx + 3 < sw) {
-                const float4 q4 = *reinterpret_cast<const float4 *>(row + gx);
-                v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
-            } else {
+            float v[G][4];
+            int jj[G], cc[G];
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = row[clampi(gx + e, 0, sw - 1)];
+            for (int i = 0; i < G; i++) {
+                jj[i] = j; cc[i] = 4 * qa - off;
+                if (j < RS) {
+                    const float *row = s + (size_t)clampi(my0 - r + j, 0, sh - 1) * spitch;
+                    const int gx = sxa + 4 * qa;
+                    if (gx >= 0 && gx + 3 < sw) {
+                        const float4 q4 = *reinterpret_cast<const float4 *>(row + gx);
+                        v[i][0] = q4.x; v[i][1] = q4.y; v[i][2] = q4.z; v[i][3] = q4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[i][e] = row[clampi(gx + e, 0, sw - 1)];
+                    }
+                }
+                qa += dq; j += dj;
+                if (qa >= NQ) { qa -= NQ; j++; }
             }
-            float *Sr = S + j * CS;
-            const int c0 = 4 * qa - off;
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (c0 + e >= 0 && c0 + e < CS) Sr[c0 + e] = v[e];
-            qa += dq; j += dj;
-            if (qa >= NQ) { qa -= NQ; j++; }
+            for (int i = 0; i < G; i++) {
+                if (jj[i] >= RS) continue;
+                float *Sr = S + jj[i] * CS;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (cc[i] + e >= 0 && cc[i] + e < CS) Sr[cc[i] + e] = v[i][e];
+            }
         }
     }
     __syncthreads();
