@@ -1091,7 +1091,7 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
 #ifndef SFA_X_AI
 #define SFA_X_AI 0
 #endif
-// wave priority of the staging phases (DMA issue, conversion, stage 1, epilogue) against the per-pixel arithmetic (priority 0).  The two blocks of a CU drift into
+// wave priority of the staging phases (DMA issue, conversion, stage 1, epilogue) against the per-pixel arithmetic (priority 0).  The blocks of a CU (two then, three now) drift into
 // step (both stage, then both compute); with the short staging phases preferred a block gets through them while the other one computes: 1174 -> 1146 us per launch
 // (priorities 1, 2, 3 measured alike; 0 = off)
 #ifndef SFA_PRIO_STAGE
@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
     // its column taps as aligned 16-byte rows (they were 2 x 8 bytes at half the LDS rate on planes shifted by two columns)
     constexpr int AW1 = DT_W;
     constexpr int NM = TR * DT_W, N1 = AT_R1 * AW1;
-    // terms are staged two at a time (one exposed global-load latency and one barrier less per pair)
+    // kAsmPair: terms are staged two at a time (one exposed global-load latency and one barrier less per pair); default: one term per round (three blocks per CU)
     constexpr int ZOFF = kAsmPair ? 6 * NM : 3 * NM, XOFF = 2 * ZOFF;           // start of the Iz planes, of the Ix planes
     __shared__ __attribute__((aligned(16))) float lds[XOFF + 6 * N1];
     float(*sM2)[NM] = reinterpret_cast<float(*)[NM]>(lds);                      // [2 terms][3 ch] M  = (I1+I2)/2, halo 4 (rows x DT_W)
@@ -1430,7 +1430,7 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             } else if (y_in) {
                 // All 69 taps of the pixel (per channel: a row and a column of Ix and of Iz, a column of Iy) are READ first and the filters run behind a scheduling
                 // fence.  Left to itself the compiler read two taps, waited, used them, read the next two (82 LDS instructions per term, nearly each with a wait
-                // of its own, in a kernel with 4 waves per SIMD): the per-pixel phase was 36 % of a wave's life, and most of that LDS latency (round-4 phase stamps).
+                // of its own, in a kernel with then 4 waves per SIMD): the per-pixel phase was 36 % of a wave's life, and most of that LDS latency (round-4 phase stamps).
                 // Two channels' taps in flight at most (all three at once: 69 registers of taps, spills at this kernel's 128).
                 float xr[3][5], xc[3][4], yc[3][5], zr[3][5], zc[3][4];
                 auto read_taps = [&](int ch) {
@@ -1589,7 +1589,7 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
         if (xcd) hipLaunchKernelGGL((k_assemble_images<kAsmTY, kAsmNT, kAsmMinWaves, ZUV_, FAST_, true>), grid1_, dim3(kAsmNT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
         else hipLaunchKernelGGL((k_assemble_images<kAsmTY, kAsmNT, kAsmMinWaves, ZUV_, FAST_, false>), grid_, dim3(kAsmNT), 0, c->stream, a, base, a11, a12, a22, b1, b2, du, dv, uu, vv, sh, sv, occ, g, xt); \
     } while (0)
-    // 64 x 8 tiles, 512 threads, 128 VGPRs (two blocks per CU).  Measured and dropped: 64 x 16 with two pixels per thread (209 VGPRs, one block per CU: slower),
+    // 64 x 8 tiles, 512 threads, <= 80 VGPRs and 48 KB of LDS (three blocks per CU; rounds 2 - mid-4: 128 VGPRs, 76 KB, two blocks).  Measured and dropped: 64 x 12 on 768 threads, 64 x 16 with two pixels per thread (209 VGPRs, one block per CU: slower),
     // 8 x 256 threads, 16 x 1024 threads (spills at its 128-register cap)
     if (a.zero_duv) { if (fast == 1) SFA_LAUNCH_AI(true, 1); else if (fast == 2) SFA_LAUNCH_AI(true, 2); else SFA_LAUNCH_AI(true, 0); }
     else            { if (fast == 1) SFA_LAUNCH_AI(false, 1); else if (fast == 2) SFA_LAUNCH_AI(false, 2); else SFA_LAUNCH_AI(false, 0); }
