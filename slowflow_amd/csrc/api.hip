@@ -88,7 +88,9 @@ struct Level {
     float *plane(int i) const { return i < 2 ? pbase + (long)i * pl : base + (long)(i - 2) * pl; }
     float *mask(int s) const { return base + off_masks + (long)s * pl; }
     float *stack(int s, int toref) const { return base + off_stacks + ((long)s * 2 + toref) * 24 * pl; }
-    float *warp(int s, int sp1) const { return base + off_warp + ((long)s * 2 + sp1) * 3 * pl; }
+    // frame s + sp1 warped by (s + sp1 - ref) flow steps.  Slot s's second image IS slot s + 1's first one (the same frame, the same number of steps): the reference
+    // warps it once per slot (variational_mt.cpp:100,109); here the two slots read one buffer (S = 3: four warps per get_derivatives instead of six)
+    float *warp(int s, int sp1) const { return base + off_warp + (long)(s + sp1) * 3 * pl; }
     float *frame(int f) const { return pbase + 2 * pl + (long)f * 3 * pl; }
     float *tmp() const { return base + off_tmp; }
     Geo geo(unsigned long long active = ~0ull) const { return Geo{w, h, pitch, pl, es, nb, active, nullptr}; }
@@ -118,10 +120,12 @@ static bool get_derivatives(sfa_ctx *c, const Level &L, const sfa_params &p, con
     const int ref = L.ref;
     WarpJobs J;
     J.n = 0;
-    for (int s = p.one_direction ? ref : 0; s < 2 * ref; s++) {
-        // the warp that also yields the slot's mask: w_s backwards (:100), w_sp1 forwards (:109); a zero-step warp is a copy (:723-728)
-        if (s - ref != 0) J.job[J.n++] = WarpJob{L.frame(s) - L.base, L.warp(s, 0) - L.base, s < ref ? L.mask(s) - L.base : -1L, s - ref};
-        if (s - ref + 1 != 0) J.job[J.n++] = WarpJob{L.frame(s + 1) - L.base, L.warp(s, 1) - L.base, s < ref ? -1L : L.mask(s) - L.base, s - ref + 1};
+    // one warp per frame f != ref, by f - ref steps: it is w_s of slot f (:100) and w_sp1 of slot f - 1 (:109) -- the same frame by the same steps -- and yields the mask
+    // of the slot on its own side of the reference frame: slot f backwards (f < ref), slot f - 1 forwards (f > ref); a zero-step warp is a copy (:723-728): never made
+    for (int f = p.one_direction ? ref + 1 : 0; f <= 2 * ref; f++) {
+        if (f == ref) continue;
+        const int s = f < ref ? f : f - 1;                       // the slot whose mask this warp yields; L.warp(f, 0) == L.warp(f - 1, 1)
+        J.job[J.n++] = WarpJob{L.frame(f) - L.base, L.warp(f < ref ? f : f - 1, f < ref ? 0 : 1) - L.base, L.mask(s) - L.base, f - ref};
     }
     const bool smoothed = with_smoothness && L.fused &&
                           launch_warp_smooth(c, g, J, L.base, L.plane(P_WX), L.plane(P_WY), p.smoothing, L.plane(P_SH), L.plane(P_SV), L.plane(P_DPSIS), p.alpha, pen(p.robust_reg));
