@@ -96,15 +96,15 @@ struct Level {
     Geo geo(unsigned long long active = ~0ull) const { return Geo{w, h, pitch, pl, es, nb, active, nullptr}; }
     static long persistent_floats(int pitch, int h, int ref) { return (long)pitch * h * (2 + (2L * ref + 1) * 3); }
     static long transient_floats(int pitch, int h, int ref, bool fused) {
-        return (long)pitch * h * ((P_COUNT - 2) + 2 * ref + 2L * ref * 6 + (fused ? 0 : 2L * ref * 2 * 24));
+        return (long)pitch * h * ((P_COUNT - 2) + 2 * ref + (2L * ref + 1) * 3 + (fused ? 0 : 2L * ref * 2 * 24));     // masks, one warped image per frame (the reference frame's slot stays empty), stacks
     }
     void layout(float *transient, float *persistent, int w_, int h_, int lstride_, int ref_, int nb_, long es_, bool fused_) {
         base = transient; pbase = persistent; w = w_; h = h_; pitch = dev_pitch(w_); lstride = lstride_; ref = ref_; F = 2 * ref_ + 1; nb = nb_; es = es_; fused = fused_;
         pl = (long)pitch * h;
         off_masks = (long)(P_COUNT - 2) * pl;
         off_warp = off_masks + 2L * ref * pl;
-        off_stacks = off_warp + 2L * ref * 6 * pl;
-        off_tmp = off_warp;                                  // 6 PL inside the 12 ref PL of the warped images (ref >= 1)
+        off_stacks = off_warp + (2L * ref + 1) * 3 * pl;
+        off_tmp = off_warp;                                  // 6 PL inside the (2 ref + 1) * 3 >= 9 PL of the warped images (ref >= 1)
     }
 };
 
