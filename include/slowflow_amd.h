@@ -232,6 +232,15 @@ int  sfa_sor_batch_download(sfa_sor_batch *sb, int b, float *du, float *dv, int 
  * A context that has returned SFA_ERR_TIMEOUT stays usable: progress words, tickets and the error word are reset by the next launch. */
 int  sfa_ctx_set_wait_bound(sfa_ctx *ctx, unsigned spins);
 
+/* ---- test / tooling hooks: the library's cross-check and what-if paths ------------------------------------------------------------
+ * sfa_debug_set: one switch ("SFA_UNFUSED", "SFA_SOR_CHAIN", ... -- the names tools/README.md lists); value NULL = back to the default.  The library reads
+ * these names from the ENVIRONMENT only when SFA_DEBUG=1 is set at the first sfa_ctx_create of the process: a drop-in caller's environment cannot otherwise
+ * select other kernels.  Process-wide; not to be called while a refinement runs.
+ * sfa_ctx_set_verbose: the reference's "inner it / outer it ... avg change" lines (variational_mt.cpp:404-405, 431-432) on stdout for this context; costs a
+ * host round trip per iteration. */
+int  sfa_debug_set(const char *name, const char *value);
+int  sfa_ctx_set_verbose(sfa_ctx *ctx, int on);
+
 /* ---- test hook: the division of the normalised data terms --------------------------------------------------------------------
  * The cfg-default instance of the fused assembly kernel forms the quotients r^2 / n and t / n of variational_aux_mt.cpp:240-250, 333-347, 479-490, 556-572
  * with the hardware's correctly-rounded chain and ONE refined reciprocal per denominator, behind range guards (kernels.hip: recip_of / div_by / num_ok).

@@ -200,6 +200,16 @@ class Oracle:
         self.lib.orc_normalize_publish(avg, std, af, sf)
         return list(avg), list(std), list(af), list(sf)
 
+    def change_log(self, cap=0):
+        """start (cap > 0) or stop (cap = 0) recording the values of the reference's per-iteration "avg change" lines; returns the buffer, rows (kind, it, a, b)"""
+        self._log = np.zeros((max(cap, 1), 4), np.float32)
+        self.lib.orc_set_change_log.argtypes = [C.c_void_p, C.c_int]
+        self.lib.orc_set_change_log(self._log.ctypes.data if cap > 0 else None, cap)
+        return self._log
+
+    def change_log_rows(self):
+        return self._log[:self.lib.orc_change_log_count()]
+
     def compute_one_level(self, p, wx, wy, frames, w, chw=None, want_occ=False):
         h, stride = wx.shape
         F = len(frames)

@@ -926,6 +926,16 @@ void orc_mask_weight(float *masks, const float *occ, int ref, float data_norm, i
         }
 }
 
+/* the values of the reference's "inner it i avg change a,b" / "outer it i avg change a,b" lines (variational_mt.cpp:404-405, 431-432), recorded instead of
+ * printed: entries of 4 floats (0 = inner / 1 = outer, iteration, a, b) into a caller's buffer (test infrastructure for the library's verbose lines) */
+static float *g_change_log = 0;
+static int g_change_cap = 0, g_change_n = 0;
+void orc_set_change_log(float *buf, int cap_entries) { g_change_log = buf; g_change_cap = buf ? cap_entries : 0; g_change_n = 0; }
+int orc_change_log_count(void) { return g_change_n; }
+static void log_change(int kind, int it, float a, float b) {
+    if (g_change_log && g_change_n < g_change_cap) { float *e = g_change_log + 4 * g_change_n++; e[0] = (float)kind; e[1] = (float)it; e[2] = a; e[3] = b; }
+}
+
 int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *const *frames,
                           const float *const chw[3], float *occ_out, int w, int h, int stride, float change[2]) {
     const int ref = p->S - 1;
@@ -1053,7 +1063,8 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
                 }
                 avg_du /= (h * w);
                 avg_dv /= (h * w);
-                if ((avg_du > avg_dv ? avg_du : avg_dv) < p->thres_inner) break;   /* :407 */
+                log_change(0, inner, avg_du, avg_dv);                           /* :404-405 */
+                if ((avg_du < avg_dv ? avg_dv : avg_du) < p->thres_inner) break;   /* :407 std::max(a, b) = (a < b) ? b : a: a NaN first argument stays */
             }
             if (rc) break;
             float avg_wx = 0, avg_wy = 0;                                       /* :412-425 */
@@ -1071,13 +1082,14 @@ int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *cons
                 }
             avg_wx /= (h * w);
             avg_wy /= (h * w);
+            log_change(1, outer, avg_wx, avg_wy);                               /* :431-432 */
             for (int y = 0; y < h; y++)
                 for (int x = 0; x < w; x++) {
                     wx[(size_t)y * stride + x] = uu[(size_t)y * stride + x];    /* :428-429 */
                     wy[(size_t)y * stride + x] = vv[(size_t)y * stride + x];
                 }
             chg_x = avg_wx; chg_y = avg_wy;
-            if ((avg_wx > avg_wy ? avg_wx : avg_wy) < p->thres_outer) break;    /* :436 */
+            if ((avg_wx < avg_wy ? avg_wy : avg_wx) < p->thres_outer) break;    /* :436 std::max, as above */
         }
     }
     if (change) { change[0] = chg_x; change[1] = chg_y; }

@@ -155,6 +155,9 @@ void orc_mask_weight(float *masks, const float *occ, int ref, float data_norm, i
 
 /* variational_mt.cpp:169-493.  frames: 2*ref+1 colour images of this level; wx,wy in/out;
  * chw[3]: channel weight planes; occ: out occlusion plane (h*stride) or NULL; change[2] out */
+/* records the values of the reference's per-iteration "avg change" lines of the next orc_compute_one_level calls: entries of 4 floats (0 inner / 1 outer, iteration, a, b) */
+void orc_set_change_log(float *buf, int cap_entries);
+int orc_change_log_count(void);
 int orc_compute_one_level(const orc_params *p, float *wx, float *wy, float *const *frames,
                           const float *const chw[3], float *occ, int w, int h, int stride, float change[2]);
 

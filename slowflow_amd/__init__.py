@@ -70,7 +70,7 @@ EXPORTS = [
     "sfa_sequence_create", "sfa_sequence_destroy", "sfa_sequence_upload", "sfa_sequence_download", "sfa_sequence_normalize",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_upload_resident", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters", "sfa_job_device_bytes",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
-    "sfa_division_chain", "sfa_ctx_set_wait_bound", "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
+    "sfa_division_chain", "sfa_ctx_set_wait_bound", "sfa_debug_set", "sfa_ctx_set_verbose", "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
 ]
 
 _lib = None
@@ -117,6 +117,33 @@ def default_params():
     p = Params()
     lib().sfa_params_default(C.byref(p))
     return p
+
+
+def debug_set(name, value=None):
+    """test / tooling hook (include/slowflow_amd.h: sfa_debug_set): one switch of the library's cross-check and what-if paths, e.g. debug_set("SFA_UNFUSED", 1);
+    value None = back to the default.  The library itself reads these names from the environment only under SFA_DEBUG=1."""
+    L = lib()
+    L.sfa_debug_set.argtypes = [C.c_char_p, C.c_char_p]
+    rc = L.sfa_debug_set(name.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise SlowflowError("sfa_debug_set(%s): %s" % (name, L.sfa_last_error(None).decode()))
+
+
+class debug_switches:
+    """with debug_switches(SFA_UNFUSED=1, SFA_SOR_CHAIN=5): ... -- sets the switches and restores the defaults on exit"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            debug_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            debug_set(k, None)
+        return False
 
 
 def device_count():
@@ -299,6 +326,10 @@ class Context:
         name = C.create_string_buffer(160)
         self._ck(lib().sfa_profile_read_kernels(self.h, C.byref(n), C.byref(ms), C.byref(px), name, 160), "sfa_profile_read_kernels")
         return n.value, ms.value, px.value, name.value.decode()
+
+    def set_verbose(self, on=True):
+        """the reference's per-iteration "avg change" lines on stdout (variational_mt.cpp:404-405, 431-432)"""
+        self._ck(lib().sfa_ctx_set_verbose(self.h, int(bool(on))), "sfa_ctx_set_verbose")
 
     def set_wait_bound(self, spins):
         """test hook: bound of the solver's in-kernel waits in polls (0 = the default of 2^22); see include/slowflow_amd.h"""

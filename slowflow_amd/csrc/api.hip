@@ -15,6 +15,33 @@ namespace sfa {
 
 thread_local std::string g_thread_err;
 
+// ---- the process-wide switch record (sfa_internal.h) ----------------------------------------------------------------
+Switches g_switches;
+static const char *const kSwitchNames[Switches::N] = {
+    "SFA_SOR_CHAIN", "SFA_SOR_BAND", "SFA_SOR_F", "SFA_SOR_CH", "SFA_SOR_LEAD", "SFA_CHAIN_LDS", "SFA_RB_TILE", "SFA_WARP_ALLJ", "SFA_NO_WARP_SMOOTH",
+    "SFA_ASSEMBLE_GENERIC", "SFA_EXACT_DIV", "SFA_ASM_XCD", "SFA_NO_DIRECT_OPERANDS", "SFA_NO_UV_ALIAS", "SFA_DEBUG_ACTIVE", "SFA_UNFUSED", "SFA_SHARE_SOR",
+    "SFA_PYRAMID_UNFUSED", "SFA_CUT_DISCHARGE", "SFA_CUT_INNER", "SFA_CUT_SUPER", "SFA_CUT_TAIL_INNER", "SFA_CUT_PER", "SFA_CUT_TAIL_PER", "SFA_CUT_TAIL_SUPER",
+    "SFA_CUT_DEBUG", "SFA_CUT_NO_TAIL", "SFA_CUT_TAIL"};
+static int set_switch(const char *name, const char *value) {
+    for (int i = 0; i < Switches::N; i++)
+        if (!strcmp(name, kSwitchNames[i])) {
+            g_switches.given[i] = value != nullptr;
+            g_switches.value[i] = value ? atoi(value) : 0;
+            return SFA_OK;
+        }
+    return SFA_ERR_ARG;
+}
+// the environment is looked at ONCE per process and only behind SFA_DEBUG=1 (tools/ and the A/B scripts set it)
+static void switches_from_environment() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *d = getenv("SFA_DEBUG");
+        if (!d || atoi(d) == 0) return;
+        for (int i = 0; i < Switches::N; i++)
+            if (const char *e = getenv(kSwitchNames[i])) (void)set_switch(kSwitchNames[i], e);
+    });
+}
+
 int set_error(sfa_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -177,7 +204,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     // The reference's per-iteration lines (variational_mt.cpp:404-405, 431-432: "inner it i avg change a,b" / "outer it i avg change a,b" under verbosity(VER_CMD)).
     // Printing them needs the norms on the host after every iteration -- a synchronisation per iteration --, so it is off unless SFA_VERBOSE_CHANGES is set (the C++
     // class and the driver set it when the cfg's `verbose` asks for it).  Batches print one line per window that still iterates, in window order.
-    const bool verbose = getenv("SFA_VERBOSE_CHANGES") != nullptr;
+    const bool verbose = c->verbose_changes;
     auto print_changes = [&](const char *what, int it, unsigned long long who) {
         if (hipMemcpyAsync(c->h_red, c->d_red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
         const double n = (double)L.w * L.h;
@@ -201,7 +228,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     // uu = wx + du, vv = wy + dv (:396-397), and wx <- uu, wy <- vv at the end of every outer iteration (:428-429).  With ONE inner iteration and the fused update
     // (k_update_outer_x) the two pairs of planes always hold the same values when anybody reads them: smoothness and assembly then read wx, wy, and the update
     // writes 16 instead of 32 bytes per pixel.
-    const bool uv_alias = L.fused && p.sor_order != 1 && !getenv("SFA_NO_DIRECT_OPERANDS") && p.niter_inner == 1 && !getenv("SFA_NO_UV_ALIAS");
+    const bool uv_alias = L.fused && p.sor_order != 1 && !sw_given(Switches::NO_DIRECT_OPERANDS) && p.niter_inner == 1 && !sw_given(Switches::NO_UV_ALIAS) && !verbose;
     float *const UU = uv_alias ? L.plane(P_WX) : L.plane(P_UU), *const VV = uv_alias ? L.plane(P_WY) : L.plane(P_VV);
     if (!uv_alias) launch_copy_planes(c, g, L.plane(P_UU), L.plane(P_WX), 2, L.es, L.es);                     // :260-261 (wx,wy and uu,vv adjacent)
 
@@ -252,7 +279,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     // of kLag iterations ago (a superset -- windows only ever leave) to stop queueing once nothing iterates any more, so the GPU always has work queued
     // and at most kLag iterations of empty launches follow the last window's break.  One blocking read per level (the norms), not one per iteration.
     constexpr int kLag = kMaskLag, kRing = kMaskRing;
-    static const bool dbg = getenv("SFA_DEBUG_ACTIVE") != nullptr;
+    const bool dbg = sw_given(Switches::DEBUG_ACTIVE);
     g.amask = c->d_amask;
     SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double), c->stream));
     launch_set_mask(c, all);
@@ -280,7 +307,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             // Windows that already met a threshold stay in the lockstep launches as passengers: every kernel skips them (Geo::active and
             // Geo::amask; the solver's workgroups of a passenger return as soon as they have drawn their ticket).
             const bool red_black = p.sor_order == 1;           // labelled mode: works on the row-major planes, never on the diagonal-major operands
-            const bool direct_outer = L.fused && !red_black && !getenv("SFA_NO_DIRECT_OPERANDS");
+            const bool direct_outer = L.fused && !red_black && !sw_given(Switches::NO_DIRECT_OPERANDS);
             if (!direct_outer) launch_zero_planes(c, g, L.plane(P_DU), 2);                                   // :323-324 (du, dv adjacent)
             unsigned long long in_active = active, outer_done = 0;
             for (int inner = 0; inner < p.niter_inner; inner++) {
@@ -300,8 +327,8 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 aa.zero_duv = first_zero ? 1 : 0;
                 if (direct) SFA_TRY(sor_operand_target(c, sorws, gi, p.niter_solver, &aa.op));
                 if (L.fused)
-                    launch_assemble_images(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
-                                           L.plane(P_DV), UU, VV, L.plane(P_SH), L.plane(P_SV), L.plane(P_OCC));   // :293-365
+                    SFA_TRY(launch_assemble_images(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
+                                                   L.plane(P_DV), UU, VV, L.plane(P_SH), L.plane(P_SV), L.plane(P_OCC)));   // :293-365
                 else
                     launch_assemble(c, gi, aa, L.base, L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1), L.plane(P_B2), L.plane(P_DU),
                                     L.plane(P_DV), L.plane(P_UU), L.plane(P_VV), L.plane(P_SH), L.plane(P_SV));   // :336-365
@@ -314,8 +341,9 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                     SFA_TRY(sor_run(c, sorws, gi, L.plane(P_DU), L.plane(P_DV), L.plane(P_A11), L.plane(P_A12), L.plane(P_A22), L.plane(P_B1),
                                     L.plane(P_B2), L.plane(P_SH), L.plane(P_SV), p.niter_solver, p.sor_omega, false));   // :368
                 }
-                if (direct && inner + 1 == p.niter_inner) {
-                    // last inner iteration: nothing reads its inner norms or du/dv; the flow update and the outer update run as one pass
+                if (direct && inner + 1 == p.niter_inner && !verbose) {
+                    // last inner iteration: nothing reads its inner norms or du/dv; the flow update and the outer update run as one pass (with the per-iteration
+                    // lines on somebody does read the inner norms, :404-405: the two passes below)
                     launch_update_outer_x(c, gi, uv_alias ? nullptr : L.plane(P_UU), uv_alias ? nullptr : L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, red);   // :396-397 + :412-429
                     outer_done = in_active;
                 } else if (direct) {
@@ -452,6 +480,7 @@ int sfa_ctx_create(int device, sfa_ctx **out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return set_error(nullptr, SFA_ERR_NO_DEVICE, "no HIP device available: slowflow_amd has no CPU fallback");
     if (device < 0 || device >= n) return set_error(nullptr, SFA_ERR_ARG, "device %d out of range (%d devices)", device, n);
+    switches_from_environment();
     std::unique_ptr<sfa_ctx> c(new sfa_ctx());
     c->device = device;
     SFA_HIP(c.get(), hipSetDevice(device));
@@ -572,8 +601,20 @@ int sfa_profile_read(sfa_ctx *c, int *n, double *ms_total, double *bytes_total) 
     c->sor_bytes = 0;
     return SFA_OK;
 }
+int sfa_debug_set(const char *name, const char *value) {
+    if (!name) return set_error(nullptr, SFA_ERR_ARG, "sfa_debug_set: null name");
+    switches_from_environment();                    // so that a later first sfa_ctx_create cannot overwrite what is set here
+    if (set_switch(name, value) != SFA_OK) return set_error(nullptr, SFA_ERR_ARG, "sfa_debug_set: unknown switch '%s'", name);
+    return SFA_OK;
+}
+int sfa_ctx_set_verbose(sfa_ctx *c, int on) {
+    if (!c) return SFA_ERR_ARG;
+    c->verbose_changes = on != 0;
+    return SFA_OK;
+}
 int sfa_ctx_set_wait_bound(sfa_ctx *c, unsigned spins) {
     if (!c) return SFA_ERR_ARG;
+    SFA_HIP(c, hipSetDevice(c->device));
     SFA_HIP(c, hipMemcpyAsync(c->d_err + 1, &spins, sizeof spins, hipMemcpyHostToDevice, c->stream));
     SFA_HIP(c, hipStreamSynchronize(c->stream));
     return SFA_OK;
@@ -684,6 +725,7 @@ int sfa_sub_laplacian(sfa_ctx *ctx, float *dst, const float *src, const float *w
 
 int sfa_division_chain(sfa_ctx *ctx, const float *a, const float *b, float *q_chain, float *q_exact, unsigned char *admitted, size_t n) {
     CHECK_ARGS(ctx && a && b && q_chain && q_exact && admitted && n > 0, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
     DevMem da, db, dq, de, dm;
     SFA_TRY(da.alloc(ctx, n * 4)); SFA_TRY(db.alloc(ctx, n * 4)); SFA_TRY(dq.alloc(ctx, n * 4)); SFA_TRY(de.alloc(ctx, n * 4)); SFA_TRY(dm.alloc(ctx, n));
     SFA_HIP(ctx, hipMemcpyAsync(da.p, a, n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1061,7 +1103,7 @@ int sfa_job_create(sfa_ctx *ctx, const sfa_params *p, int w, int h, int batch, s
     j->ctx = ctx; j->p = *p; j->w = w; j->h = h; j->nb = batch; j->ref = p->S - 1; j->F = 2 * j->ref + 1;
     j->L = pyramid_sizes(w, h, p->layers, p->p_scale, j->ws, j->hs);
     CHECK_ARGS(j->L >= 1, "image too small for even one pyramid level");
-    { const char *e = getenv("SFA_UNFUSED"); j->fused = !(e && atoi(e)); }
+    j->fused = sw_int(Switches::UNFUSED, 0) == 0;
     j->level_off.resize(j->L);
     long off = 0;
     for (int l = 0; l < j->L; l++) {
@@ -1073,7 +1115,7 @@ int sfa_job_create(sfa_ctx *ctx, const sfa_params *p, int w, int h, int batch, s
     j->es = off;
     // the solver workspaces (40 bytes per entry of the diagonal-major planes) of all levels together are 3.5 x the finest one's: from 2 Mpx on, one
     // workspace is re-shaped level by level (a few memsets per level against hundreds of ms of refinement); below that every level keeps its own
-    j->share_sor = (double)w * h >= 2.0e6 || getenv("SFA_SHARE_SOR");
+    j->share_sor = (double)w * h >= 2.0e6 || sw_given(Switches::SHARE_SOR);
     j->host_stride0 = host_stride(w);
     SFA_TRY(j->arena.alloc(ctx, (size_t)batch * j->es * sizeof(float)));
     SFA_HIP(ctx, hipMemsetAsync(j->arena.p, 0, (size_t)batch * j->es * sizeof(float), ctx->stream));
@@ -1201,7 +1243,7 @@ int sfa_job_run(sfa_job *j) {
         Level Lp = j->level(l - 1), Lc = j->level(l);
         float *tmp = Lp.tmp();
         // all F frames (3 F consecutive planes per window) in one pass: :607 + :611 fused
-        if (!getenv("SFA_PYRAMID_UNFUSED") &&
+        if (!sw_given(Switches::PYRAMID_UNFUSED) &&
             launch_pyr_down(ctx, Lc.frame(0), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Lp.frame(0), Lp.w, Lp.h, Lp.pitch, Lp.pl, Lp.es, 3 * F, nb, taps, radius))
             continue;
         for (int f = 0; f < F; f++) {

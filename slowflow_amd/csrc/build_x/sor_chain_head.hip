@@ -144,16 +144,12 @@ struct ChainLds {
     // Depth: with barrier lockstep (stage w runs chunk I - LEAD - w in interval I, the IN wave writes the band-above entries of chunk c at interval c + AH = LEAD - 1 + c)
     // row r is last read -- stage NW - 1, sweep KG - 1, for its step r - NW + 2 KG - 2 -- in interval LEAD + NW - 1 + floor((r + 2 KG - 2 - NW) / 4)
     // = LEAD - 1 + floor((r + 3 NW + 2 KG - 2) / 4), and its slot is first rewritten (IN wave, row r + OPR) in interval LEAD - 1 + floor((r + OPR) / 4): strictly later for
-    // every r iff OPR >= 3 NW + 2 KG + 2.  OPRMIN = 3 (NW - 1) + 2 (KG - 1) + 9 is that bound + 2: two rows of margin, three where they fit (OPR10); the six-stage shapes
-    // of 15 sweeps (3,3,3,2,2,2) fit the 160 KB only with two.  tools/sim_sor_chain.py ring_hazards walks every (stage, sweep, step) against these intervals: the bound is
-    // tight at one step of read-ahead, and reading further ahead (chain_compute PF) only moves the last read earlier (tests/test_sor_chain_model.py).
+    // every r iff OPR >= 3 NW + 2 KG + 2 = 3 (NW - 1) + 2 (KG - 1) + 9.  One spare row where it fits (OPR10); the six-stage shapes of 15 sweeps (3,3,3,2,2,2) fit the
+    // 160 KB only at the minimum.
     static constexpr int OPW = 64 + S::KG - 1, OPROWB = OPW * 16, OPRMIN = 3 * (S::NW - 1) + 2 * (S::KG - 1) + 9;
     static constexpr int ops0 = (dummy0 + DUMMY + 15) & ~15;
     static constexpr bool OPR10 = ops0 + 2 * (OPRMIN + 1) * OPROWB + 32 <= 160 * 1024;
-#ifndef SFA_X_OPR_CUT      // timing experiment only (rows BELOW the derived minimum: a slot may be rewritten before its last read)
-#define SFA_X_OPR_CUT 0
-#endif
-    static constexpr int OPR = (OPR10 ? OPRMIN + 1 : OPRMIN) - SFA_X_OPR_CUT, OPPLANE = OPR * OPROWB;
+    static constexpr int OPR = OPR10 ? OPRMIN + 1 : OPRMIN, OPPLANE = OPR * OPROWB;
     static constexpr bool OPRING = SFA_CHAIN_OPRING && S::KG <= 16 && ops0 + 2 * OPPLANE + 32 <= 160 * 1024;
     static constexpr int ticket = ops0 + (OPRING ? 2 * OPPLANE : 0);
     static constexpr int total = ticket + 16;
@@ -182,12 +178,7 @@ __device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bott
     s = s + pk_mul_hi(SBzw, bottom);                                 // + vp * x_bottom
     s = s + SBxy;                                                    // + b
     const v2f B = __builtin_shufflevector(hlz, hlz, 0, 0) * left + s;
-    // (a12 B2, a22 B2) as two SCALAR products: written as `{SA.y * B.y, SA.z * B.y}` the vectoriser packs them into one v_pk_mul_f32 whose first operand, the
-    // pair (a12, a22), straddles two register pairs of the 16-byte operand and has to be composed by two v_mov_b32 first -- 8 issue cycles instead of 4 per point
-    float t2x, t2y;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(t2x) : "v"(SA.y), "v"(B.y));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(t2y) : "v"(SA.z), "v"(B.y));
-    const v2f t2 = {t2x, t2y};
+    const v2f t2 = {SA.y * B.y, SA.z * B.y};                         // (a12 B2, a22 B2): two scalar products instead of composing the pair (a12, a22)
     const v2f t = SAxy * __builtin_shufflevector(B, B, 0, 0) + t2;
     return self + omega * (t - self);
 }
@@ -199,10 +190,7 @@ __device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bott
 // leaves every row in the LDS ring when it uses it; ROLE 2 and the trailing sweeps of ROLE 1 read the ring, one step ahead of their use (kap0 = sweeps of
 // the group in front of this stage, w = the stage).  Measured first (a what-if build that read arbitrary LDS rows): the operand loads of the trailing sweeps,
 // not arithmetic or the hand-over between workgroups, were what a launch of several windows waited for -- 16 windows 942 -> 642 us.
-// PF: steps by which the ring-fed sweeps read their operand rows ahead of their use (register slots NSL).  One step ahead the 16-byte LDS reads are consumed
-// ~10 instructions after their issue and the wave stalls on them in every step -- with two waves per SIMD nobody covers that; two steps ahead they have a whole
-// step to land.  PF = 2 is safe where every stage has >= 2 sweeps (tools/sim_sor_chain.py ring_hazards: a 1-sweep stage would read a row before it is written).
-template <int F, int CH, int PD, bool SHORT = false, int ROLE = 0, int OPS0 = 0, int OPR = 1, int OPROWB = 0, int KG = 1, int PF = 1>
+template <int F, int CH, int PD, bool SHORT = false, int ROLE = 0, int OPS0 = 0, int OPR = 1, int OPROWB = 0, int KG = 1>
 __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char *lds, int ring_in, int ring_out, int tvb, int esb, int dummy, int job, int b,
                                               int k0, int s_start, int lead, int lane, int kap0 = 0, int w = 0) {
     constexpr int OPPLANE = OPR * OPROWB;
@@ -243,26 +231,17 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
     // a row, and the operands of the current and the next step
     unsigned wr_off = 0, rd_off[F];
     unsigned rd_lane[F];
-    constexpr int NSL = PF == 1 ? 2 : 4;                              // register slots per ring-fed sweep: a power of two that divides the unrolled body
-    static_assert(PF >= 1 && PF < NSL && (PD * CH) % NSL == 0 && CH % NSL == 0, "slot of a step = its position in the chunk");
-    float4 la[F][NSL], lb[F][NSL];
+    float4 la[F][2], lb[F][2];
 #pragma unroll
     for (int f = 0; f < F; f++) {
         const int kap = kap0 + f;
-        // the ring's base is part of the lane's address (and opaque: the compiler otherwise keeps it in the instruction's offset field, where base + plane do not
-        // fit 16 bits, and pays a second v_add_u32 per read pair)
         rd_lane[f] = (unsigned)(OPS0 + (KG - 1 + lane - kap) * 16);
-        if (OPPLANE < 65536) asm volatile("" : "+v"(rd_lane[f]));     // (then the second plane is the 16-bit offset of the same address)
         rd_off[f] = (unsigned)(((w - 2 * kap) % OPR + OPR) % OPR * OPROWB);      // the row of step 0: step w - 2 kappa of the first stage (not written yet: zeros)
-#pragma unroll
-        for (int q = 0; q < NSL; q++) la[f][q] = lb[f][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        la[f][0] = la[f][1] = lb[f][0] = lb[f][1] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ROLE != 0 && f >= F0) {
-#pragma unroll
-            for (int q = 0; q < PF; q++) {                                  // the rows of steps 0 .. PF - 1
-                la[f][q] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);
-                lb[f][q] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
-                rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
-            }
+            la[f][0] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);
+            lb[f][0] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
+            rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
         }
     }
     const unsigned wr_lane = (unsigned)(OPS0 + (KG - 1 + lane) * 16);
@@ -331,8 +310,8 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
                     const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
                     const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
                     const bool ringfed = ROLE != 0 && f >= F0;
-                    const float4 &SA = ringfed ? la[f][j % NSL] : f == 0 ? sa0[ROLE == 2 ? 0 : j0] : sa1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
-                    const float4 &SB = ringfed ? lb[f][j % NSL] : f == 0 ? sb0[ROLE == 2 ? 0 : j0] : sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
+                    const float4 &SA = ringfed ? la[f][j & 1] : f == 0 ? sa0[ROLE == 2 ? 0 : j0] : sa1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
+                    const float4 &SB = ringfed ? lb[f][j & 1] : f == 0 ? sb0[ROLE == 2 ? 0 : j0] : sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
                     const v2f xn = sor_point2(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hlz[f], SA, SB, omega);
                     nres[f] = make_float2(xn.x, xn.y);
                     selfv[f] = right;
@@ -357,9 +336,9 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
                 for (int f = 0; f < F; f++) {
                     const bool ringfed = ROLE != 0 && f >= F0;
                     if (ringfed) {
-                        hlz[f] = (v2f){lb[f][j % NSL].z, lb[f][j % NSL].w};
-                        la[f][(j + PF) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);              // the row of step + PF
-                        lb[f][(j + PF) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
+                        hlz[f] = (v2f){lb[f][j & 1].z, lb[f][j & 1].w};
+                        la[f][(j + 1) & 1] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);              // the next step's row
+                        lb[f][(j + 1) & 1] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
                         rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
                     } else if (f == 0) hlz[0] = (v2f){sb0[ROLE == 2 ? 0 : j0].z, sb0[ROLE == 2 ? 0 : j0].w};
                     else hlz[f] = (v2f){sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0].z, sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0].w};
@@ -832,14 +811,10 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
     const int ring_in = L::ring0 + w * L::RING, ring_out = ring_in + L::RING;
     const int tvb = L::tv0 + w * L::TVW, esb = L::es0 + w * L::ESW;
     constexpr bool SHORT = NW >= 8;                  // many waves per workgroup: fewer registers each
-#ifndef SFA_CHAIN_PF
-#define SFA_CHAIN_PF 2
-#endif
-    constexpr int PF = (FA >= 2 && (NB_ == 0 || FB >= 2) && !SHORT) ? SFA_CHAIN_PF : 1;      // read-ahead of the operand ring (chain_compute)
     if (L::OPRING) {
-        if (w == 0)      chain_compute<FA, CH, PD, SHORT, 1, L::ops0, L::OPR, L::OPROWB, S::KG, PF>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, 0, 0);
-        else if (w < NA) chain_compute<FA, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PF>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
-        else             chain_compute<FB, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PF>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
+        if (w == 0)      chain_compute<FA, CH, PD, SHORT, 1, L::ops0, L::OPR, L::OPROWB, S::KG>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, 0, 0);
+        else if (w < NA) chain_compute<FA, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
+        else             chain_compute<FB, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
     } else if (w < NA) chain_compute<FA, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
     else               chain_compute<FB, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
 }
@@ -928,7 +903,7 @@ static int chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
     using S = ChainShape<FA, NA, FB, NB_>;
     using L = ChainLds<S, kChainCH>;
     size_t lds = L::total;
-    lds = std::max(lds, (size_t)sw_int(Switches::CHAIN_LDS, 0));      // experiment: a larger request limits the workgroups per CU
+    if (const char *e = getenv("SFA_CHAIN_LDS")) lds = std::max(lds, (size_t)atoi(e));      // experiment: a larger request limits the workgroups per CU
     // more than 64 KB of dynamic LDS has to be allowed per function AND per device (the driver refines on several GPUs from one process, one thread each)
     // the bit of a device is set only once the call has succeeded there; devices beyond the 64 bits are asked every time (the call is cheap and idempotent)
     static std::atomic<unsigned long long> attr_set{0};

@@ -114,8 +114,7 @@ __global__ void k_warp_jobs(WarpJobs J, float *__restrict__ base, const float *_
 void launch_warp_jobs(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base, const float *wx, const float *wy) {
     if (J.n <= 0) return;
     // all jobs of a pixel in one thread (the flow is read once; 262 -> 250 us per 64-window launch) unless SFA_WARP_ALLJ=0 (one job per grid z, rounds 1-4)
-    const char *allj_e = getenv("SFA_WARP_ALLJ");
-    const bool allj = !allj_e || atoi(allj_e);
+    const bool allj = sw_int(Switches::WARP_ALLJ, 1) != 0;
     if (allj) hipLaunchKernelGGL(k_warp_jobs<true>, grid2d(g), block2d(), 0, c->stream, J, base, wx, wy, g);
     else hipLaunchKernelGGL(k_warp_jobs<false>, grid2d(g, J.n), block2d(), 0, c->stream, J, base, wx, wy, g);
 }
@@ -499,7 +498,7 @@ __global__ void __launch_bounds__(256) k_warp_smooth(WarpJobs J, float *__restri
 // false: not this combination (the caller then launches the two kernels)
 bool launch_warp_smooth(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base, const float *wx, const float *wy, int method, float *sh, float *sv,
                         const float *dpsis, float alpha, PenaltyDev reg) {
-    const bool off = getenv("SFA_NO_WARP_SMOOTH") != nullptr;      // (read per launch: the parity test switches it inside one process)
+    const bool off = sw_given(Switches::NO_WARP_SMOOTH);
     if (off || method > 1 || J.n <= 0) return false;
     hipLaunchKernelGGL(k_warp_smooth, dim3((g.pitch + SM_X - 1) / SM_X, (g.h + SM_Y - 1) / SM_Y, g.nb), dim3(64, 4), 0, c->stream, J, base, method, sh, sv, wx, wy,
                        dpsis, g, alpha, reg);
@@ -1069,15 +1068,19 @@ namespace sfa {
 // pass put an `s_waitcnt vmcnt(0)` INSIDE the issue loops (a register of the address arithmetic had a load pending), so every wave-instruction waited for the
 // one before it: one exposed memory round trip per piece, 30 % of the kernel's wave time (round-4 ISA reading).  The assembly form is invisible to that pass:
 // nothing waits until the explicit `dma_wait` below.  Untracked DMA is safe next to tracked loads: vmcnt retires in order, so a compiler-made wait for an older
-// load is unaffected and one for a younger load over-waits.  M0 is not used by anything else in the kernels that call this.
+// load is unaffected and one for a younger load over-waits.  M0 is in the clobber list: the compiler may use it itself (dynamic register indexing, its own LDS-DMA).
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p; }
+// (clang warns that M0 is a reserved register: it is -- never allocated --, and naming it is exactly the point: the statement redefines it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 // the same with a wave-uniform 64-bit base and a 32-bit byte offset per lane (no 64-bit address arithmetic in the vector unit)
 __device__ __forceinline__ void dma16s(const float *sbase, unsigned voff, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte) : "memory", "m0");
 }
 __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // TY rows x 64 columns per block of NT threads (NT/64 rows in flight, TY*64/NT pixels per thread).
 // Column borders: the staged planes carry REPLICATED columns outside the image, so the clamped taps of image.c:501-516
@@ -1555,17 +1558,17 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         for (int i = 0; i < 14; i++) atomicAdd(&g_asm_timing[i], at_acc[i]);
 #endif
 }
-void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
-                            const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
+int launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
+                           const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ) {
     AssembleArgs a = a_in;
     // the kernel addresses the three planes of an image set with a 32-bit byte offset (dma16s): 12 bytes x plane entries must fit (357 Mpx per plane)
-    if ((unsigned long long)g.pl * 12ull >= (1ull << 32)) { (void)set_error(c, SFA_ERR_ARG, "k_assemble_images: plane of %ld entries is beyond the kernel's 32-bit offsets", g.pl); return; }
+    if ((unsigned long long)g.pl * 12ull >= (1ull << 32)) return set_error(c, SFA_ERR_ARG, "k_assemble_images: plane of %ld entries is beyond the kernel's 32-bit offsets", g.pl);
     const bool prof = c->profile && c->ev2_used + 2 <= c->ev2.size();
     if (prof) (void)hipEventRecord(c->ev2[c->ev2_used], c->stream);
     // the cfg's defaults (slow_flow_dataterm 1, modified-L1 penalties -- every id select_robust_function maps to the default class,
     // variational_aux_mt.cpp:909-925 --, no channel weights) take the instance with those choices folded in
     auto is_modl1 = [](int id) { return id != 0 && id != 2 && id != 3 && id != 4; };
-    const bool foldable = a.dt_norm == 1 && !a.chw && !getenv("SFA_ASSEMBLE_GENERIC");
+    const bool foldable = a.dt_norm == 1 && !a.chw && !sw_given(Switches::ASSEMBLE_GENERIC);
     const int fast = !foldable ? 0 : (is_modl1(a.color.id) && is_modl1(a.grad.id)) ? 1 : (a.color.id == 2 && a.grad.id == 2) ? 2 : 0;
     {   // the shared-reciprocal divisions' precondition on the scalars (see recip_of / div_by): t = mask weight * hd (hg) * psi'(s) must be +0 or in [2^-87, 2^53).
         // modified L1: psi' = 1 / (2 sqrt(s + eps^2)) in (2^-33, 2^19] for eps in [2^-20, 2^20] and s < 2^63; Lorentzian: psi' = 1 / (2 eps^2 + s) in (2^-64, 2^19] for eps
@@ -1574,12 +1577,11 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
         const float elo = fast == 2 ? 1.0f / 1024 : 1.0f / 1048576, ehi = fast == 2 ? 1024.0f : 1048576.0f, hlo = fast == 2 ? 1.0f / 4096 : 1.0f / 65536;
         bool okp = fast != 0 && in(a.data_norm, 1.0f / 256, 256.0f) && in(a.color.eps, elo, ehi) && in(a.grad.eps, elo, ehi);
         for (int t = 0; t < a.n && okp; t++) okp = (a.t[t].hd == 0.0f || in(a.t[t].hd, hlo, 65536.0f)) && (a.t[t].hg == 0.0f || in(a.t[t].hg, hlo, 65536.0f));
-        a.chain_ok = okp && !getenv("SFA_EXACT_DIV") ? 1 : 0;
+        a.chain_ok = okp && !sw_given(Switches::EXACT_DIV) ? 1 : 0;
     }
     const dim3 grid_((g.w + DT_X - 1) / DT_X, (g.h + kAsmTY - 1) / kAsmTY, g.nb);
     // the XCD-contiguous tile order (see the kernel) from 8 workgroups per XCD on; SFA_ASM_XCD=0: the plain grid, for A/B measurements
-    const char *xcd_e = getenv("SFA_ASM_XCD");
-    const bool xcd_env = !xcd_e || atoi(xcd_e) != 0;
+    const bool xcd_env = sw_int(Switches::ASM_XCD, 1) != 0;
     const long ntiles = (long)grid_.x * grid_.y * grid_.z;
     const bool xcd = xcd_env && ntiles >= 64 && ntiles < (1l << 30);
     const XcdTiles xt{(int)grid_.x, (int)grid_.y, (int)((ntiles + 7) / 8)};
@@ -1599,6 +1601,7 @@ void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a_in, 
         c->ev2_used += 2;
         c->asm_pixel_terms += (double)g.w * g.h * g.nb * a.n;
     }
+    return SFA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

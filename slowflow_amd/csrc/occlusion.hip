@@ -699,17 +699,17 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
         return set_error(c, SFA_ERR_TIMEOUT, "grid cut: breadth-first relabelling did not settle");   // unreachable: distances are < w*h
     };
     // ---- tile discharge (the default; SFA_CUT_DISCHARGE=0: the grid rounds below, kept as the cross-check) ----
-    const bool discharge = !getenv("SFA_CUT_DISCHARGE") || atoi(getenv("SFA_CUT_DISCHARGE")) != 0;
+    const bool discharge = sw_int(Switches::CUT_DISCHARGE, 1) != 0;
     if (discharge) {
         const int tiles_x = (int)bfs_grid.x, tiles_y = (int)bfs_grid.y;
         int *act = T.idle, *fixed = T.idle_next;                  // the grid rounds' bookkeeping is not in use: [nb][tiles_y][tiles_x] flags each
         const unsigned few_tiles = std::max(8u, (unsigned)(tiles_x * tiles_y * g.nb) / 64);     // active tiles up to which a batch is a tail batch
         const dim3 dgrid((tiles_x + 1) / 2, (tiles_y + 1) / 2, g.nb);
-        const int kInner = getenv("SFA_CUT_INNER") ? atoi(getenv("SFA_CUT_INNER")) : 16;      // rounds a tile runs per local relabelling, at most
-        const int kSuper = getenv("SFA_CUT_SUPER") ? atoi(getenv("SFA_CUT_SUPER")) : 2;       // visits of every colour between two relabellings
-        const int kTailInner = getenv("SFA_CUT_TAIL_INNER") ? atoi(getenv("SFA_CUT_TAIL_INNER")) : 32;   // the same once few tiles are active
-        const int kPer = getenv("SFA_CUT_PER") ? atoi(getenv("SFA_CUT_PER")) : 2, kTailPer = getenv("SFA_CUT_TAIL_PER") ? atoi(getenv("SFA_CUT_TAIL_PER")) : 1;   // rows per thread
-        const int kTailSuper = getenv("SFA_CUT_TAIL_SUPER") ? atoi(getenv("SFA_CUT_TAIL_SUPER")) : 4;
+        const int kInner = sw_int(Switches::CUT_INNER, 16);      // rounds a tile runs per local relabelling, at most
+        const int kSuper = sw_int(Switches::CUT_SUPER, 2);       // visits of every colour between two relabellings
+        const int kTailInner = sw_int(Switches::CUT_TAIL_INNER, 32);   // the same once few tiles are active
+        const int kPer = sw_int(Switches::CUT_PER, 2), kTailPer = sw_int(Switches::CUT_TAIL_PER, 1);   // rows per thread
+        const int kTailSuper = sw_int(Switches::CUT_TAIL_SUPER, 4);
         // exact distances, then which tiles hold active nodes; flags[1]: any at all
         auto relabel_and_mark = [&]() -> int {
             hipLaunchKernelGGL(k_cut_bfs_init_tiles, bfs_grid, block, 0, c->stream, P, T.dirty, fixed, gc);
@@ -725,7 +725,7 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
                 SFA_HIP(c, hipMemcpyAsync(h_flag, flags, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
                 SFA_HIP(c, hipStreamSynchronize(c->stream));
                 if (!h_flag[2 + kSweeps - 1]) {
-                    if (getenv("SFA_CUT_DEBUG")) {
+                    if (sw_given(Switches::CUT_DEBUG)) {
                         std::vector<int> ha((size_t)tiles_x * tiles_y * g.nb);
                         (void)hipMemcpy(ha.data(), act, ha.size() * sizeof(int), hipMemcpyDeviceToHost);
                         long na = 0;
@@ -770,7 +770,7 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
     const size_t tail_lds = (((size_t)2 * tiles_w + 15) & ~(size_t)15) + (size_t)4 * tiles_w;
     // worth it only when a grid launch is mostly block scheduling (many windows); a single window's grid is a few thousand blocks.
     // SFA_CUT_NO_TAIL / SFA_CUT_TAIL force one way (cross-check in the tests)
-    const bool tail_fits = tail_lds <= 150 * 1024 && !getenv("SFA_CUT_NO_TAIL") && (ntiles >= 6000 || getenv("SFA_CUT_TAIL"));
+    const bool tail_fits = tail_lds <= 150 * 1024 && !sw_given(Switches::CUT_NO_TAIL) && (ntiles >= 6000 || sw_given(Switches::CUT_TAIL));
     bool done = false;
     int batches = 0;
     for (int round = 0; round < max_rounds && !done;) {

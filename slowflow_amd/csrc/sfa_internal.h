@@ -52,6 +52,8 @@ struct sfa_ctx {
     void *rb_tmp = nullptr;       // labelled red-black mode: scratch (du, dv) pair the tile visits ping-pong with, grown on demand
     size_t rb_tmp_bytes = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    // the reference's per-iteration "avg change" lines (variational_mt.cpp:404-405, 431-432): sfa_ctx_set_verbose; costs a host round trip per iteration
+    bool verbose_changes = false;
     // default-ctx bookkeeping
     int cu_count = 256;
 };
@@ -62,6 +64,24 @@ constexpr int kRedDoubles = 1 << 18;   // 2*kMaxBatch result words + per-block p
 
 int set_error(sfa_ctx *ctx, int code, const char *fmt, ...);
 extern thread_local std::string g_thread_err;
+
+// ---------------------------------------------------------------------------------------------------
+// Cross-check and what-if paths of the library (the unfused pipeline, other solver shapes, the cut's knobs ...).  ONE record per process, filled once: from the
+// environment ONLY when SFA_DEBUG=1 is set at the first sfa_ctx_create -- without it no variable of a caller's environment can change which kernels the drop-in
+// library runs --, afterwards only through the test hook sfa_debug_set() (include/slowflow_amd.h).  api.hip holds the table of names.
+// ---------------------------------------------------------------------------------------------------
+struct Switches {
+    enum Id {
+        SOR_CHAIN, SOR_BAND, SOR_F, SOR_CH, SOR_LEAD, CHAIN_LDS, RB_TILE, WARP_ALLJ, NO_WARP_SMOOTH, ASSEMBLE_GENERIC, EXACT_DIV, ASM_XCD, NO_DIRECT_OPERANDS,
+        NO_UV_ALIAS, DEBUG_ACTIVE, UNFUSED, SHARE_SOR, PYRAMID_UNFUSED, CUT_DISCHARGE, CUT_INNER, CUT_SUPER, CUT_TAIL_INNER, CUT_PER, CUT_TAIL_PER, CUT_TAIL_SUPER,
+        CUT_DEBUG, CUT_NO_TAIL, CUT_TAIL, N
+    };
+    bool given[N] = {};
+    int value[N] = {};
+};
+extern Switches g_switches;
+inline bool sw_given(Switches::Id i) { return g_switches.given[i]; }                                   // what `getenv(name) != nullptr` used to say
+inline int sw_int(Switches::Id i, int dflt) { return g_switches.given[i] ? g_switches.value[i] : dflt; }   // `getenv(name) ? atoi(getenv(name)) : dflt`
 
 #define SFA_HIP(ctx, call)                                                                         \
     do {                                                                                           \
@@ -163,7 +183,7 @@ void launch_assemble(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const floa
 
 // The same system from the warped image pairs directly: derivative stacks formed in LDS tiles, never stored
 // (get_derivatives' 8 filters + :293-320 mask weights + :336-365 in one pass).  occ: occlusion plane.
-void launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
+int launch_assemble_images(sfa_ctx *c, const Geo &g, const AssembleArgs &a, const float *base, float *a11, float *a12, float *a22, float *b1, float *b2,
                             const float *du, const float *dv, const float *uu, const float *vv, const float *sh, const float *sv, const float *occ);
 
 // two-frame refinement (variational.c / variational_aux.c)

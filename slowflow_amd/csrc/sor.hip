@@ -898,7 +898,7 @@ int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float
     hipLaunchKernelGGL(k_rb_invert, dim3((g.w + 63) / 64, (g.h + 3) / 4, g.nb), blk, 0, c->stream, a11, a12, a22, sh, sv, g);
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
     if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
-    static const int mode = getenv("SFA_RB_TILE") ? atoi(getenv("SFA_RB_TILE")) : 5;      // sweeps per tile visit (3 or 5); 0: one launch per colour pass (the round-2 form)
+    const int mode = sw_int(Switches::RB_TILE, 5);      // sweeps per tile visit (3 or 5); 0: one launch per colour pass (the round-2 form)
     if (mode == 0) {
         const dim3 grid((g.w + 127) / 128, (g.h + 3) / 4, g.nb);
         for (int k = 0; k < K; k++)
@@ -957,8 +957,8 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
 // which chain shape (sor_chain.hip: kChainShapes) solves nb systems of K sweeps; 0 = the band / task kernels below
 static int chain_choice(int K, int nb, int NBands) {
     int id = 0;
-    if (const char *e = getenv("SFA_SOR_CHAIN")) id = atoi(e);
-    else if (getenv("SFA_SOR_BAND") || getenv("SFA_SOR_F")) id = 0;          // an explicit choice of the other kernels
+    if (sw_given(Switches::SOR_CHAIN)) id = sw_int(Switches::SOR_CHAIN, 0);
+    else if (sw_given(Switches::SOR_BAND) || sw_given(Switches::SOR_F)) id = 0;          // an explicit choice of the other kernels
     else {
         // default: by the number of bands in the launch.  Measured at 1024x436, K = 30 (8 bands per window), us per launch, with the operand ring
         // (sor_chain.hip): shape 6 (5 stages of 1 sweep) / 5 (5 x 2) / 3 (5 x 3) / the band kernel --
@@ -986,7 +986,7 @@ static int band_shape(int K, int nb) {
     // spread over K CUs (shorter critical path); SFA_SOR_BAND = 0 (never) / 1..3 (always, that many fused sweeps)
     int F = nb >= 8 ? 43 : 0;                                // round 2: 8 stages of 4,4,4,4,4,4,3,3 sweeps (two waves and 8,8,7,7 sweeps per SIMD) for K = 30, else the 6-stage shape
                                                              // (5 sweeps per wave), which with buffer addressing beats the 10-stage one by 5-7 %
-    if (const char *e = getenv("SFA_SOR_BAND")) F = atoi(e);
+    F = sw_int(Switches::SOR_BAND, F);
     if (F == 43) { if (K == 30) return 43; F = 5; }           // 6 x 4 + 2 x 3 sweeps: K = 30 only; otherwise the uniform shapes
     if (F <= 0 || F > 6 || F == 4) return 0;
     auto fits = [&](int f) { return f >= 1 && K % f == 0 && K / f <= (f == 6 ? 5 : f == 5 ? 6 : f == 3 ? 10 : 16); };
@@ -1029,8 +1029,8 @@ static void sor_shape(int K, int nwaves1, int &F, int &CHK) {
     // few waves (a single solve): the pipeline is latency bound, one iteration per wave is the shortest critical path;
     // many waves (batches): HBM bound, fusing two iterations halves the operand and x traffic
     F = nwaves1 >= 900 ? 2 : 1; CHK = F == 1 ? 16 : 8;       // a lone solve: long chunks, short start lag (SorWave::LAG / PUB)
-    if (const char *e = getenv("SFA_SOR_F")) F = atoi(e);
-    if (const char *e = getenv("SFA_SOR_CH")) CHK = atoi(e);
+    F = sw_int(Switches::SOR_F, F);
+    CHK = sw_int(Switches::SOR_CH, CHK);
     if (!((F == 1 && (CHK == 8 || CHK == 16)) || (F == 2 && (CHK == 8 || CHK == 4)) || (F == 3 && CHK == 4))) { F = 2; CHK = 8; }
     if (K % F != 0) { F = 1; CHK = 16; }                     // the fused kernel carries exactly F iterations per group
 }
@@ -1174,7 +1174,7 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         ba.sa = p.sa; ba.sb = p.sb; ba.x = p.x; ba.edge = (unsigned long long *)ws.edge.p; ba.gflags = p.flags; ba.err = c->d_err;
         ba.ent = ws.ent; ba.edge_job = ws.edge_job; ba.W = g.w; ba.H = g.h; ba.K = K; ba.NB = ws.NB; ba.NW = ws.NG; ba.RP = ws.RP; ba.G = ws.G;
         ba.lead = band_ring(ws.F);
-        if (const char *e = getenv("SFA_SOR_LEAD")) ba.lead = std::max(band_ch(ws.F) + 2, std::min(atoi(e), band_ring(ws.F)));
+        if (sw_given(Switches::SOR_LEAD)) ba.lead = std::max(band_ch(ws.F) + 2, std::min(sw_int(Switches::SOR_LEAD, 0), band_ring(ws.F)));
         ba.NS = ws.NS; ba.NCH = ws.NCH; ba.nb = g.nb; ba.Wp = ws.Wp; ba.EP = ws.EP; ba.omega = omega; ba.active = g.active; ba.amask = g.amask;
         const dim3 bgrid(g.nb * ws.NB), bblock(ws.NG * 64);
         const size_t tvb = (ws.F + 1) * band_ch(ws.F) <= 64 ? (size_t)(ws.F + 1) * band_ch(ws.F) * 8 : 0;            // lane-0 values, one chunk per wave

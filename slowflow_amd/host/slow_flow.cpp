@@ -161,7 +161,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     };
     // ---- deep_matching 1 (:744-863): the flow is initialised by EpicFlow's interpolation (epic.h) of DeepMatching matches along SED edges.  The reference starts
     //      both tools with system() (MATLAB + a binary, third-party); this build reads their outputs from the reference's own locations and says so if they are missing.
-    if (params.verbosity(VER_CMD)) setenv("SFA_VERBOSE_CHANGES", "1", 1);       // the library prints the reference's "inner it / outer it ... avg change" lines (variational_mt.cpp:404-405, 431-432)
+    const bool verbose_changes = params.verbosity(VER_CMD);       // the library prints the reference's "inner it / outer it ... avg change" lines (variational_mt.cpp:404-405, 431-432): per worker context
     const bool enable_dm = params.parameter<bool>("deep_matching");
     auto edges_file = [&](int frame_number) { return params.output + "tmp/edges_" + std::to_string(frame_number) + ".dat"; };                    // :740-741
     auto matches_file = [&](int a, int b) { return params.output + "tmp/matches_" + std::to_string(a) + "_" + std::to_string(b) + ".dat"; };    // :742-743
@@ -460,6 +460,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         if (sfa_ctx_create(device, &ctx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; return; }
         sfa_ctx *ectx = nullptr;                                                     // the EpicFlow helper's context (deep_matching 1 only)
         if (enable_dm && sfa_ctx_create(device, &ectx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; sfa_ctx_destroy(ctx); return; }
+        (void)sfa_ctx_set_verbose(ctx, verbose_changes ? 1 : 0);
         ParameterList tp(params);                                                    // one copy per thread (:708)
         // EpicFlow's interpolation of the matches of one window (:801-863 / :960-1004), per single frame step.  It runs on a helper thread with a context of its
         // own (the library's contexts are thread-compatible, not thread-safe), one batch ahead of the refinement: while the GPU refines batch n the host prepares

@@ -131,7 +131,7 @@ Point2f Variational_MT::variational(image_t *wx, image_t *wy, color_image_t *con
     if (rc == SFA_OK && occ_files) rc = sfa_job_keep_alternation_occlusions(job, 1);
     if (rc == SFA_OK) rc = sfa_job_upload(job, 0, frames.data(), F, wx->data, wy->data, wx->stride, channel_w ? chw : nullptr);
     // the per-iteration "avg change" lines of variational_mt.cpp:404-405, 431-432 are printed by the library when asked to (a host round trip per iteration)
-    if (params.verbosity(VER_CMD)) setenv("SFA_VERBOSE_CHANGES", "1", 1);
+    (void)sfa_ctx_set_verbose(ctx, params.verbosity(VER_CMD) ? 1 : 0);
     if (rc == SFA_OK) rc = sfa_job_run(job);
     if (rc == SFA_OK) rc = sfa_job_download(job, 0, wx->data, wy->data, wx->stride, change);
     if (rc == SFA_OK) rc = sfa_job_download_occlusions(job, 0, occlusions->data, occlusions->stride);

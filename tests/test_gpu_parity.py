@@ -293,16 +293,16 @@ SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH":
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))
 @pytest.mark.parametrize("w,h,K", [(67, 45, 6), (130, 98, 12), (300, 70, 30), (64, 200, 6), (1024, 436, 30), (2, 2, 6), (700, 5, 30), (200, 150, 10),
                                    (150, 130, 7), (90, 140, 15), (129, 65, 16), (100, 100, 1), (257, 33, 31)])
-def test_sor_kernel_variants(ctx, oracle, monkeypatch, variant, w, h, K):
+def test_sor_kernel_variants(ctx, oracle, switches, variant, w, h, K):
     """every solver kernel (task pipeline with 1/2/3 fused sweeps per wave, band pipeline with 1/2/3/5/6: a shape that does not divide K falls back
     to the next that does) gives the
     raster-order result bit for bit, for each element of a batch of two different systems"""
     for k in ("SFA_SOR_BAND", "SFA_SOR_F", "SFA_SOR_CH", "SFA_SOR_CHAIN"):
-        monkeypatch.delenv(k, raising=False)
+        switches.unset(k)
     if not variant.startswith("chain"):
-        monkeypatch.setenv("SFA_SOR_CHAIN", "0")
+        switches.set("SFA_SOR_CHAIN", "0")
     for k, v in SOR_VARIANTS[variant].items():
-        monkeypatch.setenv(k, v)
+        switches.set(k, v)
     rng = np.random.default_rng(w + 3 * h + K)
     systems = [sor_system(rng, w, h) for _ in range(2)]
     for s in systems:
@@ -442,7 +442,7 @@ def test_level_variants(ctx, oracle, kw):
     dict(robust_color=(3, 0.001, 0.5), robust_grad=(4, 0.05, 0.5)),
 ])
 @pytest.mark.parametrize("w,h", [(67, 45), (200, 37), (64, 16), (129, 70)])
-def test_fused_assembly_is_the_unfused_pipeline(ctx, oracle, monkeypatch, kw, w, h):
+def test_fused_assembly_is_the_unfused_pipeline(ctx, oracle, switches, kw, w, h):
     """the image->system kernel (derivative filters in LDS, mask weights on the fly) against the materialised form
     (warp copies, 24-plane stacks, mask-weight pass, per-pixel assembly): the same bits, every term kind, with
     channel weights, across tile borders (sizes off the 64x8 tile grid)"""
@@ -452,7 +452,7 @@ def test_fused_assembly_is_the_unfused_pipeline(ctx, oracle, monkeypatch, kw, w,
     _, ps = mk_params(oracle, S=3, rho=[1, 0.5], omega=[0.5, 2], norm_avg=af, norm_std=sf, niter_outer=2, **kw)
     out = []
     for unfused in ("1", "0"):
-        monkeypatch.setenv("SFA_UNFUSED", unfused)
+        switches.set("SFA_UNFUSED", unfused)
         wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
         ch, _ = ctx.compute_one_level(ps, wx, wy, [c_(f) for f in frames], w, [c_(x) for x in chw])
         out.append((wx, wy, ch))
@@ -481,6 +481,22 @@ def test_thresholds_break_like_the_oracle(ctx, oracle):
     d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
     assert d <= TOL_LEVEL, d
     assert o[2][0] < 2e-3 and abs(o[2][0] - g[2][0]) < 1e-6      # both stopped at the same outer iteration
+
+
+def test_nan_norms_never_break(ctx, oracle):
+    """std::max(a, b) = (a < b) ? b : a keeps a NaN first argument (variational_mt.cpp:407,436): a NaN change norm is never below a threshold, so neither
+    side breaks, both report NaN norms, and the NaNs have spread over the same pixels"""
+    w, h = 67, 45
+    frames, af, sf = normalized_frames(oracle, w, h, 3)
+    frames[1][1, h - 3, w - 4] = np.nan
+    po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=2, niter_solver=3, thres_outer=1e30, thres_inner=1e30)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+    assert np.isnan(o[2][0]) and np.isnan(o[2][1]) and np.isnan(g[2][0]) and np.isnan(g[2][1])
+    for k in range(2):
+        a, b = valid(o[k], w), valid(g[k], w)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        fin = ~np.isnan(a)
+        assert fin.sum() == 0 or np.abs(a[fin] - b[fin]).max() <= TOL_LEVEL
 
 
 def test_config1_translation_256(ctx, oracle):
@@ -597,7 +613,7 @@ def test_config5_level_2048_lorentzian(ctx, oracle):
     assert d <= TOL_LEVEL, d
 
 
-def test_config5_pyramid_6_levels_fused_equals_unfused(ctx, oracle, monkeypatch):
+def test_config5_pyramid_6_levels_fused_equals_unfused(ctx, oracle, switches):
     """2048x2048, 6 levels, Lorentzian, whole coarse-to-fine run: the fused pipeline is the materialised one bit for bit
     (the oracle is too slow for the whole schedule at this size; its levels are pinned above and at smaller sizes)"""
     w = h = 2048
@@ -606,7 +622,7 @@ def test_config5_pyramid_6_levels_fused_equals_unfused(ctx, oracle, monkeypatch)
     _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=2, layers=6, robust_color=lor, robust_grad=lor, robust_reg=lor)
     out = []
     for unfused in ("1", "0"):
-        monkeypatch.setenv("SFA_UNFUSED", unfused)
+        switches.set("SFA_UNFUSED", unfused)
         wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
         ctx.variational(ps, wx, wy, [c_(f) for f in frames], w, None)
         out.append((wx, wy))
@@ -640,7 +656,7 @@ def test_config5_batch_32_fits_in_1_65_gb_per_window(ctx, oracle):
 
 
 @pytest.mark.parametrize("w,h,layers", [(256, 200, 4), (130, 98, 3)])
-def test_shared_solver_workspace_is_the_per_level_one(ctx, oracle, monkeypatch, w, h, layers):
+def test_shared_solver_workspace_is_the_per_level_one(ctx, oracle, switches, w, h, layers):
     """large frames re-shape ONE solver workspace level by level instead of keeping one per level; forced on a small size (SFA_SHARE_SOR) it must not change a bit,
     (the memory figure of a bench window is test_bench_window_memory's)"""
     frames, af, sf = normalized_frames(oracle, w, h, 3, seed=31)
@@ -648,9 +664,9 @@ def test_shared_solver_workspace_is_the_per_level_one(ctx, oracle, monkeypatch, 
     out = []
     for share in (False, True):
         if share:
-            monkeypatch.setenv("SFA_SHARE_SOR", "1")
+            switches.set("SFA_SHARE_SOR", "1")
         else:
-            monkeypatch.delenv("SFA_SHARE_SOR", raising=False)
+            switches.unset("SFA_SHARE_SOR")
         wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
         for _ in range(2):                                   # twice: the second run re-shapes a workspace that already holds another level's data
             wx[...] = 0; wy[...] = 0
@@ -674,7 +690,7 @@ def test_bench_window_memory(ctx, oracle):
     assert per_window <= 0.32e9, per_window
 
 
-def test_config3_shape_2560x1440_cfg_terms(ctx, oracle, monkeypatch):
+def test_config3_shape_2560x1440_cfg_terms(ctx, oracle, switches):
     """config 3 stand-in: 2560x1440, cfgs/slow_flow.cfg terms (S=3, rho 1/1, omega 0/2, modified L1), 5 levels:
     fused == materialised bit for bit at full size, and the known (2,1) px/frame translation is recovered"""
     w, h = 2560, 1440
@@ -682,7 +698,7 @@ def test_config3_shape_2560x1440_cfg_terms(ctx, oracle, monkeypatch):
     _, ps = mk_params(oracle, S=3, rho=[1, 1], omega=[0, 2], norm_avg=af, norm_std=sf, niter_outer=2, layers=5)
     out = []
     for unfused in ("1", "0"):
-        monkeypatch.setenv("SFA_UNFUSED", unfused)
+        switches.set("SFA_UNFUSED", unfused)
         wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
         ctx.variational(ps, wx, wy, [c_(f) for f in frames], w, None)
         out.append((wx, wy))
@@ -799,30 +815,30 @@ def test_grid_cut_full_size(ctx, oracle):
 
 
 @pytest.mark.parametrize("kind,w,h", [("blobs", 1024, 436), ("stripes", 300, 200), ("noise", 130, 98), ("blobs", 67, 45)])
-def test_grid_cut_sparse_phase_runs_the_same_rounds(ctx, monkeypatch, kind, w, h):
+def test_grid_cut_sparse_phase_runs_the_same_rounds(ctx, switches, kind, w, h):
     """the one-workgroup-per-window kernel of the sparse phase executes the rounds the grid launches would: identical labels"""
     rng = np.random.default_rng(w + h)
     d0, d1 = _cut_case(rng, w, h, kind)
-    monkeypatch.setenv("SFA_CUT_DISCHARGE", "0")                # the grid rounds (round 2's schedule, the cross-check of the tile discharge)
-    monkeypatch.setenv("SFA_CUT_TAIL", "1")                     # a single window would not take it by itself
+    switches.set("SFA_CUT_DISCHARGE", "0")                # the grid rounds (round 2's schedule, the cross-check of the tile discharge)
+    switches.set("SFA_CUT_TAIL", "1")                     # a single window would not take it by itself
     occ_tail = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
-    monkeypatch.delenv("SFA_CUT_TAIL")
-    monkeypatch.setenv("SFA_CUT_NO_TAIL", "1")
+    switches.unset("SFA_CUT_TAIL")
+    switches.set("SFA_CUT_NO_TAIL", "1")
     occ_grid = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
     assert np.array_equal(occ_tail, occ_grid)
 
 
 @pytest.mark.parametrize("kind,w,h", [("blobs", 1024, 436), ("stripes", 300, 200), ("noise", 130, 98), ("blobs", 67, 45), ("stripes", 64, 16), ("noise", 65, 17)])
-def test_grid_cut_tile_discharge_finds_the_same_cut(ctx, oracle, monkeypatch, kind, w, h):
+def test_grid_cut_tile_discharge_finds_the_same_cut(ctx, oracle, switches, kind, w, h):
     """the tile-discharge schedule (rounds inside 64 x 16 tiles, four colours) and the grid rounds reach a maximum flow each; the labelling read off
     it (who still reaches the passive terminal) is the same set whichever maximum flow it is -- and the energy is the oracle's minimum"""
     rng = np.random.default_rng(w + 3 * h)
     d0, d1 = _cut_case(rng, w, h, kind)
     occ_tiles = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
     for inner, sup in ((3, 1), (200, 4)):
-        monkeypatch.setenv("SFA_CUT_INNER", str(inner)); monkeypatch.setenv("SFA_CUT_SUPER", str(sup))
+        switches.set("SFA_CUT_INNER", str(inner)); switches.set("SFA_CUT_SUPER", str(sup))
         assert np.array_equal(occ_tiles, ctx.grid_cut(c_(d0), c_(d1), 0.5, w))
-    monkeypatch.setenv("SFA_CUT_DISCHARGE", "0")
+    switches.set("SFA_CUT_DISCHARGE", "0")
     occ_grid = ctx.grid_cut(c_(d0), c_(d1), 0.5, w)
     a0 = orc.plane(*d0.shape); a0[...] = d0
     a1 = orc.plane(*d1.shape); a1[...] = d1
@@ -1047,7 +1063,7 @@ def test_two_frame_golden_gpu(ctx, case):
 
 
 @pytest.mark.parametrize("w,h,p_scale,layers", [(130, 98, 0.9, 4), (200, 150, 0.75, 3), (97, 61, 0.5, 3), (1024, 436, 0.9, 5)])
-def test_fused_pyramid_step_is_blur_then_resize(ctx, oracle, monkeypatch, w, h, p_scale, layers):
+def test_fused_pyramid_step_is_blur_then_resize(ctx, oracle, switches, w, h, p_scale, layers):
     """k_pyr_down (blur rows, blur columns, bilinear sample from an LDS tile) gives the frames of the two-kernel pyramid bit for
     bit: whole runs agree exactly, for several scale factors (tile footprints) and sizes off the tile grid"""
     frames, af, sf = normalized_frames(oracle, w, h, 3, seed=31)
@@ -1055,9 +1071,9 @@ def test_fused_pyramid_step_is_blur_then_resize(ctx, oracle, monkeypatch, w, h, 
     out = []
     for unfused in ("1", "0"):
         if unfused == "1":
-            monkeypatch.setenv("SFA_PYRAMID_UNFUSED", "1")
+            switches.set("SFA_PYRAMID_UNFUSED", "1")
         else:
-            monkeypatch.delenv("SFA_PYRAMID_UNFUSED", raising=False)
+            switches.unset("SFA_PYRAMID_UNFUSED")
         wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
         ctx.variational(ps, wx, wy, [c_(f) for f in frames], w, None)
         out.append((wx, wy))
@@ -1065,7 +1081,7 @@ def test_fused_pyramid_step_is_blur_then_resize(ctx, oracle, monkeypatch, w, h, 
 
 
 @pytest.mark.parametrize("w,h,S,smoothing", [(130, 98, 2, 1), (67, 45, 3, 1), (200, 150, 2, 0), (1024, 436, 2, 1)])
-def test_fused_warp_smoothness_is_the_two_kernels(ctx, oracle, monkeypatch, w, h, S, smoothing):
+def test_fused_warp_smoothness_is_the_two_kernels(ctx, oracle, switches, w, h, S, smoothing):
     """k_warp_smooth (the warps of get_derivatives and compute_smoothness of the same flow field in one pass; S = 3: six warps, four of them behind the
     smoothness arithmetic) gives the bits of k_warp_jobs + k_smoothness_tiled -- whole runs agree exactly -- and so does the one-job-per-grid-z form of the warps"""
     frames, af, sf = normalized_frames(oracle, w, h, 2 * S - 1, seed=37)
@@ -1073,9 +1089,9 @@ def test_fused_warp_smoothness_is_the_two_kernels(ctx, oracle, monkeypatch, w, h
     out = []
     for env in ({}, {"SFA_NO_WARP_SMOOTH": "1"}, {"SFA_NO_WARP_SMOOTH": "1", "SFA_WARP_ALLJ": "0"}):
         for k in ("SFA_NO_WARP_SMOOTH", "SFA_WARP_ALLJ"):
-            monkeypatch.delenv(k, raising=False)
+            switches.unset(k)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            switches.set(k, v)
         wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
         ctx.variational(ps, wx, wy, [c_(f) for f in frames], w, None)
         out.append((wx, wy))
@@ -1161,7 +1177,7 @@ def test_red_black_tile_kernel_is_the_pass_kernel(ctx, oracle, w, h, K):
     with tempfile.TemporaryDirectory() as d:
         for mode in ("0", "3", "5"):
             f = os.path.join(d, "rb_%s.npy" % mode)
-            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, SFA_RB_TILE=mode), capture_output=True, text=True, timeout=300)
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, SFA_DEBUG="1", SFA_RB_TILE=mode), capture_output=True, text=True, timeout=300)
             assert r.returncode == 0, r.stderr
             outs.append(np.load(f))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
@@ -1501,31 +1517,50 @@ def test_poisoned_solve_returns_timeout_and_the_context_keeps_working(oracle):
         c.close()
 
 
-def test_verbose_change_lines(oracle, capfd, monkeypatch):
+def test_verbose_change_lines(oracle, capfd, switches):
     """the reference prints "inner it i avg change a,b" / "outer it i avg change a,b" per iteration under verbosity(VER_CMD) (variational_mt.cpp:404-405, 431-432); the
-    library prints the same lines when SFA_VERBOSE_CHANGES is set (the C++ class and the driver set it from the cfg's `verbose`), and the last outer line carries the
-    change norms the call returns"""
+    library prints the same lines for a context with sfa_ctx_set_verbose (the C++ class and the driver set it from the cfg's `verbose`): every line carries the oracle's
+    value (the |old_du - du| norm on the inner lines, the last inner iteration included; fp32 raster sums there, fp64 tree sums here), the last outer line the change
+    norms the call returns, and the flow is the flow of the quiet run bit for bit"""
     w, h = 67, 45
     frames, af, sf = normalized_frames(oracle, w, h, 3)
-    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=3, niter_inner=2)
-    monkeypatch.setenv("SFA_VERBOSE_CHANGES", "1")
-    c = sfa.Context(0)
-    try:
-        wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
-        ch, _ = c.compute_one_level(ps, wx, wy, [c_(f) for f in frames], w)
-    finally:
-        c.close()
-    out = capfd.readouterr().out.splitlines()
-    inner = [l for l in out if l.startswith("\tinner it ")]
-    outer = [l for l in out if l.startswith("outer it ")]
-    assert len(inner) == 6 and len(outer) == 3, out
-    assert inner[0].startswith("\tinner it 0\tavg change ") and outer[2].startswith("outer it 2\tavg change ")
-    a, b = (float(x) for x in outer[2].split("avg change ")[1].split(","))
-    assert abs(a - ch[0]) <= 1e-5 * abs(ch[0]) + 1e-12 and abs(b - ch[1]) <= 1e-5 * abs(ch[1]) + 1e-12
+    results = {}
+    for niter_inner in (2, 1):
+        po, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=3, niter_inner=niter_inner)
+        oracle.change_log(64)
+        wxo, wyo = orc.plane(h, orc.stride_of(w)), orc.plane(h, orc.stride_of(w))
+        rc, _, _ = oracle.compute_one_level(po, wxo, wyo, frames, w)
+        ref = oracle.change_log_rows().copy()
+        oracle.change_log(0)
+        assert rc == 0 and len(ref) == 3 * niter_inner + 3
+        c = sfa.Context(0)
+        try:
+            flows = []
+            for verbose in (True, False):
+                c.set_verbose(verbose)
+                wx, wy = np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32)
+                capfd.readouterr()
+                ch, _ = c.compute_one_level(ps, wx, wy, [c_(f) for f in frames], w)
+                out = capfd.readouterr().out.splitlines()
+                flows.append((wx, wy))
+                if not verbose:
+                    assert not [l for l in out if "avg change" in l]
+                    continue
+                lines = [l for l in out if "avg change" in l]
+                assert len(lines) == len(ref), out
+                for l, (kind, it, ra, rb) in zip(lines, ref):
+                    assert l.startswith(("\tinner it %d\tavg change " if kind == 0 else "outer it %d\tavg change ") % int(it)), (l, kind, it)
+                    a, b = (float(x) for x in l.split("avg change ")[1].split(","))
+                    assert abs(a - ra) <= 2e-4 * abs(ra) + 1e-9 and abs(b - rb) <= 2e-4 * abs(rb) + 1e-9, (l, ra, rb)
+                a, b = (float(x) for x in lines[-1].split("avg change ")[1].split(","))
+                assert abs(a - ch[0]) <= 1e-5 * abs(ch[0]) + 1e-12 and abs(b - ch[1]) <= 1e-5 * abs(ch[1]) + 1e-12
+            assert np.array_equal(flows[0][0], flows[1][0]) and np.array_equal(flows[0][1], flows[1][1])
+        finally:
+            c.close()
 
 
 @pytest.mark.parametrize("pen", [1, 2])
-def test_assembly_instances_and_tile_orders_give_the_same_bits(ctx, oracle, monkeypatch, pen):
+def test_assembly_instances_and_tile_orders_give_the_same_bits(ctx, oracle, switches, pen):
     """The fused assembly kernel's variants -- the folded instances (modified L1 / Lorentzian) against the run-time instance (SFA_ASSEMBLE_GENERIC), the
     shared-reciprocal divisions against __fdiv_rn only (SFA_EXACT_DIV), the XCD-contiguous tile order against the plain grid (SFA_ASM_XCD=0) -- on a batch whose
     launch is large enough for the XCD order (9 windows of 300x200: 675 tiles), S = 3 with to-reference terms, sizes off the tile grid: one set of bits."""
@@ -1536,9 +1571,9 @@ def test_assembly_instances_and_tile_orders_give_the_same_bits(ctx, oracle, monk
     outs = {}
     for name, env in (("default", {}), ("generic", {"SFA_ASSEMBLE_GENERIC": "1"}), ("exact_div", {"SFA_EXACT_DIV": "1"}), ("plain_grid", {"SFA_ASM_XCD": "0"})):
         for k in ("SFA_ASSEMBLE_GENERIC", "SFA_EXACT_DIV", "SFA_ASM_XCD"):
-            monkeypatch.delenv(k, raising=False)
+            switches.unset(k)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            switches.set(k, v)
         job = sfa.Job(ctx, ps, w, h, nb)
         for b in range(nb):
             job.upload(b, [c_(np.roll(f, 3 * b, axis=2)) for f in frames])

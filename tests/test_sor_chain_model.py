@@ -53,3 +53,20 @@ def test_chain_protocol_thresholds_are_tight_with_one_interval_too():
     m = _sim("raw", 1, pubd=1)
     bad, _ = m.run(40, 70, 12, m.Shape(2, 3, 2, 0), 1)
     assert bad > 0
+
+
+ALL_SHAPES = [(1, 3, 1, 0), (2, 3, 2, 0), (3, 5, 3, 0), (2, 5, 2, 0), (1, 5, 1, 0), (3, 2, 3, 0), (3, 3, 2, 3), (2, 3, 3, 3)]      # kChainShapes with an operand ring
+
+
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+def test_operand_ring_depth_and_read_ahead(shape):
+    """the write-after-read argument behind the operand ring's depth lived in a comment.  The model walks every (stage, sweep, step) of the barrier
+    lockstep: at the kernel's depth and read-ahead no row is read before it is written or after its slot is rewritten; the derived minimum is tight (one row less: a
+    write-after-read clash at one step of read-ahead); a step more of read-ahead than the kernel takes reads a row too early"""
+    m = _sim("raw", 0)
+    S = m.Shape(*shape)
+    opr, oprmin = m.ring_rows(S)
+    pf = m.ring_prefetch(S)
+    assert opr >= oprmin and m.ring_hazards(S, opr, pf) == []
+    assert m.ring_hazards(S, oprmin, 1) == [] and {b[0] for b in m.ring_hazards(S, oprmin - 1, 1)} == {"war"}
+    assert {b[0] for b in m.ring_hazards(S, opr, pf + 1)} & {"raw", "raw-self", "raw-in"}

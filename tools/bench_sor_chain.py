@@ -16,7 +16,7 @@ planes=[np.ascontiguousarray(s[k]) for k in ("du","dv","a11","a12","a22","b1","b
 for B in batches:
     ref=None
     for sh in shapes:
-        os.environ["SFA_SOR_CHAIN"]=str(sh)
+        sfa.debug_set("SFA_SOR_CHAIN", sh)
         sb=sfa.SorBatch(ctx,W,H,B)
         for b in range(B): sb.upload(b,*planes)
         sb.run(K,1.9); ctx.sync()

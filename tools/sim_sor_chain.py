@@ -48,6 +48,47 @@ def round_up(a, m):
     return (a + m - 1) // m * m
 
 
+def ring_rows(S):
+    """(ChainLds::OPR, the derived minimum) of a shape: rows of the LDS operand ring (0 = the shape has none)"""
+    NW, KG, FMAX = S.NW, S.KG, S.FMAX
+    ring = 2 * CH * 64 * 8
+    tv0 = (NW + 1) * ring; tvw = 2 * CH * (FMAX + 1) * 8; es0 = tv0 + NW * tvw; esw = 2 * (FMAX - 1 if FMAX > 1 else 1) * CH * 8
+    ops0 = (es0 + NW * esw + 64 * 8 + esw + 15) & ~15
+    oprowb = (64 + KG - 1) * 16
+    derived = 3 * NW + 2 * KG + 2                                  # the smallest depth without a write-after-read clash at one step of read-ahead (ring_hazards)
+    oprmin = 3 * (NW - 1) + 2 * (KG - 1) + 9                       # ChainLds::OPRMIN = derived + 2: the kernel keeps two rows of margin, three where they fit
+    opr = oprmin + 1 if ops0 + 2 * (oprmin + 1) * oprowb + 32 <= 160 * 1024 else oprmin
+    return (opr, derived) if KG <= 16 and ops0 + 2 * opr * oprowb + 32 <= 160 * 1024 else (0, derived)
+
+
+def ring_prefetch(S):
+    """k_sor_chain's PF: steps by which the ring-fed sweeps read their rows ahead (2 where every stage has at least two sweeps and the workgroup fewer than 8 stages)"""
+    return 2 if S.FA >= 2 and (S.NB_ == 0 or S.FB >= 2) and S.NW < 8 else 1
+
+
+def ring_hazards(S, OPR, PF, nsteps=600):
+    """The LDS operand ring of chain_compute under the barrier lockstep (compute wave w runs its chunk c in interval LEAD + w + c; accesses of DIFFERENT waves inside one
+    interval are unordered, a wave's own accesses keep program order).  Row r (the first stage's step r) is written by the IN wave (the KG - 1 entries above the band) in
+    interval r // CH + AH and by the first stage in its step r (interval LEAD + r // CH); sweep kappa of stage w uses row i + w - 2 kappa at its step i and reads it at
+    the END of step i - PF (before the first barrier when i < PF); row r + OPR lands in row r's slot.  Returns the violated dependencies."""
+    bad = []
+    w_in = lambda r: r // CH + AH
+    w_st = lambda r: LEAD + r // CH
+    for w in range(S.NW):
+        for f in range(S.Fw(w)):
+            kap = S.kw(w) + f
+            if w == 0 and f == 0: continue                                   # the group's first sweep loads from memory
+            for i in range(nsteps):
+                rho, issue = i + w - 2 * kap, i - PF
+                t_read = 0 if issue < 0 else LEAD + w + issue // CH
+                if rho >= 0:                                                 # read after write (rows < 0 are never written: the ring's initial zeros)
+                    if w == 0 and not rho <= issue: bad.append(("raw-self", w, kap, i))          # the first stage's own trailing sweeps: program order inside the wave
+                    if w > 0 and not w_st(rho) < t_read: bad.append(("raw", w, kap, i))
+                    if not w_in(rho) < t_read: bad.append(("raw-in", w, kap, i))
+                if rho + OPR >= 0 and not t_read < w_in(rho + OPR): bad.append(("war", w, kap, i))   # the slot's next row arrives (IN wave first) after this read
+    return bad
+
+
 class Shape:
     def __init__(self, FA, NA, FB, NB_):
         self.FA, self.NA, self.FB, self.NB_ = FA, NA, FB, NB_
