@@ -41,7 +41,7 @@ def assemble_valu_per_pixel_term():
     from the SQ counter pass of the newest profile round that has it: SQ_INSTS_VALU / SQ_WAVES (both counters sample the same subset of the launch's waves, so
     their ratio is per wave; rounds 1-3 divided the raw instruction count by ALL pixels and reported 440 where a wave really issues ~1950 for its 64 pixels x 2
     terms) / 2 terms.  Returns (instructions, source, share of SIMD time with a VALU instruction in flight when the kernel runs alone)."""
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
                 j = json.load(f)
@@ -100,7 +100,7 @@ def sor_valu_per_wave(kernel):
     """(VALU instructions per wave of the SOR kernel, waves per workgroup, source) from the newest SQ pass whose kernel shape is the one that ran."""
     def norm(k):
         return k.replace("void ", "").replace("sfa::", "").split("(")[0].replace(" ", "")
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
                 j = json.load(f)
@@ -290,7 +290,7 @@ def measured_traffic(batch, kernel=None):
     so the committed measurement of the same command is reported, and only when it was taken at this batch size.
     Returns (bytes per launch, source, valu_busy) -- valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (SIMDs x kernel cycles) of the SOR kernel
     when the SQ pass of the same round is there (profiles/<tag>_sq.json), else None."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", tag + "_traffic.json")
         try:
             with open(path) as f:
@@ -588,9 +588,13 @@ def main():
                     "(the reference drives its windows from OpenMP threads, slow_flow.cpp:706): the groups fill each other's ramp-up / drain phases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path-only", action="store_true", help="skip the SOR-only section (used for the PMC passes: every SOR dispatch then belongs to the path)")
+    ap.add_argument("--bench-only", action="store_true", help="--path-only and none of the reported extras either (one-window latency, labelled modes, cfg-schedule sample, triad): "
+                                                              "every kernel launch of the process is a launch of the timed workload (the kernel-stats pass of profiles/collect.sh)")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU rehearsal of the multi-rank launch and exchange (gloo); prints a selftest line, never a result")
     ap.add_argument("--no-strong", action="store_true", help="skip the config-4 strong-scaling section (128 windows in total under the cfg schedule)")
     args = ap.parse_args()
+    if args.bench_only:
+        args.path_only = True
 
     # N > 1 and nobody started the ranks: do it here, as a child process, before torch / HIP are touched
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -714,7 +718,9 @@ def main():
             # charges 44 K + 12 bytes per pixel because it re-reads the operands in every sweep; a kernel that keeps 15 sweeps of a band in LDS moves far fewer, so
             # that figure exceeds the peak and is carried as `algorithmic_gbs_8d` / `algorithmic_8d_over_peak`, NOT as a fraction of anything.  The kernel is not
             # bandwidth bound at all: `limiter` says what it waits for, `valu_issue_floor_frac` how close it is to that roof.
-            "roofline": {"bound": "hbm", "kernel": sor_kernel + " -- the shape the library picked for %d windows per launch" % BL,
+            # `bound` names the roof the contract prices the kernel against (HBM bandwidth, MFMA not applicable); what the kernel actually waits for is
+            # `limited_by` / `limiter` (the two are different statements and are labelled as such)
+            "roofline": {"bound": "hbm", "limited_by": "valu_issue" if BL >= 16 else "dependency_latency", "kernel": sor_kernel + " -- the shape the library picked for %d windows per launch" % BL,
                          "achieved": round(compulsory / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(compulsory / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4) if avg_launch_s > 0 else None, "traffic": traffic,
                          "launches": n_sor, "avg_launch_ms": round(sor_ms / max(n_sor, 1), 4),
@@ -760,6 +766,14 @@ def main():
             out["roofline"]["sor_1024x436_single"] = sor_entry(1, n2, ms2, by2)
         if sor16:
             out["roofline"]["sor_1024x436_batch16"] = sor_entry(16, sor16[0], sor16[1], sor16[2], sor16[3])
+        # north_star's own budget: ">= 60 % of the HBM roofline on the SOR inner loop at 1024x436" under SURVEY 8(d)'s byte model (1332 B per pixel and 30-sweep solve)
+        # is <= 124 us per solve; per batch size, is it met?
+        budget = {"north_star_budget_us_per_solve": 124.0, "byte_model": "SURVEY 8(d): (44 K + 12) B per pixel = 594.7 MB per 1024x436x30 solve; 60 % of 8 TB/s"}
+        for key, name in (("sor_1024x436_single", "batch_1"), ("sor_1024x436_batch16", "batch_16"), ("sor_1024x436_batch", "batch_%d" % BL)):
+            e = out["roofline"].get(key)
+            if e:
+                budget[name] = {"us_per_solve": e["us_per_solve"], "meets": bool(e["us_per_solve"] <= 124.0)}
+        out["roofline"]["north_star_budget"] = budget
         # second kernel of the step: the data-term assembly (about 40 % of it).  VALU bound: wave instructions issued per second against the chip's
         # issue rate (256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles).  Instructions per pixel and term from the SQ counter pass of the same
         # kernel (profiles/), duration live from HIP events around every launch of the timed region.
@@ -783,6 +797,8 @@ def main():
         if strong5 is not None:
             out["config5_strong"] = strong5
         try:
+            if args.bench_only:
+                raise RuntimeError("--bench-only")
             lat, sor1, rb = one_window_latency(ctx)
             out["latency_one_window_ms"] = round(lat, 3)
             out["latency_one_window_sor_ms_per_solve"] = round(sor1, 4)
@@ -795,6 +811,8 @@ def main():
             except Exception as e:                                # a reported extra
                 out["cfg_schedule_with_thresholds"] = None
         try:
+            if args.bench_only:
+                raise RuntimeError("--bench-only")
             out["roofline"]["measured_triad_gbs"] = round(hbm_triad_gbs(torch), 1)
         except Exception as e:                                    # a measurement aid only
             out["roofline"]["measured_triad_gbs"] = None

@@ -189,6 +189,13 @@ int  sfa_sequence_upload(sfa_sequence *seq, int f, const float *frame3, int stri
 int  sfa_sequence_download(sfa_sequence *seq, int f, float *frame3, int stride);
 /* normalize() (variational_mt.cpp:17-85) over the frames [f0, f0 + n) in place on the GPU; avg / std as sfa_normalize */
 int  sfa_sequence_normalize(sfa_sequence *seq, int f0, int n, double avg[3], double std_dev[3]);
+/* The same in its three parts, for a sequence whose frames are spread over several GPUs (each GPU holds the frames its windows read) and must still be
+ * normalised with the statistics of ALL loaded frames (slow_flow.cpp:673): (1) the six fp64 sums of the raw frames [f0, f0 + n), sums[6 f + 2 k] = sum of
+ * channel k, sums[6 f + 2 k + 1] = sum of its squares -- a deterministic kernel, the same bits on whichever GPU holds a frame; (2) avg / std from per-frame sums
+ * in frame order (host arithmetic, variational_mt.cpp:41-52); (3) I <- (I - avg) / std on resident frames. */
+int  sfa_sequence_frame_sums(sfa_sequence *seq, int f0, int n, double *sums /* n x 6 */);
+int  sfa_normalize_statistics(const double *sums /* n_frames x 6 */, int n_frames, int w, int h, double avg[3], double std_dev[3]);
+int  sfa_sequence_apply_normalization(sfa_sequence *seq, int f0, int n, const double avg[3], const double std_dev[3]);
 
 /* ---- device-resident batches (measurement and the multi-pair driver) ------------------------------
  * A job = `batch` independent frame windows of identical size solved in lockstep by the same launches

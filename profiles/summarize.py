@@ -17,6 +17,32 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go = os.path.join(root, "gpurun_out")
 out = os.path.join(root, "profiles")
 
+# provenance: the HEAD the collection was started from (profiles/collect.sh writes it next to the raw files, with the hash of the library that
+# ran) must be the HEAD of this tree, and the kernels' sources must not have changed since; both go into every JSON written here
+import hashlib
+import subprocess
+prov = {"collected_at_head": None, "library_sha256": None}
+try:
+    lines = open(os.path.join(go, f"{tag}_head.txt")).read().split()
+    prov["collected_at_head"], prov["library_sha256"] = lines[0], (lines[1] if len(lines) > 1 else None)
+except OSError:
+    pass
+try:
+    head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "slowflow_amd/csrc", "include"], capture_output=True, text=True).stdout.strip()
+    prov["summarized_at_head"] = head
+    prov["kernel_sources_modified_since"] = bool(dirty)
+    lib = os.path.join(root, "slowflow_amd", "libslowflow_amd.so")
+    if os.path.exists(lib):
+        prov["library_sha256_here"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+    if "--force" not in sys.argv:
+        assert prov["collected_at_head"] in (None, "unknown") or head.startswith(prov["collected_at_head"]) or prov["collected_at_head"].startswith(head), \
+            f"profiles of {tag} were collected at {prov['collected_at_head']}, this tree is at {head}: collect again (or --force)"
+        assert not dirty, "kernel sources differ from HEAD: commit first, then collect and summarise (or --force)\n" + dirty
+except FileNotFoundError:
+    pass
+json.dump(prov, open(os.path.join(out, f"{tag}_provenance.json"), "w"), indent=1)
+
 
 def find(d, suffix):
     for base, _, files in os.walk(os.path.join(go, d)):
@@ -87,6 +113,7 @@ sor = sorted((k for k in res["kernels"] if "k_sor_" in k and "prepare" not in k 
 if sor:
     res["traffic_bytes_per_launch"] = res["kernels"][sor[0]]["traffic_bytes_per_launch"]
     res["kernel"] = sor[0]
+res["provenance"] = prov
 json.dump(res, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
 # SQ passes (when collected): per kernel the share of SIMD time with a VALU instruction active, the LDS bank-conflict share and the instruction mix
 try:
@@ -137,6 +164,7 @@ try:
         inst = sum(sum(sq[k]["SQ_INSTS_VALU"]) for k in asm_k) / sum(len(sq[k]["SQ_INSTS_VALU"]) for k in asm_k)
         sqj["assemble_valu_inst_per_pixel_term"] = round(inst * 64.0 / (px * batch * 2), 1)
         sqj["assemble_note"] = "SQ_INSTS_VALU (wave instructions, mean per dispatch of both k_assemble_images instances) x 64 / (mean level pixels x %d windows x 2 terms)" % batch
+    sqj["provenance"] = prov
     json.dump(sqj, open(os.path.join(out, f"{tag}_sq.json"), "w"), indent=1)
     print("SQ:", {k[-40:]: v for k, v in list(sqj["kernels"].items())[:4]})
 except FileNotFoundError:

@@ -67,7 +67,7 @@ EXPORTS = [
     "sfa_variational", "sfa_variational_2frame", "sfa_params_2frame_default", "variational", "sfa_compute_one_level", "sfa_normalize", "sfa_sor_coupled", "sfa_sor_red_black", "sor_coupled",
     "sfa_image_warp", "sfa_derivative_stack", "sfa_convolve", "sfa_dpsis_weight", "sfa_smoothness", "sfa_sub_laplacian",
     "sfa_add_data_and_match", "sfa_occlusion_costs", "sfa_grid_cut", "sfa_gaussian_blur", "sfa_resize_linear", "sfa_resize_linear_fx", "sfa_gaussian_presmooth", "sfa_pyramid_sizes",
-    "sfa_sequence_create", "sfa_sequence_destroy", "sfa_sequence_upload", "sfa_sequence_download", "sfa_sequence_normalize",
+    "sfa_sequence_create", "sfa_sequence_destroy", "sfa_sequence_upload", "sfa_sequence_download", "sfa_sequence_normalize", "sfa_sequence_frame_sums", "sfa_normalize_statistics", "sfa_sequence_apply_normalization",
     "sfa_job_create", "sfa_job_destroy", "sfa_job_upload", "sfa_job_upload_resident", "sfa_job_reset_flow", "sfa_job_run", "sfa_job_download", "sfa_job_download_occlusions", "sfa_job_keep_alternation_occlusions", "sfa_job_download_alternation_occlusions", "sfa_job_mpix_iters", "sfa_job_device_bytes",
     "sfa_sor_batch_create", "sfa_sor_batch_destroy", "sfa_sor_batch_upload", "sfa_sor_batch_run", "sfa_sor_batch_download",
     "sfa_division_chain", "sfa_ctx_set_wait_bound", "sfa_debug_set", "sfa_ctx_set_verbose", "sfa_profile_enable", "sfa_profile_read", "sfa_profile_read_kernels", "sfa_timer_start", "sfa_timer_stop",
@@ -421,6 +421,16 @@ class Job:
             pass
 
 
+def normalize_statistics(sums, w, h):
+    """normalize()'s (avg, std) from per-frame sums in frame order (include/slowflow_amd.h: sfa_normalize_statistics; host arithmetic)"""
+    s = np.ascontiguousarray(sums, np.float64)
+    avg, std = (C.c_double * 3)(), (C.c_double * 3)()
+    rc = lib().sfa_normalize_statistics(C.c_void_p(s.ctypes.data), int(s.shape[0]), int(w), int(h), avg, std)
+    if rc != 0:
+        raise SlowflowError("sfa_normalize_statistics: bad arguments")
+    return list(avg), list(std)
+
+
 class Sequence:
     """sfa_sequence: the frames of a sequence resident on the GPU, normalised there"""
 
@@ -442,6 +452,17 @@ class Sequence:
         avg, std = (C.c_double * 3)(), (C.c_double * 3)()
         self.ctx._ck(lib().sfa_sequence_normalize(self.h_, f0, self.n - f0 if n is None else n, avg, std), "sfa_sequence_normalize")
         return list(avg), list(std)
+
+    def frame_sums(self, f0=0, n=None):
+        """(n, 6) fp64 sums of the raw frames (per channel: sum, sum of squares)"""
+        n = self.n - f0 if n is None else n
+        s = np.zeros((n, 6), np.float64)
+        self.ctx._ck(lib().sfa_sequence_frame_sums(self.h_, f0, n, C.c_void_p(s.ctypes.data)), "sfa_sequence_frame_sums")
+        return s
+
+    def apply_normalization(self, avg, std, f0=0, n=None):
+        a, s = (C.c_double * 3)(*avg), (C.c_double * 3)(*std)
+        self.ctx._ck(lib().sfa_sequence_apply_normalization(self.h_, f0, self.n - f0 if n is None else n, a, s), "sfa_sequence_apply_normalization")
 
     def close(self):
         if self.h_:

@@ -1059,27 +1059,47 @@ int sfa_sequence_download(sfa_sequence *q, int f, float *frame3, int stride) {
 }
 // normalize() over frames [f0, f0 + n): statistics over exactly these frames (the reference's `-jet k` mode normalises over that jet's frames only,
 // slow_flow.cpp:418-424,673), every frame's sums by the same kernels in the same order whatever the number of frames
-int sfa_sequence_normalize(sfa_sequence *q, int f0, int n, double avg[3], double std_dev[3]) {
+// normalize() (variational_mt.cpp:17-85) in its three parts, so that a sequence spread over several GPUs is normalised with ONE set of statistics: (1) the six
+// fp64 sums of every frame -- a deterministic kernel: the same bits on whichever GPU holds the frame --, (2) the statistics from the per-frame sums in frame
+// order, plain host arithmetic, (3) I <- (I - avg) / std on the resident frames.  sfa_sequence_normalize is the three in a row.
+int sfa_sequence_frame_sums(sfa_sequence *q, int f0, int n, double *sums) {
     sfa_ctx *ctx = q ? q->ctx : nullptr;
-    CHECK_ARGS(q && avg && std_dev && f0 >= 0 && n > 0 && f0 + n <= q->n, "bad arguments");
+    CHECK_ARGS(q && sums && f0 >= 0 && n > 0 && f0 + n <= q->n, "bad arguments");
     SFA_HIP(ctx, hipSetDevice(ctx->device));
     double *dsum = reinterpret_cast<double *>(q->sums.p);
     for (int f = f0; f < f0 + n; f++) launch_normalize_sums(ctx, q->geo(), q->frame(f), dsum + 6 * f);
-    std::vector<double> hs((size_t)6 * n);
-    SFA_HIP(ctx, hipMemcpyAsync(hs.data(), dsum + 6 * f0, hs.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SFA_HIP(ctx, hipMemcpyAsync(sums, dsum + 6 * f0, (size_t)6 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SFA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFA_OK;
+}
+int sfa_normalize_statistics(const double *sums, int n, int w, int h, double avg[3], double std_dev[3]) {
+    if (!sums || n <= 0 || w <= 0 || h <= 0 || !avg || !std_dev) return set_error(nullptr, SFA_ERR_ARG, "sfa_normalize_statistics: bad arguments");
     for (int k = 0; k < 3; k++) { avg[k] = 0; std_dev[k] = 0; }
     for (int f = 0; f < n; f++)
         for (int k = 0; k < 3; k++) {
-            avg[k] += hs[6 * f + 2 * k] / (q->h * q->w);                                 // variational_mt.cpp:41-47
-            std_dev[k] += hs[6 * f + 2 * k + 1] / (q->h * q->w);
+            avg[k] += sums[6 * f + 2 * k] / (h * w);                                     // variational_mt.cpp:41-47
+            std_dev[k] += sums[6 * f + 2 * k + 1] / (h * w);
         }
     for (int k = 0; k < 3; k++) {
         avg[k] /= n;
         std_dev[k] = sqrt((std_dev[k] / n) - avg[k] * avg[k]) / 255.0f;                 // :52
     }
+    return SFA_OK;
+}
+int sfa_sequence_apply_normalization(sfa_sequence *q, int f0, int n, const double avg[3], const double std_dev[3]) {
+    sfa_ctx *ctx = q ? q->ctx : nullptr;
+    CHECK_ARGS(q && avg && std_dev && f0 >= 0 && n > 0 && f0 + n <= q->n, "bad arguments");
+    SFA_HIP(ctx, hipSetDevice(ctx->device));
     for (int f = f0; f < f0 + n; f++) launch_normalize_apply(ctx, q->geo(), q->frame(f), avg, std_dev);
     return sfa_ctx_sync(ctx);
+}
+int sfa_sequence_normalize(sfa_sequence *q, int f0, int n, double avg[3], double std_dev[3]) {
+    sfa_ctx *ctx = q ? q->ctx : nullptr;
+    CHECK_ARGS(q && avg && std_dev && f0 >= 0 && n > 0 && f0 + n <= q->n, "bad arguments");
+    std::vector<double> hs((size_t)6 * n);
+    SFA_TRY(sfa_sequence_frame_sums(q, f0, n, hs.data()));
+    SFA_TRY(sfa_normalize_statistics(hs.data(), n, q->w, q->h, avg, std_dev));
+    return sfa_sequence_apply_normalization(q, f0, n, avg, std_dev);
 }
 
 int sfa_normalize(sfa_ctx *ctx, float *const *frames, int F, int w, int h, int stride, double avg[3], double std_dev[3]) {

@@ -172,6 +172,7 @@ __device__ __forceinline__ v2f pk_mul_hi(v2f hi2, v2f b) {
 }
 // The SOR point update (solver.c:337-343), the same operations in the same order as sor_device.h's sor_point: one rounding per
 // operation, no FMA.  hlz = the operand pair (hp, vp) of the PREVIOUS column: its low half is this point's left weight.
+template <bool SCALAR_T2 = true>
 __device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bottom, v2f left, v2f hlz, const float4 &SA, const float4 &SB, float omega) {
     const v2f SAxy = {SA.x, SA.y}, SAzw = {SA.z, SA.w}, SBxy = {SB.x, SB.y}, SBzw = {SB.z, SB.w};
 #ifdef SFA_X_NOARITH      // timing experiment only: one dependent operation instead of fifteen
@@ -183,11 +184,17 @@ __device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bott
     s = s + SBxy;                                                    // + b
     const v2f B = __builtin_shufflevector(hlz, hlz, 0, 0) * left + s;
     // (a12 B2, a22 B2) as two SCALAR products: written as `{SA.y * B.y, SA.z * B.y}` the vectoriser packs them into one v_pk_mul_f32 whose first operand, the
-    // pair (a12, a22), straddles two register pairs of the 16-byte operand and has to be composed by two v_mov_b32 first -- 8 issue cycles instead of 4 per point
-    float t2x, t2y;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(t2x) : "v"(SA.y), "v"(B.y));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(t2y) : "v"(SA.z), "v"(B.y));
-    const v2f t2 = {t2x, t2y};
+    // pair (a12, a22), straddles two register pairs of the 16-byte operand and has to be composed by two v_mov_b32 first -- 8 issue cycles instead of 4 per point.
+    // Stages of ONE sweep (the lone solve's shape) keep the packed form: their step is a single dependent chain, the moves are off it, and one packed product
+    // on the chain is shorter than two scalar ones (one window 263 against 275 us)
+    v2f t2;
+    if (SCALAR_T2) {
+        float t2x, t2y;
+        asm("v_mul_f32 %0, %1, %2" : "=v"(t2x) : "v"(SA.y), "v"(B.y));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(t2y) : "v"(SA.z), "v"(B.y));
+        t2 = (v2f){t2x, t2y};
+    } else
+        t2 = (v2f){SA.y * B.y, SA.z * B.y};
     const v2f t = SAxy * __builtin_shufflevector(B, B, 0, 0) + t2;
     return self + omega * (t - self);
 }
@@ -333,7 +340,7 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
                     const bool ringfed = ROLE != 0 && f >= F0;
                     const float4 &SA = ringfed ? la[f][j % NSL] : f == 0 ? sa0[ROLE == 2 ? 0 : j0] : sa1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
                     const float4 &SB = ringfed ? lb[f][j % NSL] : f == 0 ? sb0[ROLE == 2 ? 0 : j0] : sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
-                    const v2f xn = sor_point2(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hlz[f], SA, SB, omega);
+                    const v2f xn = sor_point2<(F >= 2)>(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hlz[f], SA, SB, omega);
                     nres[f] = make_float2(xn.x, xn.y);
                     selfv[f] = right;
                 }

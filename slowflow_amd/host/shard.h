@@ -13,6 +13,7 @@
 #include <mutex>
 #include <queue>
 #include <thread>
+#include <utility>
 #include <vector>
 
 // One worker = one host thread with its own context (= HIP stream) on one GPU; it refines the windows [lo, hi) of the
@@ -35,6 +36,34 @@ inline std::vector<WorkerPlan> plan_workers(size_t n_windows, int ngpu, int stre
         plan.push_back(p);
     }
     return plan;
+}
+
+// Which frames of the loaded sequence a GPU must hold: the union of the frames its windows read -- window i reads the frames [first, last] of `window_frames[i]`:
+// jet j forwards j*steps .. j*steps + 2*ref, backwards j*steps + ref .. j*steps + 3*ref (slow_flow.cpp:721-724, :590-591) --, widened so that the ranges of the
+// GPUs that have windows cover [0, n_frames) without a gap: every loaded frame enters normalize()'s statistics (slow_flow.cpp:673), so a frame no window reads
+// (jets skipped by -resume) is still summed by one GPU.  Neighbouring GPUs overlap by the 2*ref..3*ref frames their boundary jets share (the halo).
+// A GPU without windows gets lo == hi.
+struct FrameRange { int lo, hi; };
+inline std::vector<FrameRange> plan_frames(const std::vector<std::pair<int, int>> &window_frames, const std::vector<WorkerPlan> &plan, int ngpu, int n_frames) {
+    ngpu = std::max(1, ngpu);
+    std::vector<FrameRange> r((size_t)ngpu, FrameRange{0, 0});
+    std::vector<char> has((size_t)ngpu, 0);
+    for (const WorkerPlan &wp : plan)
+        for (size_t i = wp.lo; i < wp.hi && i < window_frames.size(); i++) {
+            FrameRange &g = r[(size_t)wp.gpu];
+            const int lo = std::max(0, window_frames[i].first), hi = std::min(n_frames, window_frames[i].second + 1);
+            if (!has[(size_t)wp.gpu]) { g.lo = lo; g.hi = hi; has[(size_t)wp.gpu] = 1; }
+            else { g.lo = std::min(g.lo, lo); g.hi = std::max(g.hi, hi); }
+        }
+    int prev = -1;
+    for (int g = 0; g < ngpu; g++) {
+        if (!has[(size_t)g]) continue;
+        if (prev < 0) r[(size_t)g].lo = 0;                                            // frames in front of the first window
+        else if (r[(size_t)prev].hi < r[(size_t)g].lo) r[(size_t)prev].hi = r[(size_t)g].lo;   // a gap between two GPUs' windows goes to the earlier one
+        prev = g;
+    }
+    if (prev >= 0) r[(size_t)prev].hi = n_frames;                                    // ... and behind the last one
+    return r;
 }
 
 // Adaptive frame rates (slow_flow.cpp:322-352).  quantil = 0.99-quantile of the flow magnitude per frame at max_fps

@@ -134,6 +134,13 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     const string format_flow = format.substr(0, format.find_last_of('.'));
     const int io_threads = std::max(1, std::min(64, params.parameter<int>("io_threads", std::to_string(std::max(1u, std::min(16u, std::thread::hardware_concurrency()))))));
 
+    {                                                                                // a job's windows-still-iterating mask is one 64-bit word: refused by name, not clamped
+        const int gpu_batch = params.parameter<int>("gpu_batch", "32");
+        if (gpu_batch < 1 || gpu_batch > 64) {
+            std::cerr << "gpu_batch " << gpu_batch << " is out of range: a lockstep job takes 1 .. 64 windows (more windows run as several jobs: gpu_streams, batches per worker)" << std::endl;
+            return 2;
+        }
+    }
     mkdirs(params.output);
 
     const int frames = 1 + (params.Jets + 2) * steps;                                // :411
@@ -196,45 +203,111 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     if (!oversubscribe && dev0 >= ndev) { std::cerr << "gpu_device " << dev0 << " does not exist (" << ndev << " device(s))" << std::endl; return 4; }
     auto device_of = [&](int g) { return oversubscribe ? (dev0 + g) % ndev : dev0 + g; };
     const int n_loaded = (int)(end_f - start_f);
+
+    // ---- the windows to refine: forward and backward of every jet (:706-1047), and who refines them -- known before a frame is read, so that every GPU is sent
+    //      only the frames ITS windows read (until round 4 every GPU received and normalised the whole sequence) ----------------------------------
+    std::vector<Window> todo;
+    for (unsigned j = start_j; j < end_j; j++) {
+        const int f = j * steps;
+        string fwd, bwd;
+        flow_files(j, fwd, bwd);
+        if (!opt.resume_frame || !file_exists(fwd)) todo.push_back(Window(j, false, fwd));
+        else std::cout << "Forward flow from frame " << start + f << " to " << start + f * skip + steps * skip << " already exist!" << std::endl;
+        if (!opt.resume_frame || !file_exists(bwd)) todo.push_back(Window(j, true, bwd));
+        else std::cout << "Backward flow from frame " << start + f * skip << " to " << start + f * skip + steps * skip << " already exist!" << std::endl;
+    }
+    // `gpu_streams` workers per GPU (default 2), each with its own context = HIP stream: two lockstep groups fill each other's
+    // ramp-up / drain phases (the reference runs its windows from `threads` OpenMP threads the same way, slow_flow.cpp:706)
+    const int streams = std::max(1, std::min(4, params.parameter<int>("gpu_streams", "2")));
+    const std::vector<WorkerPlan> plan = plan_workers(todo.size(), ngpu, streams);
+    std::vector<std::pair<int, int>> window_frames;                                  // relative to the loaded range [start_f, end_f)
+    for (const Window &wd : todo) {
+        const int f = (int)wd.jet * steps - (int)start_f;
+        window_frames.push_back(wd.backward ? std::make_pair(f + steps, f + 3 * steps) : std::make_pair(f, f + 2 * ref));   // :721-724, :590-591
+    }
+    const std::vector<FrameRange> gpu_frames = plan_frames(window_frames, plan, ngpu, n_loaded);
+
     std::vector<sfa_ctx *> seq_ctx(ngpu, nullptr);
     std::vector<sfa_sequence *> seq_dev(ngpu, nullptr);
-    std::vector<double> stat_avg(3 * ngpu, 0.0), stat_std(3 * ngpu, 0.0);
     std::vector<string> seq_err(ngpu);
-    // The frames go to the GPUs once and are normalised there (:673; sfa_sequence = normalize() on resident frames: same kernels, same statistics as the
-    // host-plane normalize() of variational_mt.h).  Every GPU holds the loaded frames -- 133 frames of 1024x436 are 0.7 GB -- so no GPU waits for another;
-    // the statistics are those of GPU 0 (identical on all: same data, same deterministic kernels).  One thread per GPU: it creates the context while the
-    // io pool decodes, then uploads every frame the moment its decode task has finished (`ready`), and normalises when the last one is there.
+    // The frames go to the GPUs once and are normalised there (:673; the three parts of sfa_sequence_normalize: same kernels, same statistics as the host-plane
+    // normalize() of variational_mt.h).  GPU g holds the frames gpu_frames[g] of its own windows (+ the halo its boundary jets share with the neighbour): about 1 / N
+    // of the sequence.  The statistics are those of ALL loaded frames: every GPU forms the six fp64 sums of the frames it holds (a deterministic kernel: a frame two
+    // GPUs hold gets the same bits from both), the sums are collected per frame on the host, and the moment the last frame's sums are in, the statistics are formed
+    // from them in frame order -- one set of doubles for every GPU.  One thread per GPU: it creates the context while the io pool decodes, uploads each of its frames the
+    // moment its decode task has finished (`ready`), normalises its frames once the statistics are known and releases its workers (`gpu_ready`); no GPU waits for
+    // another GPU's uploads beyond the sums of the frames it does not hold itself.
     std::mutex ready_mu;
     std::condition_variable ready_cv;
     std::vector<char> frame_ready(frames, 0);
     bool ingest_abort = false, size_known = false;
     int width = 0, height = 0;
+    std::vector<double> frame_sums((size_t)6 * n_loaded, 0.0);
+    std::vector<char> have_sums(n_loaded, 0), gpu_ready(ngpu, 0);
+    int n_have = 0;
+    bool stats_known = false;
+    double stat_avg[3] = {0, 0, 0}, stat_std[3] = {1, 1, 1};
+    std::vector<double> upload_bytes(ngpu, 0.0), upload_done_s(ngpu, 0.0), ready_s(ngpu, 0.0);
+    auto seconds_since_begin = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
     const bool upload_while_decoding = !(((!params.exists("raw") || params.parameter<float>("raw_weight", "1.0") == 1.0f)) && scale != 1);   // a rescaled sequence exists only after all frames are in
     std::vector<std::thread> up;
     for (int g = 0; g < ngpu; g++)
         up.emplace_back([&, g] {
+            const FrameRange fr = gpu_frames[g];
+            const int n_mine = fr.hi - fr.lo;
             int rc = sfa_ctx_create(device_of(g), &seq_ctx[g]);
+            auto fail = [&] {                                                         // nobody may wait for this GPU's sums or readiness
+                seq_err[g] = seq_ctx[g] ? sfa_last_error(seq_ctx[g]) : sfa_last_error(nullptr);
+                { std::lock_guard<std::mutex> l(ready_mu); ingest_abort = true; }
+                ready_cv.notify_all();
+            };
+            if (rc != SFA_OK) { fail(); return; }
+            if (n_mine <= 0) return;                                                 // more GPUs than windows
             {
                 std::unique_lock<std::mutex> l(ready_mu);
                 ready_cv.wait(l, [&] { return size_known || ingest_abort; });
                 if (ingest_abort) return;
             }
-            if (rc == SFA_OK) rc = sfa_sequence_create(seq_ctx[g], width, height, n_loaded, &seq_dev[g]);
-            for (int f = 0; f < n_loaded && rc == SFA_OK; f++) {
+            rc = sfa_sequence_create(seq_ctx[g], width, height, n_mine, &seq_dev[g]);
+            for (int f = fr.lo; f < fr.hi && rc == SFA_OK; f++) {
                 {
                     std::unique_lock<std::mutex> l(ready_mu);
                     ready_cv.wait(l, [&] { return frame_ready[start_f + f] || ingest_abort; });
                     if (ingest_abort) return;
                 }
-                rc = sfa_sequence_upload(seq_dev[g], f, seq[start_f + f]->c1, seq[start_f + f]->stride);
+                rc = sfa_sequence_upload(seq_dev[g], f - fr.lo, seq[start_f + f]->c1, seq[start_f + f]->stride);
             }
-            if (rc == SFA_OK) rc = sfa_sequence_normalize(seq_dev[g], 0, n_loaded, &stat_avg[3 * g], &stat_std[3 * g]);
-            if (rc != SFA_OK) seq_err[g] = seq_ctx[g] ? sfa_last_error(seq_ctx[g]) : sfa_last_error(nullptr);
+            std::vector<double> mine((size_t)6 * n_mine);
+            if (rc == SFA_OK) rc = sfa_sequence_frame_sums(seq_dev[g], 0, n_mine, mine.data());      // (waits for the uploads: one stream)
+            if (rc != SFA_OK) { fail(); return; }
+            {
+                std::unique_lock<std::mutex> l(ready_mu);
+                upload_bytes[g] = (double)n_mine * 3 * width * height * sizeof(float);
+                upload_done_s[g] = seconds_since_begin();
+                for (int f = fr.lo; f < fr.hi; f++)
+                    if (!have_sums[f]) {                                             // a halo frame: whoever is first; the other GPU's sums are the same bits
+                        std::copy(mine.begin() + 6 * (f - fr.lo), mine.begin() + 6 * (f - fr.lo) + 6, frame_sums.begin() + 6 * f);
+                        have_sums[f] = 1;
+                        n_have++;
+                    }
+                if (n_have == n_loaded && !stats_known) {                            // variational_mt.cpp:41-52 over all loaded frames, in frame order
+                    (void)sfa_normalize_statistics(frame_sums.data(), n_loaded, width, height, stat_avg, stat_std);
+                    stats_known = true;
+                }
+                ready_cv.notify_all();
+                ready_cv.wait(l, [&] { return stats_known || ingest_abort; });
+                if (ingest_abort) return;
+            }
+            rc = sfa_sequence_apply_normalization(seq_dev[g], 0, n_mine, stat_avg, stat_std);
+            if (rc != SFA_OK) { fail(); return; }
+            { std::lock_guard<std::mutex> l(ready_mu); gpu_ready[g] = 1; ready_s[g] = seconds_since_begin(); }
+            ready_cv.notify_all();
         });
     auto release_sequences = [&] {
         for (int g = 0; g < ngpu; g++) {
             if (seq_dev[g]) sfa_sequence_destroy(seq_dev[g]);
             if (seq_ctx[g]) sfa_ctx_destroy(seq_ctx[g]);
+            seq_dev[g] = nullptr; seq_ctx[g] = nullptr;
         }
     };
     auto abort_ingest = [&] {
@@ -385,10 +458,27 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
 
     // ---- the GPU threads started above have been uploading beside the decoding; what is left of the ingest is the normalisation ------------------
     const auto t_norm = std::chrono::steady_clock::now();
-    for (auto &t : up) t.join();                                                     // the GPU threads uploaded every frame as it was decoded; here they finish normalising
-    for (int g = 0; g < ngpu; g++)
-        if (!seq_err[g].empty()) { std::cerr << "GPU " << device_of(g) << ": " << seq_err[g] << std::endl; release_sequences(); return 4; }
-    publish_normalization(params, &stat_avg[0], &stat_std[0]);                       // the slow_flow_img_norm_* parameters (variational_mt.cpp:71-84)
+    auto ingest_failed = [&]() -> bool {
+        bool any = false;
+        for (int g = 0; g < ngpu; g++)
+            if (!seq_err[g].empty()) { std::cerr << "GPU " << device_of(g) << ": " << seq_err[g] << std::endl; any = true; }
+        return any;
+    };
+    if (todo.empty()) {                                                              // nothing to refine (-resume over finished jets): the statistics are not needed either
+        std::lock_guard<std::mutex> l(ready_mu);
+        ingest_abort = true;
+    } else {
+        std::unique_lock<std::mutex> l(ready_mu);                                    // the GPU threads uploaded their frames as they were decoded; the last frame's sums make the statistics
+        ready_cv.wait(l, [&] { return stats_known || ingest_abort; });
+    }
+    ready_cv.notify_all();
+    if (ingest_abort) {
+        for (auto &t : up) t.join();
+        const bool err = ingest_failed();
+        release_sequences();
+        if (err) return 4;
+    }
+    if (!todo.empty()) publish_normalization(params, stat_avg, stat_std);            // the slow_flow_img_norm_* parameters (variational_mt.cpp:71-84)
     const double normalize_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_norm).count();
     {
         std::ofstream infos((params.output + "config.cfg").c_str());                 // :684-688
@@ -396,19 +486,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     }
     const double ingest_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 
-    // ---- the windows to refine: forward and backward of every jet (:706-1047) --------------------------------------
-    std::vector<Window> todo;
-    for (unsigned j = start_j; j < end_j; j++) {
-        const int f = j * steps;
-        string fwd, bwd;
-        flow_files(j, fwd, bwd);
-        if (!opt.resume_frame || !file_exists(fwd)) todo.push_back(Window(j, false, fwd));
-        else std::cout << "Forward flow from frame " << start + f << " to " << start + f * skip + steps * skip << " already exist!" << std::endl;
-        if (!opt.resume_frame || !file_exists(bwd)) todo.push_back(Window(j, true, bwd));
-        else std::cout << "Backward flow from frame " << start + f * skip << " to " << start + f * skip + steps * skip << " already exist!" << std::endl;
-    }
-
-    const int batch = std::max(1, std::min(64, params.parameter<int>("gpu_batch", "32")));
+    const int batch = params.parameter<int>("gpu_batch", "32");                      // 1 .. 64: checked before anything was read
     const int F = 2 * ref + 1;
     const bool backward_forward_only = params.exists("method") && params.parameter("method") == "forward";   // :1019-1020
     const bool occ_on = params.parameter<bool>("slow_flow_occlusion_reasoning", "0");
@@ -420,11 +498,8 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
 
     std::mutex io_mu;
     std::atomic<bool> failed(false);
-    // `gpu_streams` workers per GPU (default 2), each with its own context = HIP stream: two lockstep groups fill each other's
-    // ramp-up / drain phases (the reference runs its windows from `threads` OpenMP threads the same way, slow_flow.cpp:706)
-    const int streams = std::max(1, std::min(4, params.parameter<int>("gpu_streams", "2")));
-    const std::vector<WorkerPlan> plan = plan_workers(todo.size(), ngpu, streams);
     TaskPool out_pool(io_threads);
+    std::vector<double> first_refine_s(ngpu, -1.0);                                  // when the first worker of a GPU started refining (seconds since the run began)
 
     // what happens to a finished window off the GPU worker's thread: flow * steps -> .flo, colour PNG, EPE / AAE, occlusion images
     auto emit = [&](std::shared_ptr<WindowResult> r) {
@@ -461,6 +536,13 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         sfa_ctx *ectx = nullptr;                                                     // the EpicFlow helper's context (deep_matching 1 only)
         if (enable_dm && sfa_ctx_create(device, &ectx) != SFA_OK) { std::lock_guard<std::mutex> l(io_mu); std::cerr << sfa_last_error(nullptr) << std::endl; failed = true; sfa_ctx_destroy(ctx); return; }
         (void)sfa_ctx_set_verbose(ctx, verbose_changes ? 1 : 0);
+        {                                                                            // this GPU's frames are resident and normalised
+            std::unique_lock<std::mutex> l(ready_mu);
+            ready_cv.wait(l, [&] { return gpu_ready[wp.gpu] || ingest_abort; });
+            if (ingest_abort) { failed = true; if (ectx) sfa_ctx_destroy(ectx); sfa_ctx_destroy(ctx); return; }
+            if (first_refine_s[wp.gpu] < 0) first_refine_s[wp.gpu] = seconds_since_begin();
+        }
+        const int frame0 = gpu_frames[wp.gpu].lo;                                    // the GPU's resident sequence starts at this frame of the loaded range
         ParameterList tp(params);                                                    // one copy per thread (:708)
         // EpicFlow's interpolation of the matches of one window (:801-863 / :960-1004), per single frame step.  It runs on a helper thread with a context of its
         // own (the library's contexts are thread-compatible, not thread-safe), one batch ahead of the refinement: while the GPU refines batch n the host prepares
@@ -550,7 +632,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                     const int f = wd.jet * steps;
                     // the window's frames in the loaded sequence: forward seq[f + k]; backward seq_back[frames - 1 - f - 3*steps + k] = seq[f + 3*steps - k] (:590-591, :721-724)
                     std::vector<int> idx(F);
-                    for (int k = 0; k < F; k++) idx[k] = (wd.backward ? f + 3 * steps - k : f + k) - (int)start_f;
+                    for (int k = 0; k < F; k++) idx[k] = (wd.backward ? f + 3 * steps - k : f + k) - (int)start_f - frame0;
                     const float *chw[3] = {channel_weights->c1, channel_weights->c2, channel_weights->c3};
                     image_t *iwx = enable_dm ? inits[e].wx : nullptr, *iwy = enable_dm ? inits[e].wy : nullptr;
                     if (enable_dm && inits[e].rc != SFA_OK) rc = inits[e].rc;
@@ -612,6 +694,8 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     for (const WorkerPlan &wp : plan) th.emplace_back(worker, wp);
     for (auto &t : th) t.join();
     const double compute_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_compute).count();
+    for (auto &t : up) if (t.joinable()) t.join();
+    if (ingest_failed()) failed = true;
     out_pool.wait_all();
     const double total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 
@@ -626,7 +710,18 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
         tj << "\n]\n";
         std::ofstream rj((params.output + "run.json").c_str());
         rj << "{\"windows\": " << todo.size() << ", \"gpus\": " << ngpu << ", \"streams\": " << streams << ", \"batch\": " << batch << ", \"io_threads\": " << io_threads
-           << ", \"decode_seconds\": " << decode_seconds << ", \"normalize_seconds\": " << normalize_seconds << ", \"ingest_seconds\": " << ingest_seconds << ", \"refine_seconds\": " << compute_seconds << ", \"total_seconds\": " << total_seconds << "}\n";
+           << ", \"decode_seconds\": " << decode_seconds << ", \"normalize_seconds\": " << normalize_seconds << ", \"ingest_seconds\": " << ingest_seconds << ", \"refine_seconds\": " << compute_seconds << ", \"total_seconds\": " << total_seconds;
+        // per GPU: the frames it was sent (its windows' frames + halo), when the last of them had arrived, when its frames were normalised and when its first worker
+        // began to refine -- all in seconds since the run began.  The whole sequence is "sequence_bytes"
+        double last_upload = 0, first_refine = -1;
+        rj << ", \"sequence_bytes\": " << (double)n_loaded * 3 * width * height * sizeof(float) << ", \"per_gpu\": [";
+        for (int g = 0; g < ngpu; g++) {
+            rj << (g ? ", " : "") << "{\"gpu\": " << g << ", \"device\": " << device_of(g) << ", \"frames\": [" << gpu_frames[g].lo << ", " << gpu_frames[g].hi << "], \"upload_bytes\": " << upload_bytes[g]
+               << ", \"upload_done_s\": " << upload_done_s[g] << ", \"ready_s\": " << ready_s[g] << ", \"first_refine_s\": " << first_refine_s[g] << "}";
+            last_upload = std::max(last_upload, upload_done_s[g]);
+            if (first_refine_s[g] >= 0 && (first_refine < 0 || first_refine_s[g] < first_refine)) first_refine = first_refine_s[g];
+        }
+        rj << "], \"first_refine_s\": " << first_refine << ", \"last_upload_done_s\": " << last_upload << "}\n";
     }
     release_sequences();
     for (unsigned f = start_f; f < end_f; f++) color_image_delete(seq[f]);

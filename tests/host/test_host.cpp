@@ -288,6 +288,42 @@ int main(int argc, char **argv) {
                 }
         CHECK(plan_workers(5, 0, 0).size() == 1);
     }
+    // ---- shard.h: which frames a GPU is sent.  Config 4 on a full node: 64 jets x 2 directions, S = 3 (steps = ref = 2): 133 frames; jet j reads
+    //      2 j .. 2 j + 4 forwards and 2 j + 2 .. 2 j + 6 backwards (slow_flow.cpp:721-724, :590-591) ---------------------------------------------------------
+    {
+        const int jets = 64, steps = 2, ref = 2, n_frames = 1 + (jets + 2) * steps;
+        std::vector<std::pair<int, int>> wf;
+        for (int j = 0; j < jets; j++) { wf.push_back({j * steps, j * steps + 2 * ref}); wf.push_back({j * steps + steps, j * steps + 3 * steps}); }
+        const std::vector<WorkerPlan> plan = plan_workers(wf.size(), 8, 2);
+        const std::vector<FrameRange> fr = plan_frames(wf, plan, 8, n_frames);
+        CHECK(fr.size() == 8 && n_frames == 133);
+        long total = 0;
+        for (int g = 0; g < 8; g++) {
+            // GPU g: jets 8 g .. 8 g + 7 -> frames 16 g .. 16 g + 14 + 6 (inclusive): 21 frames, of which the neighbour holds 5 too (the halo)
+            CHECK(fr[g].lo == 16 * g && fr[g].hi == (g == 7 ? n_frames : 16 * g + 21));
+            total += fr[g].hi - fr[g].lo;
+            for (const WorkerPlan &w : plan)
+                if (w.gpu == g)
+                    for (size_t i = w.lo; i < w.hi; i++) CHECK(wf[i].first >= fr[g].lo && wf[i].second < fr[g].hi);     // every window finds its frames on its GPU
+        }
+        CHECK(total == 8 * 21 && total * 8 < 2 * 8 * n_frames);                   // 168 frame uploads instead of 8 x 133 (16 %)
+        // coverage without gaps whatever is left to do (-resume): every loaded frame is summed by somebody
+        for (int ngpu = 1; ngpu <= 8; ngpu++)
+            for (int st = 1; st <= 2; st++)
+                for (int keep = 1; keep <= 7; keep++) {
+                    std::vector<std::pair<int, int>> some;
+                    for (size_t i = 0; i < wf.size(); i++) if ((int)(i * 2654435761u % 7) < keep) some.push_back(wf[i]);
+                    const std::vector<WorkerPlan> p = plan_workers(some.size(), ngpu, st);
+                    const std::vector<FrameRange> r = plan_frames(some, p, ngpu, n_frames);
+                    std::vector<int> cover(n_frames, 0);
+                    for (int g = 0; g < ngpu; g++) for (int f = r[g].lo; f < r[g].hi; f++) cover[f]++;
+                    for (int f = 0; f < n_frames; f++) CHECK(cover[f] >= 1);
+                    for (const WorkerPlan &w : p)
+                        for (size_t i = w.lo; i < w.hi; i++) CHECK(some[i].first >= r[w.gpu].lo && some[i].second < r[w.gpu].hi);
+                }
+        const std::vector<FrameRange> none = plan_frames({}, plan_workers(0, 4, 2), 4, n_frames);
+        for (const FrameRange &f : none) CHECK(f.lo == f.hi);
+    }
     // ---- shard.h: adaptive frame rates (slow_flow.cpp:322-352), evaluated by hand from the reference's text -----------------------------
     {
         AdaptiveRates r = adaptive_rates(1.0, 2.0, 4, 10, 1);      // hfr = round(2/1) = 2 (10 % 2 == 0); lfr = min(10, 8) = 8 -> 9 -> 10; min(10/1, 10)

@@ -408,6 +408,15 @@ def test_driver_refuses_a_frame_of_another_size(host_build, tmp_path):
         assert r.returncode == 3 and "different sizes" in r.stderr, r.stdout + r.stderr
 
 
+def test_driver_refuses_gpu_batch_beyond_a_job(host_build, tmp_path):
+    """a lockstep job takes at most 64 windows (one 64-bit mask of the windows still iterating): the driver says so instead of clamping the key;
+    checked before a frame is read, so no GPU is needed"""
+    cfg = tmp_path / "run.cfg"
+    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t1\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\nslow_flow_S\t2\ngpu_batch\t65\n" % (tmp_path, tmp_path))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "gpu_batch 65 is out of range" in r.stderr, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_driver_multi_gpu_path_rehearsed_on_one_card(host_build, tmp_path):
     """the driver's N-GPU path (a resident, normalised sequence per GPU; `gpu_streams` workers per GPU; windows dealt out by plan_workers) cannot run on
@@ -436,6 +445,17 @@ def test_driver_multi_gpu_path_rehearsed_on_one_card(host_build, tmp_path):
     assert len(flo) == 2 * jets
     for f in flo:
         assert (tmp_path / "out_one" / f).read_bytes() == (tmp_path / "out_three" / f).read_bytes(), f
+    # the ingest is sharded: a GPU is sent the frames of its own windows + the halo it shares with its neighbour, not the sequence; the statistics
+    # are formed once from per-frame sums (the same .flo as the one-GPU run, above, says the normalisation is the same bit for bit)
+    one, three = (json.load(open(str(tmp_path / ("out_" + n) / "run.json"))) for n in ("one", "three"))
+    seq_bytes = nframes * 3 * w * h * 4
+    assert one["sequence_bytes"] == seq_bytes and [g["frames"] for g in one["per_gpu"]] == [[0, nframes]] and one["per_gpu"][0]["upload_bytes"] == seq_bytes
+    # 14 windows on 6 workers: GPU 0 gets windows 0..3 (jets 0, 1 -> frames 0..4), GPU 1 windows 4..8 (jets 2, 3 and jet 4 forwards -> 2..6), GPU 2 the rest
+    # (jet 4 backwards, jets 5, 6 -> 5..9)
+    assert [g["frames"] for g in three["per_gpu"]] == [[0, 5], [2, 7], [5, nframes]], three["per_gpu"]
+    for g in three["per_gpu"]:
+        assert g["upload_bytes"] == (g["frames"][1] - g["frames"][0]) * 3 * w * h * 4 and g["upload_done_s"] <= g["ready_s"] <= g["first_refine_s"]
+    assert sum(g["upload_bytes"] for g in three["per_gpu"]) < 3 * seq_bytes * 0.6          # round 4: three whole sequences
 
 
 @pytest.mark.gpu
