@@ -209,7 +209,7 @@ __device__ __forceinline__ v2f sor_point2(v2f self, v2f right, v2f top, v2f bott
 // PF: steps by which the ring-fed sweeps read their operand rows ahead of their use (register slots NSL).  One step ahead the 16-byte LDS reads are consumed
 // ~10 instructions after their issue and the wave stalls on them in every step -- with two waves per SIMD nobody covers that; two steps ahead they have a whole
 // step to land.  PF = 2 is safe where every stage has >= 2 sweeps (tools/sim_sor_chain.py ring_hazards: a 1-sweep stage would read a row before it is written).
-template <int F, int CH, int PD, bool SHORT = false, int ROLE = 0, int OPS0 = 0, int OPR = 1, int OPROWB = 0, int KG = 1, int PF = 1>
+template <int F, int CH, int PD, bool SHORT = false, int ROLE = 0, int OPS0 = 0, int OPR = 1, int OPROWB = 0, int KG = 1, int PF_ = 1>
 __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char *lds, int ring_in, int ring_out, int tvb, int esb, int dummy, int job, int b,
                                               int k0, int s_start, int lead, int lane, int kap0 = 0, int w = 0) {
     constexpr int OPPLANE = OPR * OPROWB;
@@ -250,8 +250,17 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
     // a row, and the operands of the current and the next step
     unsigned wr_off = 0, rd_off[F];
     unsigned rd_lane[F];
-    constexpr int NSL = PF == 1 ? 2 : 4;                              // register slots per ring-fed sweep: a power of two that divides the unrolled body
-    static_assert(PF >= 1 && PF < NSL && (PD * CH) % NSL == 0 && CH % NSL == 0, "slot of a step = its position in the chunk");
+    // PF == CH ("chunk-ahead", the one-sweep stages of the lone-solve shapes): at the top of chunk c -- right behind the barrier -- a ring-fed stage reads the rows of
+    // its steps 4 c + 1 .. 4 c + 4 in one go: all of them are in the ring by then (row i + w - 2 kappa, written by the first stage in its own chunk, at least one
+    // interval earlier for every stage w >= 1 with kappa >= w: ring_hazards, mode "chunk"), step 4 c runs on what the previous chunk's top fetched, and no step waits
+    // for an LDS round trip on its critical path any more.  One step ahead the two 16-byte reads were issued behind the step's result and consumed ~2 instructions
+    // later: every step of a lone solve -- a single dependent chain per wave -- carried a full LDS latency.
+    constexpr bool CHUNK_AHEAD = PF_ == CH && ROLE == 2;
+    static_assert(!(PF_ == CH && ROLE == 1 && F > 1), "the first stage's trailing sweeps read rows the wave itself wrote at most 2 kappa steps ago");
+    constexpr int PF = (PF_ == CH && !CHUNK_AHEAD) ? 1 : PF_;         // (the first stage of a chunk-ahead shape has no ring-fed sweep at all)
+    constexpr int NSL = CHUNK_AHEAD ? 2 * CH : PF == 1 ? 2 : 4;       // register slots per ring-fed sweep: a power of two that divides the unrolled body
+    static_assert(PF >= 1 && PF < NSL && (PD * CH) % NSL == 0 && (CHUNK_AHEAD || CH % NSL == 0), "slot of a step = its position in the unrolled body");
+    constexpr int PRE = CHUNK_AHEAD ? 1 : PF;                         // rows read before the first barrier: those of steps 0 .. PRE - 1
     float4 la[F][NSL], lb[F][NSL];
 #pragma unroll
     for (int f = 0; f < F; f++) {
@@ -265,7 +274,7 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
         for (int q = 0; q < NSL; q++) la[f][q] = lb[f][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ROLE != 0 && f >= F0) {
 #pragma unroll
-            for (int q = 0; q < PF; q++) {                                  // the rows of steps 0 .. PF - 1
+            for (int q = 0; q < PRE; q++) {                                 // the rows of steps 0 .. PRE - 1
                 la[f][q] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);
                 lb[f][q] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
                 rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
@@ -310,6 +319,16 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
                     for (int fi = 0; fi <= F; fi++) fl[j][fi] = tvp[(par * CH + j) * (F + 1) + fi];
                 }
             }
+            if (CHUNK_AHEAD) {                                       // the rows of the chunk's steps 1 .. CH - 1 and of the next chunk's first step
+#pragma unroll
+                for (int f = 0; f < F; f++)
+#pragma unroll
+                    for (int j = 1; j <= CH; j++) {
+                        la[f][(q * CH + j) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);
+                        lb[f][(q * CH + j) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
+                        rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
+                    }
+            }
 #ifdef SFA_CHAIN_TIMING
             {   // how long the chunk's LDS reads take (diagnosis only: the wait is forced here)
                 unsigned long long ta = __builtin_readcyclecounter();
@@ -338,8 +357,8 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
                     const float2 right = f == 0 ? right0 : sh[f > 0 ? f - 1 : 0];
                     const float2 bottom = f == 0 ? bottom0 : res[f > 0 ? f - 1 : 0];
                     const bool ringfed = ROLE != 0 && f >= F0;
-                    const float4 &SA = ringfed ? la[f][j % NSL] : f == 0 ? sa0[ROLE == 2 ? 0 : j0] : sa1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
-                    const float4 &SB = ringfed ? lb[f][j % NSL] : f == 0 ? sb0[ROLE == 2 ? 0 : j0] : sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
+                    const float4 &SA = ringfed ? la[f][(CHUNK_AHEAD ? q * CH + j : j) % NSL] : f == 0 ? sa0[ROLE == 2 ? 0 : j0] : sa1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
+                    const float4 &SB = ringfed ? lb[f][(CHUNK_AHEAD ? q * CH + j : j) % NSL] : f == 0 ? sb0[ROLE == 2 ? 0 : j0] : sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0];
                     const v2f xn = sor_point2<(F >= 2)>(f2v(selfv[f]), f2v(right), f2v(sh[f]), f2v(bottom), f2v(res[f]), hlz[f], SA, SB, omega);
                     nres[f] = make_float2(xn.x, xn.y);
                     selfv[f] = right;
@@ -364,10 +383,12 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
                 for (int f = 0; f < F; f++) {
                     const bool ringfed = ROLE != 0 && f >= F0;
                     if (ringfed) {
-                        hlz[f] = (v2f){lb[f][j % NSL].z, lb[f][j % NSL].w};
-                        la[f][(j + PF) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);              // the row of step + PF
-                        lb[f][(j + PF) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
-                        rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
+                        hlz[f] = (v2f){lb[f][(CHUNK_AHEAD ? q * CH + j : j) % NSL].z, lb[f][(CHUNK_AHEAD ? q * CH + j : j) % NSL].w};
+                        if (!CHUNK_AHEAD) {
+                            la[f][(j + PF) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);              // the row of step + PF
+                            lb[f][(j + PF) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
+                            rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
+                        }
                     } else if (f == 0) hlz[0] = (v2f){sb0[ROLE == 2 ? 0 : j0].z, sb0[ROLE == 2 ? 0 : j0].w};
                     else hlz[f] = (v2f){sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0].z, sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0].w};
                 }
@@ -842,7 +863,11 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
 #ifndef SFA_CHAIN_PF
 #define SFA_CHAIN_PF 2
 #endif
-    constexpr int PF = (FA >= 2 && (NB_ == 0 || FB >= 2) && !SHORT) ? SFA_CHAIN_PF : 1;      // read-ahead of the operand ring (chain_compute)
+#ifndef SFA_CHAIN_PF1
+#define SFA_CHAIN_PF1 CH                                             // one-sweep stages: the whole chunk's rows at its top (set to 1 for the step-ahead form)
+#endif
+    // read-ahead of the operand ring (chain_compute): two steps where every stage has at least two sweeps; a chunk where every stage has one (the lone solve)
+    constexpr int PF = (FA >= 2 && (NB_ == 0 || FB >= 2) && !SHORT) ? SFA_CHAIN_PF : (FA == 1 && NB_ == 0 && !SHORT) ? SFA_CHAIN_PF1 : 1;
     if (L::OPRING) {
         if (w == 0)      chain_compute<FA, CH, PD, SHORT, 1, L::ops0, L::OPR, L::OPROWB, S::KG, PF>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, 0, 0);
         else if (w < NA) chain_compute<FA, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PF>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);

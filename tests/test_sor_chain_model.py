@@ -69,4 +69,7 @@ def test_operand_ring_depth_and_read_ahead(shape):
     pf = m.ring_prefetch(S)
     assert opr >= oprmin and m.ring_hazards(S, opr, pf) == []
     assert m.ring_hazards(S, oprmin, 1) == [] and {b[0] for b in m.ring_hazards(S, oprmin - 1, 1)} == {"war"}
-    assert {b[0] for b in m.ring_hazards(S, opr, pf + 1)} & {"raw", "raw-self", "raw-in"}
+    if pf == "chunk":                                # one step more: the row of step 4 c + 5 at the top of chunk c is not written yet for the second stage
+        assert m.ring_hazards(S, opr, 1) == [] and {b[0] for b in m.ring_hazards(S, opr, 2)} & {"raw", "raw-in"}
+    else:
+        assert {b[0] for b in m.ring_hazards(S, opr, pf + 1)} & {"raw", "raw-self", "raw-in"}

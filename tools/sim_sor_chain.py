@@ -62,8 +62,12 @@ def ring_rows(S):
 
 
 def ring_prefetch(S):
-    """k_sor_chain's PF: steps by which the ring-fed sweeps read their rows ahead (2 where every stage has at least two sweeps and the workgroup fewer than 8 stages)"""
-    return 2 if S.FA >= 2 and (S.NB_ == 0 or S.FB >= 2) and S.NW < 8 else 1
+    """k_sor_chain's PF: steps by which the ring-fed sweeps read their rows ahead: 2 where every stage has at least two sweeps, "chunk" (the rows of steps 4 c + 1 ..
+    4 c + 4 at the top of chunk c) where every stage has one; 1 otherwise and for workgroups of 8 stages or more"""
+    if S.NW >= 8: return 1
+    if S.FA >= 2 and (S.NB_ == 0 or S.FB >= 2): return 2
+    if S.FA == 1 and S.NB_ == 0: return "chunk"
+    return 1
 
 
 def ring_hazards(S, OPR, PF, nsteps=600):
@@ -79,8 +83,14 @@ def ring_hazards(S, OPR, PF, nsteps=600):
             kap = S.kw(w) + f
             if w == 0 and f == 0: continue                                   # the group's first sweep loads from memory
             for i in range(nsteps):
-                rho, issue = i + w - 2 * kap, i - PF
-                t_read = 0 if issue < 0 else LEAD + w + issue // CH
+                rho = i + w - 2 * kap
+                if PF == "chunk":                                            # read at the top of the chunk of step i - 1 (step 0: before the first barrier); ring-fed stages w >= 1 only
+                    if w == 0: bad.append(("raw-self", w, kap, i)); continue
+                    issue = -1 if i == 0 else (i - 1) // CH * CH - 1         # "behind step issue": the chunk top lies behind the last step of the chunk before
+                    t_read = 0 if i == 0 else LEAD + w + (i - 1) // CH
+                else:
+                    issue = i - PF
+                    t_read = 0 if issue < 0 else LEAD + w + issue // CH
                 if rho >= 0:                                                 # read after write (rows < 0 are never written: the ring's initial zeros)
                     if w == 0 and not rho <= issue: bad.append(("raw-self", w, kap, i))          # the first stage's own trailing sweeps: program order inside the wave
                     if w > 0 and not w_st(rho) < t_read: bad.append(("raw", w, kap, i))
