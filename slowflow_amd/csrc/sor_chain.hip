@@ -116,12 +116,42 @@ __device__ unsigned long long g_chain_timing[64 * 8 * 16];
 #endif
 // chunks by which a group with an operand ring starts early: the first stage's first step then sits at column <= 1 - KG - ... (s_start <= -1 - 4 SHIFT)
 __host__ __device__ constexpr int chain_start_shift(int KG) { return KG <= 10 ? 2 : 4; }
+#ifndef SFA_CHAIN_PF
+#define SFA_CHAIN_PF 2
+#endif
+#ifndef SFA_CHAIN_PFL
+#define SFA_CHAIN_PFL 3
+#endif
+#ifndef SFA_CHAIN_PF1
+#define SFA_CHAIN_PF1 4                                              // = CH: one-sweep stages read a whole chunk's rows at its top (1: the step-ahead form)
+#endif
 // shape of a workgroup: NA stages of FA sweeps, then NB_ stages of FB sweeps
 template <int FA, int NA, int FB, int NB_>
 struct ChainShape {
     static constexpr int NW = NA + NB_, KG = NA * FA + NB_ * FB, FMAX = FA > FB ? FA : FB;
     __host__ __device__ static constexpr int Fw(int w) { return w < NA ? FA : FB; }
     __host__ __device__ static constexpr int kw(int w) { return w < NA ? w * FA : NA * FA + (w - NA) * FB; }   // sweeps of the group in front of wave w
+    // Read-ahead of the operand ring (chain_compute PF): steps between the LDS read of a ring-fed sweep's operand row and its use.  Every stage of >= 2 sweeps:
+    // the first stage 2 (its own trailing sweeps read rows the wave wrote itself at most 2 kappa steps ago), the later stages 3 (their rows are at least an
+    // interval old); every stage of one sweep (the lone solve): the whole chunk at its top (PF1 = CH); 8 stages and more (register budget) or mixed with
+    // one-sweep stages: one step.  tools/sim_sor_chain.py ring_prefetch / ring_hazards carry the same rule and check it against the barrier lockstep.
+    static constexpr bool MULTI = FA >= 2 && (NB_ == 0 || FB >= 2) && NW < 8, LONE = FA == 1 && NB_ == 0 && NW < 8;
+    static constexpr int PF0 = MULTI ? SFA_CHAIN_PF : LONE ? SFA_CHAIN_PF1 : 1;       // first stage (for one-sweep stages: nothing is ring-fed there)
+    static constexpr int PFL = MULTI ? SFA_CHAIN_PFL : LONE ? SFA_CHAIN_PF1 : 1;      // stages 1 ..
+    // Which stage a wave runs (wave 0 = IN, wave NW + 1 = OUT).  Waves i, i + 4, i + 8 of a workgroup share a SIMD.  Seven stages of 3,2,2,2,2,2,2 sweeps: nine
+    // waves -- SIMD 0 takes the two I/O waves and the 3-sweep first stage (wave 4), the other three SIMDs two 2-sweep stages each: at most 4 sweeps on a SIMD where
+    // the six-stage shape (3,3,3,2,2,2 on eight waves) puts 5.
+    static constexpr bool PERM9 = NW == 7 && NA == 1;
+#ifndef SFA_CHAIN_PERM6
+#define SFA_CHAIN_PERM6 0
+#endif
+    // six stages on eight waves: which stage shares a SIMD with which (pairs of waves (0,4) (1,5) (2,6) (3,7); 0 = IN, 7 = OUT).  0: stage = wave - 1 -- (IN, st3) (st0, st4)
+    // (st1, st5) (st2, OUT); 1: the first stage (the only one that loads from memory and fills the operand ring) beside the OUT wave instead of a compute wave --
+    // (IN, st3) (st2, st4) (st1, st5) (st0, OUT); 2: beside the IN wave -- (IN, st0) (st3, st4) (st1, st5) (st2, OUT)
+    __host__ __device__ static constexpr int stage_of_wave6(int wave) {
+        return SFA_CHAIN_PERM6 == 1 ? (wave == 1 ? 2 : wave == 3 ? 0 : wave - 1) : SFA_CHAIN_PERM6 == 2 ? (wave == 4 ? 0 : wave == 1 ? 3 : wave - 1) : wave - 1;
+    }
+    __host__ __device__ static constexpr int stage_of_wave(int wave) { return PERM9 ? (wave == 4 ? 0 : wave < 4 ? wave : wave - 1) : NW == 6 ? stage_of_wave6(wave) : wave - 1; }
 };
 
 // LDS map of a workgroup (bytes).  rings: [NW+1][2][CH][64] u64 (ring w = input of compute wave w; ring NW = output of the last one);
@@ -149,11 +179,14 @@ struct ChainLds {
     // tight at one step of read-ahead, and reading further ahead (chain_compute PF) only moves the last read earlier (tests/test_sor_chain_model.py).
     static constexpr int OPW = 64 + S::KG - 1, OPROWB = OPW * 16, OPRMIN = 3 * (S::NW - 1) + 2 * (S::KG - 1) + 9;
     static constexpr int ops0 = (dummy0 + DUMMY + 15) & ~15;
-    static constexpr bool OPR10 = ops0 + 2 * (OPRMIN + 1) * OPROWB + 32 <= 160 * 1024;
+    static constexpr bool OPR10 = ops0 + 2 * (OPRMIN + 1) * OPROWB + 32 <= 160 * 1024, OPR00 = ops0 + 2 * OPRMIN * OPROWB + 32 <= 160 * 1024;
+    // a shape that does not fit with the margin takes the bound itself, lowered by what its later stages read ahead beyond one step (the last read of a row -- last
+    // stage, last sweep -- comes PFL - 1 steps earlier): 3,2,2,2,2,2,2 needs 51 rows and 51 fit
+    static constexpr int OPRTIGHT = 3 * S::NW + 2 * S::KG + 2 - (S::PFL < CH ? S::PFL - 1 : 0);
 #ifndef SFA_X_OPR_CUT      // timing experiment only (rows BELOW the derived minimum: a slot may be rewritten before its last read)
 #define SFA_X_OPR_CUT 0
 #endif
-    static constexpr int OPR = (OPR10 ? OPRMIN + 1 : OPRMIN) - SFA_X_OPR_CUT, OPPLANE = OPR * OPROWB;
+    static constexpr int OPR = (OPR10 ? OPRMIN + 1 : OPR00 ? OPRMIN : OPRTIGHT) - SFA_X_OPR_CUT, OPPLANE = OPR * OPROWB;
     static constexpr bool OPRING = SFA_CHAIN_OPRING && S::KG <= 16 && ops0 + 2 * OPPLANE + 32 <= 160 * 1024;
     static constexpr int ticket = ops0 + (OPRING ? 2 * OPPLANE : 0);
     static constexpr int total = ticket + 16;
@@ -854,24 +887,17 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
 #endif
     if (wave == 0) { chain_in<S, CH, AH, PL>(a, smem, job, b, g, c_first, c_first_prev, lane); return; }
     if (wave == NW + 1) { chain_out<S, CH, AH, PUBD>(a, smem, job, b, g, c_first, lane); return; }
-    const int w = wave - 1;
+    const int w = S::stage_of_wave(wave);
     const int st = g * NW + w, k0 = g * S::KG + S::kw(w), O = k0 - st + 1;
     const int s_start = c_first * CH - O;
     const int ring_in = L::ring0 + w * L::RING, ring_out = ring_in + L::RING;
     const int tvb = L::tv0 + w * L::TVW, esb = L::es0 + w * L::ESW;
     constexpr bool SHORT = NW >= 8;                  // many waves per workgroup: fewer registers each
-#ifndef SFA_CHAIN_PF
-#define SFA_CHAIN_PF 2
-#endif
-#ifndef SFA_CHAIN_PF1
-#define SFA_CHAIN_PF1 CH                                             // one-sweep stages: the whole chunk's rows at its top (set to 1 for the step-ahead form)
-#endif
-    // read-ahead of the operand ring (chain_compute): two steps where every stage has at least two sweeps; a chunk where every stage has one (the lone solve)
-    constexpr int PF = (FA >= 2 && (NB_ == 0 || FB >= 2) && !SHORT) ? SFA_CHAIN_PF : (FA == 1 && NB_ == 0 && !SHORT) ? SFA_CHAIN_PF1 : 1;
+    constexpr int PF0 = S::PF0, PFL = S::PFL;              // read-ahead of the operand ring (ChainShape)
     if (L::OPRING) {
-        if (w == 0)      chain_compute<FA, CH, PD, SHORT, 1, L::ops0, L::OPR, L::OPROWB, S::KG, PF>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, 0, 0);
-        else if (w < NA) chain_compute<FA, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PF>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
-        else             chain_compute<FB, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PF>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
+        if (w == 0)      chain_compute<FA, CH, PD, SHORT, 1, L::ops0, L::OPR, L::OPROWB, S::KG, PF0>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, 0, 0);
+        else if (w < NA) chain_compute<FA, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PFL>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
+        else             chain_compute<FB, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PFL>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
     } else if (w < NA) chain_compute<FA, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
     else               chain_compute<FB, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
 }
@@ -906,6 +932,7 @@ static const ChainShapeInfo kChainShapes[] = {
     {10, 3, 10, 3, 0, 2, 2, 2},    // 10 stages of 3                 KG = 30
     {11, 3, 3, 2, 3, 2, 1, 1},     // 3 stages of 3 + 3 of 2         KG = 15: with the I/O waves 8 waves, two per SIMD, at most 5 sweeps on a SIMD (5 x 3: 6)
     {12, 2, 3, 3, 3, 2, 2, 2},     // 3 stages of 2 + 3 of 3         KG = 15
+    {13, 3, 1, 2, 6, 2, 1, 1},     // 1 stage of 3 + 6 of 2          KG = 15: nine waves, at most 4 sweeps on a SIMD (ChainShape::stage_of_wave)
     {16, 1, 5, 1, 0, 4, 1, 1},     // 5 stages of 1, one-interval poll / publication lags: the lone solve
 };
 
@@ -949,6 +976,7 @@ int chain_shift(int id) {
         case 11: return shape_shift<3, 3, 2, 3>();
         case 16: return shape_shift<1, 5, 1, 0>();
         case 12: return shape_shift<2, 3, 3, 3>();
+        case 13: return shape_shift<3, 1, 2, 6>();
     }
     return 0;
 }
@@ -999,6 +1027,7 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
         case 11: return chain_launch_shape<3, 3, 2, 3, 2, 1, 1>(c, a, nwg);
         case 16: return chain_launch_shape<1, 5, 1, 0, 4, 1, 1>(c, a, nwg);
         case 12: return chain_launch_shape<2, 3, 3, 3, 2>(c, a, nwg);
+        case 13: return chain_launch_shape<3, 1, 2, 6, 2, 1, 1>(c, a, nwg);
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }
 }

@@ -286,6 +286,8 @@ SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH":
                 "chain_1x5": {"SFA_SOR_CHAIN": "6"}, "chain_3x2": {"SFA_SOR_CHAIN": "8"}, "chain_5x6": {"SFA_SOR_CHAIN": "9"}, "chain_3x10": {"SFA_SOR_CHAIN": "10"},
                 # six stages of mixed width (15 sweeps per group: K = 15, 30; other K fall back): the operand ring at its minimum depth
                 "chain_3x3_2x3": {"SFA_SOR_CHAIN": "11"}, "chain_2x3_3x3": {"SFA_SOR_CHAIN": "12"},
+                # round 5: seven stages of 3,2,2,2,2,2,2 sweeps on nine waves (at most 4 sweeps on a SIMD), the operand ring at its tight depth of 51 rows
+                "chain_3x1_2x6": {"SFA_SOR_CHAIN": "13"},
                 # 1 x 5 with one-interval poll / publication lags (the lone-solve default; 11 runs with them too)
                 "chain_1x5_lags1": {"SFA_SOR_CHAIN": "16"}}
 

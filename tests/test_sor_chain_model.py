@@ -21,7 +21,8 @@ def _sim(mode, slack, pubd=2):
 
 
 CASES = [(40, 70, 12, (2, 3, 2, 0), 1), (50, 130, 9, (1, 3, 1, 0), 2), (45, 100, 14, (4, 1, 3, 1), 1), (33, 150, 12, (3, 2, 3, 0), 1), (37, 200, 10, (2, 5, 2, 0), 1),
-         (41, 140, 30, (3, 3, 2, 3), 1), (36, 90, 15, (2, 3, 3, 3), 2)]          # round 4: the six-stage shapes of mixed width (3,3,3,2,2,2 is the default from 97 bands on)
+         (41, 140, 30, (3, 3, 2, 3), 1), (36, 90, 15, (2, 3, 3, 3), 2),          # round 4: the six-stage shapes of mixed width (3,3,3,2,2,2 is the default from 97 bands on)
+         (43, 150, 30, (3, 1, 2, 6), 1)]                                          # round 5: seven stages of 3,2,2,2,2,2,2 sweeps on nine waves
 
 
 @pytest.mark.parametrize("mode", ["raw", "war"])
@@ -55,7 +56,7 @@ def test_chain_protocol_thresholds_are_tight_with_one_interval_too():
     assert bad > 0
 
 
-ALL_SHAPES = [(1, 3, 1, 0), (2, 3, 2, 0), (3, 5, 3, 0), (2, 5, 2, 0), (1, 5, 1, 0), (3, 2, 3, 0), (3, 3, 2, 3), (2, 3, 3, 3)]      # kChainShapes with an operand ring
+ALL_SHAPES = [(1, 3, 1, 0), (2, 3, 2, 0), (3, 5, 3, 0), (2, 5, 2, 0), (1, 5, 1, 0), (3, 2, 3, 0), (3, 3, 2, 3), (2, 3, 3, 3), (3, 1, 2, 6)]      # kChainShapes with an operand ring
 
 
 @pytest.mark.parametrize("shape", ALL_SHAPES)
@@ -67,9 +68,12 @@ def test_operand_ring_depth_and_read_ahead(shape):
     S = m.Shape(*shape)
     opr, oprmin = m.ring_rows(S)
     pf = m.ring_prefetch(S)
-    assert opr >= oprmin and m.ring_hazards(S, opr, pf) == []
+    assert opr > 0 and m.ring_hazards(S, opr, pf) == []
     assert m.ring_hazards(S, oprmin, 1) == [] and {b[0] for b in m.ring_hazards(S, oprmin - 1, 1)} == {"war"}
-    if pf == "chunk":                                # one step more: the row of step 4 c + 5 at the top of chunk c is not written yet for the second stage
+    if pf[1] == "chunk":                             # one step more: the row of step 4 c + 5 at the top of chunk c is not written yet for the second stage
         assert m.ring_hazards(S, opr, 1) == [] and {b[0] for b in m.ring_hazards(S, opr, 2)} & {"raw", "raw-in"}
     else:
-        assert {b[0] for b in m.ring_hazards(S, opr, pf + 1)} & {"raw", "raw-self", "raw-in"}
+        assert {b[0] for b in m.ring_hazards(S, opr, (pf[0] + 1, pf[1]))} & {"raw", "raw-self", "raw-in"}          # the first stage cannot read further ahead
+        assert {b[0] for b in m.ring_hazards(S, opr - 1, pf)} == {"war"} or opr > oprmin - (pf[1] - 1)               # a shape at its tight depth has no row to spare
+    if shape == (3, 1, 2, 6):
+        assert opr == 51 and {b[0] for b in m.ring_hazards(S, opr, (2, 2))} == {"war"}                            # ... and needs the later stages' third step of read-ahead

@@ -31,17 +31,7 @@ SLACK = int(os.environ.get("SIM_SLACK", "0"))      # > 0: weaken every wait thre
 
 def start_shift(S):
     """sor_chain.hip chain_start_shift / ChainLds::OPRING: chunks by which the groups of a shape with an operand ring start early"""
-    NW, KG, FMAX = S.NW, S.KG, S.FMAX
-    ring = 2 * CH * 64 * 8
-    tv0 = (NW + 1) * ring; tvw = 2 * CH * (FMAX + 1) * 8; es0 = tv0 + NW * tvw; esw = 2 * (FMAX - 1 if FMAX > 1 else 1) * CH * 8
-    dummy0 = es0 + NW * esw; dummy = 64 * 8 + esw
-    ops0 = (dummy0 + dummy + 15) & ~15
-    oprowb = (64 + KG - 1) * 16
-    oprmin = 3 * (NW - 1) + 2 * (KG - 1) + 9                       # ChainLds::OPRMIN; one spare row where it fits
-    opr = oprmin + 1 if ops0 + 2 * (oprmin + 1) * oprowb + 32 <= 160 * 1024 else oprmin
-    opplane = opr * oprowb
-    opring = KG <= 16 and ops0 + 2 * opplane + 32 <= 160 * 1024
-    return (2 if KG <= 10 else 4) if opring else 0
+    return (2 if S.KG <= 10 else 4) if ring_rows(S)[0] > 0 else 0
 
 
 def round_up(a, m):
@@ -57,17 +47,20 @@ def ring_rows(S):
     oprowb = (64 + KG - 1) * 16
     derived = 3 * NW + 2 * KG + 2                                  # the smallest depth without a write-after-read clash at one step of read-ahead (ring_hazards)
     oprmin = 3 * (NW - 1) + 2 * (KG - 1) + 9                       # ChainLds::OPRMIN = derived + 2: the kernel keeps two rows of margin, three where they fit
-    opr = oprmin + 1 if ops0 + 2 * (oprmin + 1) * oprowb + 32 <= 160 * 1024 else oprmin
-    return (opr, derived) if KG <= 16 and ops0 + 2 * opr * oprowb + 32 <= 160 * 1024 else (0, derived)
+    fits = lambda r: ops0 + 2 * r * oprowb + 32 <= 160 * 1024
+    pfl = ring_prefetch(S)[1]
+    tight = derived - (pfl - 1 if isinstance(pfl, int) else 0)     # ChainLds::OPRTIGHT: the bound itself, lowered by the later stages' read-ahead (3,2,2,2,2,2,2: 51 rows)
+    opr = oprmin + 1 if fits(oprmin + 1) else oprmin if fits(oprmin) else tight
+    return (opr, derived) if KG <= 16 and fits(opr) else (0, derived)
 
 
 def ring_prefetch(S):
-    """k_sor_chain's PF: steps by which the ring-fed sweeps read their rows ahead: 2 where every stage has at least two sweeps, "chunk" (the rows of steps 4 c + 1 ..
-    4 c + 4 at the top of chunk c) where every stage has one; 1 otherwise and for workgroups of 8 stages or more"""
-    if S.NW >= 8: return 1
-    if S.FA >= 2 and (S.NB_ == 0 or S.FB >= 2): return 2
-    if S.FA == 1 and S.NB_ == 0: return "chunk"
-    return 1
+    """ChainShape::PF0 / PFL: steps by which the ring-fed sweeps of the first stage / of the later stages read their rows ahead -- (2, 3) where every stage has at least
+    two sweeps, "chunk" (the rows of steps 4 c + 1 .. 4 c + 4 at the top of chunk c) where every stage has one; 1 otherwise and for workgroups of 8 stages or more"""
+    if S.NW >= 8: return (1, 1)
+    if S.FA >= 2 and (S.NB_ == 0 or S.FB >= 2): return (2, 3)
+    if S.FA == 1 and S.NB_ == 0: return ("chunk", "chunk")
+    return (1, 1)
 
 
 def ring_hazards(S, OPR, PF, nsteps=600):
@@ -78,7 +71,9 @@ def ring_hazards(S, OPR, PF, nsteps=600):
     bad = []
     w_in = lambda r: r // CH + AH
     w_st = lambda r: LEAD + r // CH
+    PF_of = PF if isinstance(PF, tuple) else (PF, PF)              # (first stage, later stages)
     for w in range(S.NW):
+        PF = PF_of[0] if w == 0 else PF_of[1]
         for f in range(S.Fw(w)):
             kap = S.kw(w) + f
             if w == 0 and f == 0: continue                                   # the group's first sweep loads from memory
