@@ -30,12 +30,12 @@ except OSError:
 try:
     head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "slowflow_amd/csrc", "include"], capture_output=True, text=True).stdout.strip()
-    prov["summarized_at_head"] = head
-    prov["kernel_sources_modified_since"] = bool(dirty)
+    prov["summarized_at_head"] = head or "(on the GPU box: no .git there; the raw counter files are too large to travel back)"
+    prov["kernel_sources_modified_since"] = bool(dirty) if head else None
     lib = os.path.join(root, "slowflow_amd", "libslowflow_amd.so")
     if os.path.exists(lib):
         prov["library_sha256_here"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()
-    if "--force" not in sys.argv:
+    if head and "--force" not in sys.argv:
         assert prov["collected_at_head"] in (None, "unknown") or head.startswith(prov["collected_at_head"]) or prov["collected_at_head"].startswith(head), \
             f"profiles of {tag} were collected at {prov['collected_at_head']}, this tree is at {head}: collect again (or --force)"
         assert not dirty, "kernel sources differ from HEAD: commit first, then collect and summarise (or --force)\n" + dirty
