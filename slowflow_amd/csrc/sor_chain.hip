@@ -401,7 +401,11 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
 #pragma unroll
                 for (int f = 0; f + 1 < F; f++) esp[(par * (F - 1) + f) * CH + j] = f2u(res[f].x, res[f].y);
                 rout[(par * CH + j) * 64] = f2u(res[F - 1].x, res[F - 1].y);
+#ifdef SFA_X_NORINGWR     // timing experiment only: the first stage does not fill the ring
+                if (false) {
+#else
                 if (ROLE == 1) {                                     // the row this step used goes to the ring (the later sweeps of the group read it there)
+#endif
                     *reinterpret_cast<float4 *>(lds + wr_lane + wr_off) = sa0[j0];
                     *reinterpret_cast<float4 *>(lds + wr_lane + wr_off + OPPLANE) = sb0[j0];
                     wr_off = wr_off + OPROWB == (unsigned)OPPLANE ? 0u : wr_off + OPROWB;
@@ -417,10 +421,16 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
                     const bool ringfed = ROLE != 0 && f >= F0;
                     if (ringfed) {
                         hlz[f] = (v2f){lb[f][(CHUNK_AHEAD ? q * CH + j : j) % NSL].z, lb[f][(CHUNK_AHEAD ? q * CH + j : j) % NSL].w};
+#ifdef SFA_X_NORINGRD     // timing experiment only: the ring-fed sweeps keep the operands they have (what do the 16-byte LDS reads cost?)
+                        if (false) {
+#else
                         if (!CHUNK_AHEAD) {
+#endif
                             la[f][(j + PF) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f]);              // the row of step + PF
                             lb[f][(j + PF) % NSL] = *reinterpret_cast<const float4 *>(lds + rd_lane[f] + rd_off[f] + OPPLANE);
+#ifndef SFA_X_NOWRAP      // timing experiment only: every step reads the same row (no row arithmetic at all: the upper bound of what a cheaper ring addressing could win)
                             rd_off[f] = rd_off[f] + OPROWB == (unsigned)OPPLANE ? 0u : rd_off[f] + OPROWB;
+#endif
                         }
                     } else if (f == 0) hlz[0] = (v2f){sb0[ROLE == 2 ? 0 : j0].z, sb0[ROLE == 2 ? 0 : j0].w};
                     else hlz[f] = (v2f){sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0].z, sb1[(f > 0 && ROLE == 0) ? f - 1 : 0][ROLE == 0 ? j1 : 0].w};
