@@ -1249,6 +1249,50 @@ def test_resident_sequence_is_normalize_plus_upload(ctx, oracle):
     a.close(); b.close(); seq.close(); seq2.close()
 
 
+def test_sequence_sharded_over_two_contexts_normalises_like_one(ctx, oracle):
+    """the multi-GPU driver's ingest: every GPU holds a slice of the frames (here two contexts, frames 0..3 and 2..5: a halo of two), forms the
+    per-frame sums of what it holds, the statistics come from the sums of ALL frames in frame order on the host, each slice is normalised with them -- the frames and the
+    published statistics are those of one sequence normalised as a whole, bit for bit; a halo frame gets the same sums from both holders"""
+    w, h, n = 130, 98, 6
+    frames = [c_(texture_frame(w, h, k)) for k in range(n)]
+    whole = sfa.Sequence(ctx, w, h, n)
+    for f in range(n):
+        whole.upload(f, frames[f])
+    raw_sums = whole.frame_sums()
+    avg_w, std_w = whole.normalize()
+    other = sfa.Context(0)
+    try:
+        parts = [(ctx, 0, 4), (other, 2, 6)]
+        seqs, sums = [], np.zeros((n, 6))
+        have = np.zeros(n, bool)
+        for c, lo, hi in parts:
+            q = sfa.Sequence(c, w, h, hi - lo)
+            for f in range(lo, hi):
+                q.upload(f - lo, frames[f])
+            mine = q.frame_sums()
+            for f in range(lo, hi):
+                if have[f]:
+                    assert np.array_equal(sums[f], mine[f - lo])          # the halo: the same bits from both holders
+                sums[f] = mine[f - lo]; have[f] = True
+            seqs.append(q)
+        assert np.array_equal(sums, raw_sums)
+        avg, std = sfa.normalize_statistics(sums, w, h)
+        assert avg == avg_w and std == std_w
+        for (c, lo, hi), q in zip(parts, seqs):
+            q.apply_normalization(avg, std)
+            for f in range(lo, hi):
+                assert np.array_equal(q.download(f - lo)[:, :, :w], whole.download(f)[:, :, :w])
+    finally:
+        other.close()
+
+
+def test_debug_switch_hook_rejects_unknown_names(ctx):
+    """sfa_debug_set knows the library's switches by name (sfa_internal.h: Switches); anything else is an error, not a silently ignored variable"""
+    sfa.debug_set("SFA_SOR_CHAIN", 11); sfa.debug_set("SFA_SOR_CHAIN", None)
+    with pytest.raises(sfa.SlowflowError):
+        sfa.debug_set("SFA_NO_SUCH_SWITCH", 1)
+
+
 @pytest.mark.gpu
 def test_objects_may_be_finalised_in_any_order():
     """a context finalised before the jobs created on it (cyclic garbage, interpreter shutdown) must neither crash nor hang: close() on the context
