@@ -584,8 +584,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=128, help="frame windows per GPU (fwd/bwd of several jets), refined as --streams lockstep groups")
-    ap.add_argument("--streams", type=int, default=2, help="the batch is refined as this many lockstep groups on separate HIP streams, one host thread each "
-                    "(the reference drives its windows from OpenMP threads, slow_flow.cpp:706): the groups fill each other's ramp-up / drain phases")
+    ap.add_argument("--streams", type=int, default=1, help="the batch is refined as this many lockstep groups on separate HIP streams, one host thread each "
+                    "(the reference drives its windows from OpenMP threads, slow_flow.cpp:706).  Default since round 5: ONE group of 128 windows (a job holds up to 128 "
+                    "since the window set became two mask words): the solver's launches then fill whole rounds of the 256 CUs at every pyramid level -- 115.8 ms per "
+                    "step against 117.4-117.9 for two groups of 64 on two streams, same box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path-only", action="store_true", help="skip the SOR-only section (used for the PMC passes: every SOR dispatch then belongs to the path)")
     ap.add_argument("--bench-only", action="store_true", help="--path-only and none of the reported extras either (one-window latency, labelled modes, cfg-schedule sample, triad): "

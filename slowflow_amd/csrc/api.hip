@@ -120,7 +120,8 @@ struct Level {
     float *warp(int s, int sp1) const { return base + off_warp + (long)(s + sp1) * 3 * pl; }
     float *frame(int f) const { return pbase + 2 * pl + (long)f * 3 * pl; }
     float *tmp() const { return base + off_tmp; }
-    Geo geo(unsigned long long active = ~0ull) const { return Geo{w, h, pitch, pl, es, nb, active, nullptr}; }
+    Geo geo() const { return Geo{w, h, pitch, pl, es, nb, WMask::first(nb), nullptr}; }
+    Geo geo(const WMask &active) const { return Geo{w, h, pitch, pl, es, nb, active, nullptr}; }
     static long persistent_floats(int pitch, int h, int ref) { return (long)pitch * h * (2 + (2L * ref + 1) * 3); }
     static long transient_floats(int pitch, int h, int ref, bool fused) {
         return (long)pitch * h * ((P_COUNT - 2) + 2 * ref + (2L * ref + 1) * 3 + (fused ? 0 : 2L * ref * 2 * 24));     // masks, one warped image per frame (the reference frame's slot stays empty), stacks
@@ -198,18 +199,18 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                      float *occ_log) {
     const int ref = L.ref;
     const float gamma_over3 = p.gamma / 3.0f, delta_over3 = p.delta / 3.0f;                                   // :548-549
-    unsigned long long active = L.nb >= 64 ? ~0ull : ((1ull << L.nb) - 1);
-    const unsigned long long all = active;
+    WMask active = WMask::first(L.nb);
+    const WMask all = active;
     Geo g = L.geo(active);
     // The reference's per-iteration lines (variational_mt.cpp:404-405, 431-432: "inner it i avg change a,b" / "outer it i avg change a,b" under verbosity(VER_CMD)).
     // Printing them needs the norms on the host after every iteration -- a synchronisation per iteration --, so it is off unless SFA_VERBOSE_CHANGES is set (the C++
     // class and the driver set it when the cfg's `verbose` asks for it).  Batches print one line per window that still iterates, in window order.
     const bool verbose = c->verbose_changes;
-    auto print_changes = [&](const char *what, int it, unsigned long long who) {
+    auto print_changes = [&](const char *what, int it, const WMask &who) {
         if (hipMemcpyAsync(c->h_red, c->d_red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return;
         const double n = (double)L.w * L.h;
         for (int b = 0; b < L.nb; b++)
-            if ((who >> b) & 1) {
+            if (who.test(b)) {
                 if (L.nb > 1) printf("[window %d] ", b);
                 printf("%s %d\tavg change %g,%g\n", what, it, (double)(float)(c->h_red[2 * b] / n), (double)(float)(c->h_red[2 * b + 1] / n));
             }
@@ -296,10 +297,10 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             if (use_thres_out && outer >= kLag) {
                 const int slot = (outer - kLag) % kRing;
                 SFA_HIP(c, hipEventSynchronize(c->ev_mask[slot]));
-                active = *(volatile unsigned long long *)&c->h_amask[slot];
-                if (!active) break;                                                                      // :436, every window
+                for (int i = 0; i < kMaskWords; i++) active.w[i] = *(volatile unsigned long long *)&c->h_amask[slot].w[i];
+                if (!active.any()) break;                                                                // :436, every window
             }
-            if (dbg) fprintf(stderr, "level %dx%d alter %d outer %d known active %d\n", L.w, L.h, alter, outer, __builtin_popcountll(active));
+            if (dbg) fprintf(stderr, "level %dx%d alter %d outer %d known active %d\n", L.w, L.h, alter, outer, active.count());
             g.active = active;
             if (outer > 0) smoothed = get_derivatives(c, L, p, g, need_toref, uv_alias);                    // :289-290 (+ :333)
             if (!L.fused) launch_mask_weight(c, g, L.mask(0), L.plane(P_OCC), data_norm, ref, p.one_direction);   // :293-320
@@ -309,7 +310,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             const bool red_black = p.sor_order == 1;           // labelled mode: works on the row-major planes, never on the diagonal-major operands
             const bool direct_outer = L.fused && !red_black && !sw_given(Switches::NO_DIRECT_OPERANDS);
             if (!direct_outer) launch_zero_planes(c, g, L.plane(P_DU), 2);                                   // :323-324 (du, dv adjacent)
-            unsigned long long in_active = active, outer_done = 0;
+            WMask in_active = active, outer_done = WMask::none();
             for (int inner = 0; inner < p.niter_inner; inner++) {
                 Geo gi = g;
                 gi.active = in_active;
@@ -358,18 +359,18 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                     SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                     SFA_HIP(c, hipStreamSynchronize(c->stream));
                     for (int b = 0; b < L.nb; b++)
-                        if ((in_active >> b) & 1) {
+                        if (in_active.test(b)) {
                             const float a = (float)(c->h_red[2 * b] / npx), d = (float)(c->h_red[2 * b + 1] / npx);
-                            if (std::max(a, d) < p.thres_inner) in_active &= ~(1ull << b);                   // :407
+                            if (std::max(a, d) < p.thres_inner) in_active.clear(b);                         // :407
                         }
-                    if (!in_active) break;
+                    if (!in_active.any()) break;
                 }
             }
             if (outer_done != active) {
                 // windows that left the inner loop early (or the unfused form): their outer update.  The reductions only write the result
                 // words of the windows of their Geo::active, so the norms of the windows updated above stay in `red`.
                 Geo go = g;
-                go.active = active & ~outer_done;
+                go.active = active.andnot(outer_done);
                 launch_update_outer(c, go, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);                      // :412-429
             }
             if (verbose) print_changes("outer it", outer, active);                                            // :431-432
@@ -377,7 +378,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             if (use_thres_out || last_iter) launch_outer_threshold(c, g, red, use_thres_out ? p.thres_outer : 0.0f);   // :431-436
             if (use_thres_out) {
                 const int slot = outer % kRing;
-                SFA_HIP(c, hipMemcpyAsync(&c->h_amask[slot], c->d_amask, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+                SFA_HIP(c, hipMemcpyAsync(&c->h_amask[slot], c->d_amask, sizeof(WMask), hipMemcpyDeviceToHost, c->stream));
                 SFA_HIP(c, hipEventRecord(c->ev_mask[slot], c->stream));
             }
         }
@@ -460,7 +461,7 @@ struct sfa_job {
     }
     int host_stride0 = 0;
     bool fused = true;                 // false: SFA_UNFUSED=1 at creation (stack planes materialised; cross-check only)
-    unsigned long long presmoothed = 0;   // windows whose level-0 frames already hold the presmoothed images (cfg sigma > 0): smoothing is applied once per upload
+    WMask presmoothed = WMask::none();    // windows whose level-0 frames already hold the presmoothed images (cfg sigma > 0): smoothing is applied once per upload
     bool keep_alt_occ = false;         // record the occlusion labels of every alternation (slow_flow_occlusions_output, variational_mt.cpp:275-285)
     DevMem occ_log;                    // [nb][niter_alter][pl(level 0)]
 };
@@ -489,7 +490,7 @@ int sfa_ctx_create(int device, sfa_ctx **out) {
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, 2 * kMaxBatch * sizeof(double) + 64, hipHostMallocDefault));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_amask, 64));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double)));
-    SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, kMaskRing * sizeof(unsigned long long), hipHostMallocDefault));
+    SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, kMaskRing * sizeof(WMask), hipHostMallocDefault));
     for (auto &e : c->ev_mask) SFA_HIP(c.get(), hipEventCreateWithFlags(&e, hipEventDisableTiming));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_err, 64));
     SFA_HIP(c.get(), hipMemset(c->d_err, 0, 64));
@@ -647,7 +648,7 @@ struct Staging {
         SFA_HIP(c, hipMemsetAsync(mem.p, 0, (size_t)nplanes * pl * sizeof(float), c->stream));
         return SFA_OK;
     }
-    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, 1ull, nullptr}; }
+    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, WMask::first(1), nullptr}; }
     int up(int i, const float *host, int stride, int n = 1) {
         for (int k = 0; k < n; k++) SFA_TRY(upload_plane(c, plane(i + k), pitch, host + (size_t)k * stride * h, stride, w, h));
         return SFA_OK;
@@ -890,7 +891,7 @@ int sfa_sor_batch_run(sfa_sor_batch *sb, int iterations, float omega) {
     sfa_ctx *ctx = sb ? sb->ctx : nullptr;
     CHECK_ARGS(sb, "null batch");
     SFA_HIP(ctx, hipSetDevice(ctx->device));
-    Geo g{sb->w, sb->h, sb->pitch, sb->pl, sb->es, sb->nb, sb->nb >= 64 ? ~0ull : ((1ull << sb->nb) - 1), nullptr};
+    Geo g{sb->w, sb->h, sb->pitch, sb->pl, sb->es, sb->nb, WMask::first(sb->nb), nullptr};
     return sor_run(ctx, sb->ws, g, sb->plane(0, 0), sb->plane(0, 1), sb->plane(0, 2), sb->plane(0, 3), sb->plane(0, 4), sb->plane(0, 5), sb->plane(0, 6),
                    sb->plane(0, 7), sb->plane(0, 8), iterations, omega, true);
 }
@@ -1020,7 +1021,7 @@ struct sfa_sequence {
     DevMem mem;                        // n x 3 planes at the device pitch
     DevMem sums;                       // n x 6 doubles: per frame and channel sum(I), sum(I*I)
     float *frame(int f) const { return mem.f() + (long)f * 3 * pl; }
-    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, 1ull, nullptr}; }
+    Geo geo() const { return Geo{w, h, pitch, pl, 0, 1, WMask::first(1), nullptr}; }
 };
 
 int sfa_sequence_create(sfa_ctx *ctx, int w, int h, int n_frames, sfa_sequence **out) {
@@ -1118,6 +1119,7 @@ int sfa_normalize(sfa_ctx *ctx, float *const *frames, int F, int w, int h, int s
 int sfa_job_create(sfa_ctx *ctx, const sfa_params *p, int w, int h, int batch, sfa_job **out) {
     CHECK_ARGS(ctx && p && out && w >= 2 && h >= 5 && batch > 0 && batch <= kMaxBatch, "bad arguments (h >= 5, w >= 2)");
     CHECK_ARGS(p->S >= 2 && p->S - 1 <= SFA_MAX_REF && p->layers >= 1 && p->layers <= 64, "unsupported slow_flow_S / slow_flow_layers");
+    CHECK_ARGS(2L * kMaxBatch + 2L * batch * ((w + 63) / 64) * 16 <= kRedDoubles, "batch x width beyond the change norms' scratch (sfa_internal.h: kRedDoubles)");
     SFA_HIP(ctx, hipSetDevice(ctx->device));
     std::unique_ptr<sfa_job> j(new sfa_job());
     j->ctx = ctx; j->p = *p; j->w = w; j->h = h; j->nb = batch; j->ref = p->S - 1; j->F = 2 * j->ref + 1;
@@ -1194,7 +1196,7 @@ int sfa_job_upload(sfa_job *j, int b, const float *const *frames, int n_frames, 
     SFA_HIP(ctx, hipSetDevice(ctx->device));
     Level L0 = j->level(0);
     j->host_stride0 = stride;
-    j->presmoothed &= ~(1ull << b);
+    j->presmoothed.clear(b);
     for (int f = 0; f < j->F; f++) {
         CHECK_ARGS(frames[f], "null frame");
         for (int k = 0; k < 3; k++)
@@ -1220,7 +1222,7 @@ int sfa_job_upload_resident(sfa_job *j, int b, const sfa_sequence *q, const int 
     SFA_HIP(ctx, hipSetDevice(ctx->device));
     Level L0 = j->level(0);
     j->host_stride0 = stride;
-    j->presmoothed &= ~(1ull << b);
+    j->presmoothed.clear(b);
     for (int f = 0; f < j->F; f++) {
         CHECK_ARGS(frame_index[f] >= 0 && frame_index[f] < q->n, "frame index out of range");
         SFA_HIP(ctx, hipMemcpyAsync(L0.frame(f) + b * j->es, q->frame(frame_index[f]), (size_t)3 * L0.pl * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1243,7 +1245,7 @@ int sfa_job_run(sfa_job *j) {
     SFA_HIP(ctx, hipSetDevice(ctx->device));
     const sfa_params &p = j->p;
     const int nb = j->nb, F = j->F, L = j->L;
-    const unsigned long long all = nb >= 64 ? ~0ull : ((1ull << nb) - 1);
+    const WMask all = WMask::first(nb);
     // ---- pyramid (variational_mt.cpp:583-652) -----------------------------------------------------------
     const float sigma = 1 / sqrtf(2 * p.p_scale);
     float taps[64];
@@ -1255,7 +1257,7 @@ int sfa_job_run(sfa_job *j) {
         float *tmp = L0.tmp();
         for (int f = 0; f < F; f++) {
             launch_presmooth(ctx, L0.geo(all), tmp + 3 * L0.pl, tmp, L0.frame(f), 3, p.presmooth_sigma);
-            launch_copy_planes(ctx, L0.geo(all & ~j->presmoothed), L0.frame(f), tmp + 3 * L0.pl, 3, L0.es, L0.es);
+            launch_copy_planes(ctx, L0.geo(all.andnot(j->presmoothed)), L0.frame(f), tmp + 3 * L0.pl, 3, L0.es, L0.es);
         }
         j->presmoothed = all;
     }

@@ -1764,10 +1764,10 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx,
     }
 }
 // one block per batch element sums that element's partials in a fixed order
-__global__ void k_reduce_partials(const double *__restrict__ partial, int per_elem, double *__restrict__ out, unsigned long long active,
+__global__ void k_reduce_partials(const double *__restrict__ partial, int per_elem, double *__restrict__ out, WMask active,
                                   const unsigned long long *__restrict__ amask) {
     const int b = blockIdx.x;
-    if (!elem_active(active_mask(active, amask), b)) return;                              // the result words of passengers keep their last values
+    if (!elem_active(active, amask, b)) return;                                            // the result words of passengers keep their last values
     double sa = 0, sb = 0;
     for (int i = threadIdx.x; i < per_elem; i += 256) { sa += partial[2 * ((size_t)b * per_elem + i)]; sb += partial[2 * ((size_t)b * per_elem + i) + 1]; }
     __shared__ double s0[256], s1[256];
@@ -1781,13 +1781,13 @@ __global__ void k_reduce_partials(const double *__restrict__ partial, int per_el
 }
 
 // The outer break on the device (variational_mt.cpp:431-436): the norms of the windows that ran this outer iteration, and the windows that go on.
-// One wave; lane b = window b.  `last` keeps every window's norms of ITS last iteration (what the caller gets back as the change).
+// One wave per mask word; lane = window within the word.  `last` keeps every window's norms of ITS last iteration (what the caller gets back as the change).
 __global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict__ red, double *__restrict__ last, unsigned long long *__restrict__ amask,
-                                                        unsigned long long active, int nb, double npx, float thres) {
-    const int b = threadIdx.x;
-    const unsigned long long cur = *amask & active;
+                                                        WMask active, int nb, double npx, float thres) {
+    const int word = blockIdx.x, b = 64 * word + (int)threadIdx.x;
+    const unsigned long long cur = amask[word] & active.w[word];
     bool met = false;
-    if (b < nb && ((cur >> b) & 1ull)) {
+    if (b < nb && ((cur >> threadIdx.x) & 1ull)) {
         const double a = red[2 * b] / npx, d = red[2 * b + 1] / npx;
         last[2 * b] = a; last[2 * b + 1] = d;
         // std::max(a, d) as the reference writes it (:436): (a < d) ? d : a -- a NaN norm in `a` stays a NaN, the comparison is false and the window
@@ -1797,13 +1797,13 @@ __global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict
         met = thres > 0.0f && mx < thres;
     }
     const unsigned long long m = __ballot(met);
-    if (b == 0) *amask = *amask & ~m;
+    if (threadIdx.x == 0) amask[word] = amask[word] & ~m;
 }
-__global__ void k_set_mask(unsigned long long *amask, unsigned long long v) { *amask = v; }
+__global__ void k_set_mask(unsigned long long *amask, WMask v) { for (int i = 0; i < kMaskWords; i++) amask[i] = v.w[i]; }
 void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres) {
-    hipLaunchKernelGGL(k_outer_threshold, dim3(1), dim3(64), 0, c->stream, red, c->d_last, c->d_amask, g.active, g.nb, (double)g.h * g.w, thres);
+    hipLaunchKernelGGL(k_outer_threshold, dim3(kMaskWords), dim3(64), 0, c->stream, red, c->d_last, c->d_amask, g.active, g.nb, (double)g.h * g.w, thres);
 }
-void launch_set_mask(sfa_ctx *c, unsigned long long v) { hipLaunchKernelGGL(k_set_mask, dim3(1), dim3(1), 0, c->stream, c->d_amask, v); }
+void launch_set_mask(sfa_ctx *c, const WMask &v) { hipLaunchKernelGGL(k_set_mask, dim3(1), dim3(1), 0, c->stream, c->d_amask, v); }
 
 // partial-sum scratch lives behind the result words in ctx->d_red: [0, 2*kMaxBatch) results, then partials
 static double *partials_of(sfa_ctx *c) { return c->d_red + 2 * kMaxBatch; }
@@ -2223,7 +2223,7 @@ __global__ void __launch_bounds__(BX *BY) k_norm_sums(const float *__restrict__ 
 void launch_normalize_sums(sfa_ctx *c, const Geo &g, const float *frames3, double *red) {
     dim3 grid = red_grid(g, 3);
     hipLaunchKernelGGL(k_norm_sums, grid, block2d(), 0, c->stream, frames3, partials_of(c), g);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, c->stream, partials_of(c), (int)(grid.x * grid.y), red, 7ull, (const unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(3), dim3(256), 0, c->stream, partials_of(c), (int)(grid.x * grid.y), red, WMask::first(3), (const unsigned long long *)nullptr);
 }
 __global__ void k_norm_apply(float *__restrict__ frames3, Geo g, double a0, double a1, double a2, double s0, double s1, double s2) {
     const int ch = blockIdx.z;

@@ -13,9 +13,12 @@ namespace sfa {
 static inline dim3 grid2d(const Geo &g, int zmul = 1) { return dim3((g.w + BX - 1) / BX, (g.h + BY - 1) / BY, g.nb * zmul); }
 static inline dim3 block2d() { return dim3(BX, BY, 1); }
 
-__device__ __forceinline__ bool elem_active(unsigned long long active, int b) { return (active >> b) & 1ull; }
-__device__ __forceinline__ unsigned long long active_mask(unsigned long long active, const unsigned long long *amask) { return amask ? (active & *amask) : active; }
-__device__ __forceinline__ bool elem_active(const Geo &g, int b) { return (active_mask(g.active, g.amask) >> b) & 1ull; }
+// window b takes part: its bit in what the host knows AND in what the device knows (one word of each is looked at)
+__device__ __forceinline__ bool elem_active(const WMask &active, const unsigned long long *amask, int b) {
+    const unsigned long long m = amask ? (active.w[b >> 6] & amask[b >> 6]) : active.w[b >> 6];
+    return (m >> (b & 63)) & 1ull;
+}
+__device__ __forceinline__ bool elem_active(const Geo &g, int b) { return elem_active(g.active, g.amask, b); }
 __device__ __forceinline__ int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
 
 // derivative filter taps as convolution_new builds them (image.c:363-366, variational_mt.cpp:570-573)

@@ -13,7 +13,28 @@
 
 namespace sfa {
 
-constexpr int kMaxBatch = 64;
+// Windows a lockstep job can hold.  Which of them take part in a launch is a bit set of kMaskWords 64-bit words (WMask): what the host knows (Geo::active) AND what the
+// device knows (the windows that have not met the outer threshold yet: sfa_ctx::d_amask, Geo::amask).  Round 5 widened the set from one word to two.
+constexpr int kMaskWords = 2;
+constexpr int kMaxBatch = 64 * kMaskWords;
+struct WMask {
+    unsigned long long w[kMaskWords];
+    __host__ __device__ bool test(int b) const { return (w[b >> 6] >> (b & 63)) & 1ull; }
+    __host__ __device__ void clear(int b) { w[b >> 6] &= ~(1ull << (b & 63)); }
+    __host__ __device__ bool any() const { unsigned long long o = 0; for (int i = 0; i < kMaskWords; i++) o |= w[i]; return o != 0; }
+    __host__ __device__ bool operator==(const WMask &o) const { bool e = true; for (int i = 0; i < kMaskWords; i++) e = e && w[i] == o.w[i]; return e; }
+    __host__ __device__ bool operator!=(const WMask &o) const { return !(*this == o); }
+    __host__ __device__ WMask operator&(const WMask &o) const { WMask r; for (int i = 0; i < kMaskWords; i++) r.w[i] = w[i] & o.w[i]; return r; }
+    __host__ __device__ WMask andnot(const WMask &o) const { WMask r; for (int i = 0; i < kMaskWords; i++) r.w[i] = w[i] & ~o.w[i]; return r; }
+    int count() const { int n = 0; for (int i = 0; i < kMaskWords; i++) n += __builtin_popcountll(w[i]); return n; }
+    static WMask none() { WMask r; for (int i = 0; i < kMaskWords; i++) r.w[i] = 0; return r; }
+    static WMask first(int nb) {                                   // windows 0 .. nb - 1
+        WMask r;
+        for (int i = 0; i < kMaskWords; i++) r.w[i] = nb >= 64 * (i + 1) ? ~0ull : nb <= 64 * i ? 0ull : (1ull << (nb - 64 * i)) - 1;
+        return r;
+    }
+    static WMask one(int b) { WMask r = none(); r.w[b >> 6] = 1ull << (b & 63); return r; }
+};
 constexpr int kMaxTerms = 4 * SFA_MAX_REF;
 // device-side outer break (api.hip run_level): the host reads the mask of kMaskLag iterations ago from a ring of kMaskRing pinned words
 constexpr int kMaskLag = 2, kMaskRing = 4;
@@ -35,9 +56,9 @@ struct sfa_ctx {
     double *h_red = nullptr;      // pinned host mirror
     // thresholds on the device (variational_mt.cpp:436): the windows still iterating, the norms of each window's last iteration, and a ring of pinned
     // copies of the mask (one per outer iteration in flight) with the events that say a copy has landed
-    unsigned long long *d_amask = nullptr;
+    unsigned long long *d_amask = nullptr;         // kMaskWords words
     double *d_last = nullptr;                      // 2 * kMaxBatch doubles
-    unsigned long long *h_amask = nullptr;         // kMaskRing pinned words
+    sfa::WMask *h_amask = nullptr;                      // kMaskRing pinned masks
     hipEvent_t ev_mask[sfa::kMaskRing] = {};
     unsigned *d_err = nullptr;    // device error/timeout word
     // profiling of the SOR solve kernel
@@ -60,7 +81,7 @@ struct sfa_ctx {
 
 namespace sfa {
 
-constexpr int kRedDoubles = 1 << 18;   // 2*kMaxBatch result words + per-block partials (<= 64 x 128 x 16 blocks)
+constexpr int kRedDoubles = 1 << 20;   // 2*kMaxBatch result words + per-block partials: 2 x windows x ceil(w / 64) x 16 row blocks (sfa_job_create checks the size)
 
 int set_error(sfa_ctx *ctx, int code, const char *fmt, ...);
 extern thread_local std::string g_thread_err;
@@ -124,7 +145,7 @@ int download_plane(sfa_ctx *ctx, float *host, int stride, const float *dev, int 
 // ---------------------------------------------------------------------------------------------------
 // pl = pitch*h.  A window b takes part in a launch when bit b is set in `active` (what the host knows) AND in *amask (what the device knows: the windows
 // that have not met the outer threshold yet, sfa_ctx::d_amask; null = no device-side mask)
-struct Geo { int w, h, pitch; long pl; long es; int nb; unsigned long long active; const unsigned long long *amask; };
+struct Geo { int w, h, pitch; long pl; long es; int nb; WMask active; const unsigned long long *amask; };
 
 struct PenaltyDev { int id; float eps, trunc; };
 
@@ -148,7 +169,7 @@ void launch_division_chain(sfa_ctx *c, const float *a, const float *b, float *q_
 void launch_fill_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes, float v);
 void launch_zero_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes);
 void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres);   // updates *c->d_amask and c->d_last
-void launch_set_mask(sfa_ctx *c, unsigned long long v);
+void launch_set_mask(sfa_ctx *c, const WMask &v);
 
 // Where a kernel other than k_sor_prepare leaves the solver's operands (diagonal-major planes of a SorWorkspace)
 struct SorOperandOut {

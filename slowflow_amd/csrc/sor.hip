@@ -55,7 +55,7 @@ struct SorArgs {
     int W, H, K, NB, NG, RP, G, NS, NCH, ntasks, nb;
     int nwords;                     // progress words per window (padded)
     float omega;
-    unsigned long long active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' tasks return at once
+    WMask active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' tasks return at once
 };
 
 
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(64) k_sor_solve(SorArgs a) {
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= (unsigned)(a.nb * a.ntasks)) return;
     const int job = t % a.nb, idx = t / a.nb;
-    if (!elem_active(active_mask(a.active, a.amask), job)) return;        // a passenger: none of its tasks runs, so none of them waits
+    if (!elem_active(a.active, a.amask, job)) return;        // a passenger: none of its tasks runs, so none of them waits
     const int2 bg = a.order[idx];
     const int b = __builtin_amdgcn_readfirstlane(bg.x), g = __builtin_amdgcn_readfirstlane(bg.y);
     const int k0 = g * F;
@@ -268,7 +268,7 @@ struct BandArgs {
     int W, H, K, NB, NW, RP, G, NS, NCH, nb, Wp, EP;
     int lead;                      // steps a stage may run ahead of the next one (<= ring slots)
     float omega;
-    unsigned long long active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' bands return at once
+    WMask active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' bands return at once
 };
 
 // What a band hands to the band below -- lane 63's iterates and the progress word -- leaves as write-through (sc1) stores.  sor_chain.hip found that ONE
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(MAXW * 64) k_sor_band(BandArgs a) {
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;                     // band-major tickets
-    if (!elem_active(active_mask(a.active, a.amask), job)) return;
+    if (!elem_active(a.active, a.amask, job)) return;
     if (NW == 1)               band_wave<F, CH, MC, RING, 3>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
     else if (wave == 0)        band_wave<F, CH, MC, RING, 0>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
     else if (wave == NW - 1)   band_wave<F, CH, MC, RING, 2>(a, ring, lprog, win0 + (size_t)wave * WINB, est0 + (size_t)wave * F, tvb0 + (size_t)wave * TVB, job, b, wave, lane, wave * F);
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__((NA + NB_) * 64) k_sor_band_mixed(BandArgs a) 
     const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
     if (t >= (unsigned)(a.nb * a.NB)) return;
     const int job = t % a.nb, b = t / a.nb;
-    if (!elem_active(active_mask(a.active, a.amask), job)) return;
+    if (!elem_active(a.active, a.amask, job)) return;
     unsigned char *win = wave < NA ? win0 + (size_t)wave * WINA : win0 + (size_t)NA * WINA + (size_t)(wave - NA) * WINB_;
     unsigned long long(*est)[MC] = est0 + (size_t)wave * FA;
     unsigned long long *tvb = tvb0 + (size_t)wave * TVB;
@@ -678,7 +678,7 @@ struct PrepArgs {
     float *a11, *a12, *a22;
     long ent, es;
     int W, H, RP, ND, G, pitch, ntasks, nb, inv_out;
-    unsigned long long active; const unsigned long long *amask;
+    WMask active; const unsigned long long *amask;
 };
 // One block = a 64-column x 16-row tile: row-major reads coalesced along the columns, the 10 operand floats staged in
 // LDS, then written along the tile's anti-diagonals: 16 consecutive entries (256 B of SA/SB) per diagonal.  Only valid
@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(256) k_sor_prepare(PrepArgs p) {
         for (int i = threadIdx.x; i < p.ntasks; i += 256) p.flags[(size_t)job * p.ntasks + i] = 0;
         if (job == 0 && threadIdx.x == 0) p.flags[(size_t)p.nb * p.ntasks] = 0;      // ticket
     }
-    if (!elem_active(active_mask(p.active, p.amask), job)) return;                   // passengers: progress words reset, operands left alone
+    if (!elem_active(p.active, p.amask, job)) return;                   // passengers: progress words reset, operands left alone
 #pragma unroll
     for (int i = 0; i < PT_R / 4; i++) {
         const int rl = ty + 4 * i, r = r0 + rl, c = c0 + tx;
@@ -734,10 +734,10 @@ __global__ void __launch_bounds__(256) k_sor_prepare(PrepArgs p) {
 }
 
 __global__ void k_sor_finish(float *__restrict__ du, float *__restrict__ dv, const unsigned long long *__restrict__ x, long ent, long es, int W, int H,
-                             int RP, int G, int pitch, unsigned long long active, const unsigned long long *__restrict__ amask) {
+                             int RP, int G, int pitch, WMask active, const unsigned long long *__restrict__ amask) {
     const int job = blockIdx.z;
     const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y * 4 + threadIdx.y;
-    if (c >= W || r >= H || !elem_active(active_mask(active, amask), job)) return;
+    if (c >= W || r >= H || !elem_active(active, amask, job)) return;
     const float2 v = u2f(x[(size_t)job * ent + (size_t)(c + r + G) * RP + (r + G)]);
     const size_t o = (size_t)job * es + (size_t)r * pitch + c;
     du[o] = v.x;
@@ -747,8 +747,8 @@ __global__ void k_sor_finish(float *__restrict__ du, float *__restrict__ dv, con
 // tiny systems: the reference itself falls back to the readable solver (solver.c:66-69, 17-57)
 __global__ void k_sor_readable(float *du_, float *dv_, const float *a11_, const float *a12_, const float *a22_, const float *b1_, const float *b2_,
                                const float *sh_, const float *sv_, long es, int w, int h, int stride, int iterations, float omega,
-                               unsigned long long active, const unsigned long long *amask) {
-    if (threadIdx.x != 0 || !elem_active(active_mask(active, amask), blockIdx.x)) return;
+                               WMask active, const unsigned long long *amask) {
+    if (threadIdx.x != 0 || !elem_active(active, amask, blockIdx.x)) return;
     const long eb = (long)blockIdx.x * es;
     float *du = du_ + eb, *dv = dv_ + eb;
     const float *a11 = a11_ + eb, *a12 = a12_ + eb, *a22 = a22_ + eb, *b1 = b1_ + eb, *b2 = b2_ + eb, *sh = sh_ + eb, *sv = sv_ + eb;

@@ -45,7 +45,7 @@ struct ChainArgs {
     int nch;                       // chunks per stage (even)
     int NI;                        // barrier intervals per workgroup (multiple of AH)
     float omega;
-    unsigned long long active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' workgroups return at once
+    WMask active; const unsigned long long *amask;   // windows of this launch (Geo::active, Geo::amask): the others' workgroups return at once
 };
 
 // one progress word per workgroup, each on a 128-byte line of its own: every OUT wave updates its word once per interval (atomic) and up to
@@ -795,7 +795,7 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
     const unsigned t = __builtin_amdgcn_readfirstlane(*s_ticket);
     if (t >= (unsigned)(a.nb * a.NB * a.NG)) return;
     const int job = t % a.nb;
-    if (!elem_active(active_mask(a.active, a.amask), job)) return;        // a passenger: none of its workgroups runs, so none of them waits
+    if (!elem_active(a.active, a.amask, job)) return;        // a passenger: none of its workgroups runs, so none of them waits
     const int2 bg = a.order[t / a.nb];
     const int b = __builtin_amdgcn_readfirstlane(bg.x), g = __builtin_amdgcn_readfirstlane(bg.y);
     // first chunk of the group (even): every stage of the group starts at a local step <= -1 -- with an operand ring SHIFT chunks earlier still, so

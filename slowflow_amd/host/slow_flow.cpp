@@ -134,10 +134,10 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     const string format_flow = format.substr(0, format.find_last_of('.'));
     const int io_threads = std::max(1, std::min(64, params.parameter<int>("io_threads", std::to_string(std::max(1u, std::min(16u, std::thread::hardware_concurrency()))))));
 
-    {                                                                                // a job's windows-still-iterating mask is one 64-bit word: refused by name, not clamped
+    {                                                                                // a job's windows-still-iterating mask is two 64-bit words: refused by name, not clamped
         const int gpu_batch = params.parameter<int>("gpu_batch", "32");
-        if (gpu_batch < 1 || gpu_batch > 64) {
-            std::cerr << "gpu_batch " << gpu_batch << " is out of range: a lockstep job takes 1 .. 64 windows (more windows run as several jobs: gpu_streams, batches per worker)" << std::endl;
+        if (gpu_batch < 1 || gpu_batch > 128) {
+            std::cerr << "gpu_batch " << gpu_batch << " is out of range: a lockstep job takes 1 .. 128 windows (more windows run as several jobs: gpu_streams, batches per worker)" << std::endl;
             return 2;
         }
     }
@@ -486,7 +486,7 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     }
     const double ingest_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
 
-    const int batch = params.parameter<int>("gpu_batch", "32");                      // 1 .. 64: checked before anything was read
+    const int batch = params.parameter<int>("gpu_batch", "32");                      // 1 .. 128: checked before anything was read
     const int F = 2 * ref + 1;
     const bool backward_forward_only = params.exists("method") && params.parameter("method") == "forward";   // :1019-1020
     const bool occ_on = params.parameter<bool>("slow_flow_occlusion_reasoning", "0");

@@ -979,6 +979,55 @@ def test_full_batch_of_64_with_thresholds(ctx, oracle):
     job.close()
 
 
+def test_full_batch_of_128_with_thresholds(ctx, oracle):
+    """round 5: the set of windows that still iterate is two 64-bit words (sfa_internal.h: WMask).  The largest lockstep batch -- 128 windows, every bit of both words
+    in use, windows on both sides of the word boundary stopping at different outer iterations (k_outer_threshold: one wave per word) and riding along as passengers --
+    each with exactly the result it gets alone; and a batch of 100 (a partly filled second word)"""
+    w, h = 67, 45
+    sets = [normalized_frames(oracle, w, h, 3, seed=s)[0] for s in (1, 2)]
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=3)
+    still = [frames[1], frames[1], frames[1]]
+    kinds = [still, sets[0], sets[1], frames]
+    _, ps = mk_params(oracle, S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=8, niter_inner=2, layers=2, thres_outer=2e-3, thres_inner=1e-3)
+    alone = []
+    for f in kinds:
+        j1 = sfa.Job(ctx, ps, w, h, 1)
+        j1.upload(0, [c_(x) for x in f]); j1.run()
+        alone.append(j1.download(0))
+        j1.close()
+    assert np.abs(alone[0][0]).max() < 1e-3                                                 # the still window stops early
+    for nb in (128, 100):
+        job = sfa.Job(ctx, ps, w, h, nb)
+        pick = lambda b: (b * 7 + b // 4) % 4
+        for b in range(nb):
+            job.upload(b, [c_(x) for x in kinds[pick(b)]])
+        job.run()
+        for b in range(nb):
+            gx, gy, chg = job.download(b)
+            ref = alone[pick(b)]
+            assert np.array_equal(gx, ref[0]) and np.array_equal(gy, ref[1]) and chg == ref[2], (nb, b)
+        job.close()
+    with pytest.raises(sfa.SlowflowError):
+        sfa.Job(ctx, ps, w, h, 129)
+
+
+def test_solver_batch_beyond_one_mask_word(ctx, oracle):
+    """100 systems in one solver launch (the second mask word partly filled): first, last and the two around the word boundary are the raster-order oracle's bits"""
+    w, h, K, nb = 130, 98, 30, 100
+    rng = np.random.default_rng(7)
+    systems = [sor_system(rng, w, h) for _ in range(3)]
+    sb = sfa.SorBatch(ctx, w, h, nb)
+    for b in range(nb):
+        sb.upload(b, *[c_(systems[b % 3][k]) for k in ("du", "dv", "a11", "a12", "a22", "b1", "b2", "sh", "sv")])
+    sb.run(K, 1.9)
+    for b in (0, 63, 64, 99):
+        a = copy_sys(systems[b % 3])
+        oracle.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, K, 1.9)
+        du, dv = sb.download(b)
+        assert np.array_equal(valid(a["du"], w), valid(du, w)) and np.array_equal(valid(a["dv"], w), valid(dv, w)), b
+    sb.close()
+
+
 def test_job_can_be_run_again_and_slots_reused(ctx, oracle):
     """a resident job is reused: run(); run() gives run() -- also with presmoothing (cfg sigma > 0), which replaces the uploaded frames once
     per upload -- and a slot that held channel weights forgets them when the next window comes without"""
@@ -1339,7 +1388,7 @@ def test_boundary_rejects_bad_arguments_without_exiting(ctx):
     C = sfa.C
     p = sfa.default_params()
     job = C.c_void_p()
-    for (w, h, batch) in [(1, 48, 1), (64, 4, 1), (64, 48, 0), (64, 48, 65)]:
+    for (w, h, batch) in [(1, 48, 1), (64, 4, 1), (64, 48, 0), (64, 48, 129)]:
         assert L.sfa_job_create(ctx.h, C.byref(p), w, h, batch, C.byref(job)) == -1
         assert b"bad arguments" in L.sfa_last_error(ctx.h)
     assert L.sfa_job_create(None, C.byref(p), 64, 48, 1, C.byref(job)) == -1

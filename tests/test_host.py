@@ -409,12 +409,12 @@ def test_driver_refuses_a_frame_of_another_size(host_build, tmp_path):
 
 
 def test_driver_refuses_gpu_batch_beyond_a_job(host_build, tmp_path):
-    """a lockstep job takes at most 64 windows (one 64-bit mask of the windows still iterating): the driver says so instead of clamping the key;
+    """a lockstep job takes at most 128 windows (two 64-bit words of windows still iterating): the driver says so instead of clamping the key;
     checked before a frame is read, so no GPU is needed"""
     cfg = tmp_path / "run.cfg"
-    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t1\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\nslow_flow_S\t2\ngpu_batch\t65\n" % (tmp_path, tmp_path))
+    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t1\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t0\nslow_flow_S\t2\ngpu_batch\t129\n" % (tmp_path, tmp_path))
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "gpu_batch 65 is out of range" in r.stderr, r.stdout + r.stderr
+    assert r.returncode != 0 and "gpu_batch 129 is out of range" in r.stderr, r.stdout + r.stderr
 
 
 @pytest.mark.gpu

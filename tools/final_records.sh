@@ -5,7 +5,7 @@ TAG=${1:-r05}; HEAD=${2:-unknown}
 mkdir -p gpurun_out/${TAG}_summary
 if [ "$3" != "bench-only" ]; then
   bash profiles/collect.sh $TAG 128 $HEAD > gpurun_out/${TAG}_collect.log 2>&1
-  python3 profiles/summarize.py $TAG 64 > gpurun_out/${TAG}_summarize.log 2>&1
+  python3 profiles/summarize.py $TAG 128 > gpurun_out/${TAG}_summarize.log 2>&1
   cp profiles/${TAG}_* gpurun_out/${TAG}_summary/
   rm -rf gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_stats gpurun_out/${TAG}_stats1
 fi
