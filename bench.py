@@ -697,7 +697,17 @@ def main():
     # between them; the bench's own jobs are closed first -- config 5's 32 windows need the memory
     strong = strong5 = None
     if not args.no_strong and not args.path_only:
-        strong = config4_strong(ctxs, dev, world, rank, dist, xdev)
+        # config 4 runs under break thresholds: two lockstep groups carry fewer passengers than one (1.56 against 1.60 s for the 128 windows on one GPU), which is
+        # what the driver does too (gpu_streams 2) -- a second context for this section when the bench itself runs one group
+        ctxs4 = ctxs
+        if len(ctxs) < 2:
+            try:
+                ctxs4 = ctxs + [sfa.Context(dev)]
+            except Exception:                                      # (nothing may raise between the sections' collectives: one group then)
+                ctxs4 = ctxs
+        strong = config4_strong(ctxs4, dev, world, rank, dist, xdev)
+        for extra in ctxs4[len(ctxs):]:
+            extra.close()
         strong5 = config5_strong(ctxs, dev, world, rank, dist, xdev)
     if rank == 0:
         total = mpix_iters * args.steps * world
