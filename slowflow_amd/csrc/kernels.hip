@@ -1950,6 +1950,9 @@ void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl,
 // against 1.9x at 8); the source footprint (+ blur radius, replicated at the image border) is staged in LDS,
 // blurred along rows, then along columns, and sampled bilinearly -- the same operations in the same order as k_gauss_h,
 // k_gauss_v, k_resize, without the two intermediate images.
+// Round 5: the footprint starts at a source column that is a multiple of 4 (up to three columns left of what the tile needs), so the staging is plain 16-byte
+// copies (the scatter of quads into an unaligned footprint was 43 % LDS bank-conflict cycles), and the column pass writes over the staged footprint, which is dead by
+// then: 40 KB per block instead of 54, four blocks per CU instead of two.
 #ifndef SFA_PYR_GROUP
 #define SFA_PYR_GROUP 4
 #endif
@@ -1959,53 +1962,43 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
     extern __shared__ __attribute__((aligned(16))) float pyr_lds[];
     constexpr int r = R;                                              // compile-time radius: the tap loops unroll, the row buffer stays in registers
     const int CS = (CM + 2 * r + 3) / 4 * 4 + 4, RS = RM + 2 * r;       // CM, CS multiples of 4; CS leaves room for the aligned quads of the row pass
-    float *S = pyr_lds, *Hb = S + RS * CS, *V = Hb + RS * CM;
+    float *S = pyr_lds, *Hb = S + RS * CS, *V = S;                      // V (RM x CM) lies on S (RS x CS): S is dead once the row pass has run
     const int b = blockIdx.z / nplanes, pl = blockIdx.z % nplanes;
     const int dx0 = blockIdx.x * 64, dy0 = blockIdx.y * td;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     // first source column / row any pixel of the tile samples (k_resize's own coordinate arithmetic)
     int mx0 = (int)floorf((float)((dx0 + 0.5) * scale_x - 0.5)), my0 = (int)floorf((float)((dy0 + 0.5) * scale_y - 0.5));
     mx0 = mx0 < 0 ? 0 : mx0; my0 = my0 < 0 ? 0 : my0;
+    const int sxa = (mx0 - r) & ~3;                                  // source column of S column 0 (two's complement: & ~3 floors negative columns too)
+    mx0 = sxa + r;                                                   // source column of tile column 0: <= the first one sampled, by at most 3
     const float *s = src + b * ses + pl * spl;
-    // staging: S column c is source column mx0 - r + c (replicated outside the image).  The source is read as ALIGNED quads -- one 16-byte load per
-    // item instead of four scalar ones; the scalar version spent over half of the kernel issuing loads -- and scattered into S, which keeps
-    // its own alignment for the row pass.  (row, quad) of a thread's items advance incrementally: one division per thread instead of one per item.
+    // staging: S column c is source column sxa + c (replicated outside the image), one aligned 16-byte load and one 16-byte LDS store per item.
+    // (row, quad) of a thread's items advance incrementally: one division per thread instead of one per item.
     {
-        const int sx0 = mx0 - r, sxa = sx0 & ~3, off = sx0 - sxa;    // two's complement: & ~3 floors negative columns too
-        const int NQ = (CS + off + 3) / 4;
+        const int NQ = CS / 4;
         int j = tid / NQ, qa = tid % NQ;
         const int dj = 256 / NQ, dq = 256 % NQ;
-        // a thread's items four at a time: every global load of the group is issued before the first value is scattered (one item at a time -- load, wait,
-        // four LDS stores the next load could not pass -- a thread's 4-5 items were as many memory round trips in a row)
+        // a thread's items four at a time: every global load of the group is issued before the first value is stored (one item at a time -- load, wait,
+        // LDS store the next load could not pass -- a thread's 4-5 items were as many memory round trips in a row)
         constexpr int G = SFA_PYR_GROUP;
         while (j < RS) {
-            float v[G][4];
-            int jj[G], cc[G];
+            float4 v[G];
+            int jj[G], qq[G];
 #pragma unroll
             for (int i = 0; i < G; i++) {
-                jj[i] = j; cc[i] = 4 * qa - off;
+                jj[i] = j; qq[i] = qa;
                 if (j < RS) {
                     const float *row = s + (size_t)clampi(my0 - r + j, 0, sh - 1) * spitch;
                     const int gx = sxa + 4 * qa;
-                    if (gx >= 0 && gx + 3 < sw) {
-                        const float4 q4 = *reinterpret_cast<const float4 *>(row + gx);
-                        v[i][0] = q4.x; v[i][1] = q4.y; v[i][2] = q4.z; v[i][3] = q4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) v[i][e] = row[clampi(gx + e, 0, sw - 1)];
-                    }
+                    if (gx >= 0 && gx + 3 < sw) v[i] = *reinterpret_cast<const float4 *>(row + gx);
+                    else v[i] = make_float4(row[clampi(gx, 0, sw - 1)], row[clampi(gx + 1, 0, sw - 1)], row[clampi(gx + 2, 0, sw - 1)], row[clampi(gx + 3, 0, sw - 1)]);
                 }
                 qa += dq; j += dj;
                 if (qa >= NQ) { qa -= NQ; j++; }
             }
 #pragma unroll
-            for (int i = 0; i < G; i++) {
-                if (jj[i] >= RS) continue;
-                float *Sr = S + jj[i] * CS;
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (cc[i] + e >= 0 && cc[i] + e < CS) Sr[cc[i] + e] = v[i][e];
-            }
+            for (int i = 0; i < G; i++)
+                if (jj[i] < RS) *reinterpret_cast<float4 *>(S + jj[i] * CS + 4 * qq[i]) = v[i];
         }
     }
     __syncthreads();
@@ -2077,13 +2070,13 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
 bool launch_pyr_down(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
                      int nplanes, int nb, const float *taps, int radius) {
     const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
-    const int CM = (((int)ceil(64 * scale_x) + 2) + 3) / 4 * 4, CS = (CM + 2 * radius + 3) / 4 * 4 + 4;
+    const int CM = (((int)ceil(64 * scale_x) + 2) + 3 + 3) / 4 * 4, CS = (CM + 2 * radius + 3) / 4 * 4 + 4;   // + 3: the footprint starts at a multiple of 4
     int td = 32, RM = 0, RS = 0;
     size_t lds = 0;
     for (;; td /= 2) {                                               // the tallest tile whose footprint fits
         RM = (int)ceil(td * scale_y) + 2; RS = RM + 2 * radius;
-        lds = (size_t)(RS * CS + RS * CM + RM * CM) * sizeof(float);
-        if (lds <= 60 * 1024 || td == 8) break;
+        lds = (size_t)(RS * CS + RS * CM) * sizeof(float);          // the column pass writes over the staged footprint (RM * CM <= RS * CS)
+        if (lds <= 40 * 1024 || td == 8) break;                     // 40 KB: four blocks per CU
     }
     if (lds > 60 * 1024 || radius > 8) return false;
     Taps t;
