@@ -383,12 +383,14 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
             }
         }
     }
-    // the norms of every window's last outer iteration
-    SFA_HIP(c, hipMemcpyAsync(c->h_red, c->d_last, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    SFA_HIP(c, hipStreamSynchronize(c->stream));
+    // the norms of every window's last outer iteration -- where the caller wants them (the finest level: the coarser levels' are overwritten, variational_mt.cpp:761), and
+    // only there does the host wait for the level: a blocking read per level left the GPU idle for ~30 us five times per run (a lone window: 2 % of its time)
     (void)npx;
-    if (change)
+    if (change) {
+        SFA_HIP(c, hipMemcpyAsync(c->h_red, c->d_last, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        SFA_HIP(c, hipStreamSynchronize(c->stream));
         for (int i = 0; i < 2 * L.nb; i++) change[i] = (float)c->h_red[i];
+    }
     return SFA_OK;
 }
 
@@ -1277,8 +1279,7 @@ int sfa_job_run(sfa_job *j) {
     Level Lt = j->level(L - 1);
     if (L > 1) {
         const float fx = (1.0f * Lt.w) / j->w, fy = (1.0f * Lt.h) / j->h;
-        launch_resize(ctx, Lt.plane(P_WX), Lt.w, Lt.h, Lt.pitch, Lt.pl, Lt.es, j->init_flow.f(), j->w, j->h, L0.pitch, L0.pl, 2 * L0.pl, 1, nb, fx);
-        launch_resize(ctx, Lt.plane(P_WY), Lt.w, Lt.h, Lt.pitch, Lt.pl, Lt.es, j->init_flow.f() + L0.pl, j->w, j->h, L0.pitch, L0.pl, 2 * L0.pl, 1, nb, fy);
+        launch_resize_flow(ctx, Lt.plane(P_WX), Lt.plane(P_WY), Lt.w, Lt.h, Lt.pitch, Lt.es, j->init_flow.f(), j->init_flow.f() + L0.pl, j->w, j->h, L0.pitch, 2 * L0.pl, nb, fx, fy);
     } else {
         launch_copy_planes(ctx, L0.geo(all), L0.plane(P_WX), j->init_flow.f(), 2, L0.es, 2 * L0.pl);
     }
@@ -1292,10 +1293,9 @@ int sfa_job_run(sfa_job *j) {
         if (l < L - 1) {
             Level Ln = j->level(l + 1);
             const float fx = (1.0f * Lc.w) / Ln.w, fy = (1.0f * Lc.h) / Ln.h;                                   // :703-704
-            launch_resize(ctx, Lc.plane(P_WX), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WX), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fx);   // :711,716
-            launch_resize(ctx, Lc.plane(P_WY), Lc.w, Lc.h, Lc.pitch, Lc.pl, Lc.es, Ln.plane(P_WY), Ln.w, Ln.h, Ln.pitch, Ln.pl, Ln.es, 1, nb, fy);
+            launch_resize_flow(ctx, Lc.plane(P_WX), Lc.plane(P_WY), Lc.w, Lc.h, Lc.pitch, Lc.es, Ln.plane(P_WX), Ln.plane(P_WY), Ln.w, Ln.h, Ln.pitch, Ln.es, nb, fx, fy);   // :711,716
         }
-        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[j->share_sor ? 0 : l], j->cut_scratch, j->change.data(), l == 0 && j->keep_alt_occ ? j->occ_log.f() : nullptr));   // :761
+        SFA_TRY(run_level(ctx, Lc, p, cw, *j->sor[j->share_sor ? 0 : l], j->cut_scratch, l == 0 ? j->change.data() : nullptr, l == 0 && j->keep_alt_occ ? j->occ_log.f() : nullptr));   // :761
     }
     SFA_HIP(ctx, hipGetLastError());
     return SFA_OK;

@@ -1945,6 +1945,59 @@ void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl,
     launch_resize_scaled(c, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes, nb, post_scale, (double)sw / dw, (double)sh / dh);
 }
 
+// The flow field's two planes one level up (variational_mt.cpp:703-717): k_resize's arithmetic for both planes of a pixel at once -- the column's source index and
+// weight once per thread, the rows' once per block (LDS) -- four rows per thread.  As two launches of k_resize (an fp64 coordinate pair per pixel and plane) the step
+// ran at 1.9 TB/s.
+constexpr int kRfRows = 16;
+__global__ void __launch_bounds__(BX * 4) k_resize_flow(float *__restrict__ dx_, float *__restrict__ dy_, int dw, int dh, int dpitch, long des, const float *__restrict__ sx_,
+                                                         const float *__restrict__ sy_, int sw, int sh, int spitch, long ses, double scale_x, double scale_y, float post_x,
+                                                         float post_y) {
+    __shared__ int s_sy[kRfRows], s_sy1[kRfRows];
+    __shared__ float s_fy[kRfRows];
+    const int b = blockIdx.z;
+    const int dx = blockIdx.x * BX + threadIdx.x, dy0 = blockIdx.y * kRfRows;
+    if (threadIdx.y == 0 && threadIdx.x < kRfRows) {
+        const int dy = dy0 + threadIdx.x;
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        s_sy[threadIdx.x] = sy; s_sy1[threadIdx.x] = sy + 1 < sh ? sy + 1 : sy; s_fy[threadIdx.x] = fy;
+    }
+    __syncthreads();
+    if (dx >= dw) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+    const float a0 = 1.f - fx, a1 = fx;
+    const float *px = sx_ + b * ses, *py = sy_ + b * ses;
+#pragma unroll
+    for (int k = 0; k < kRfRows / 4; k++) {
+        const int ry = threadIdx.y + 4 * k, dy = dy0 + ry;
+        if (dy >= dh) break;
+        const size_t o0 = (size_t)s_sy[ry] * spitch, o1 = (size_t)s_sy1[ry] * spitch;
+        const float fy = s_fy[ry], b0 = 1.f - fy, b1 = fy;
+        const float x00 = px[o0 + sx], x01 = px[o0 + sx1], x10 = px[o1 + sx], x11 = px[o1 + sx1];
+        const float y00 = py[o0 + sx], y01 = py[o0 + sx1], y10 = py[o1 + sx], y11 = py[o1 + sx1];
+        float vx = (x00 * a0 + x01 * a1) * b0 + (x10 * a0 + x11 * a1) * b1;
+        float vy = (y00 * a0 + y01 * a1) * b0 + (y10 * a0 + y11 * a1) * b1;
+        if (post_x != 1.0f) vx *= post_x;                                              // image_mul_scalar after the flow resize (:679-680,716-717)
+        if (post_y != 1.0f) vy *= post_y;
+        const size_t o = b * des + (size_t)dy * dpitch + dx;
+        dx_[o] = vx; dy_[o] = vy;
+    }
+}
+void launch_resize_flow(sfa_ctx *c, float *dstx, float *dsty, int dw, int dh, int dpitch, long des, const float *srcx, const float *srcy, int sw, int sh, int spitch,
+                        long ses, int nb, float post_x, float post_y) {
+    const dim3 grid((dw + BX - 1) / BX, (dh + kRfRows - 1) / kRfRows, nb);
+    hipLaunchKernelGGL(k_resize_flow, grid, dim3(BX, 4), 0, c->stream, dstx, dsty, dw, dh, dpitch, des, srcx, srcy, sw, sh, spitch, ses, (double)sw / dw, (double)sh / dh,
+                       post_x, post_y);
+}
+
 // One pyramid step in one pass (variational_mt.cpp:607,611): GaussianBlur then resize of `nplanes` planes per window.  A block owns a
 // 64 x td tile of the DESTINATION (td = 32 when the footprint fits LDS: the row pass runs over the footprint plus 2r rows, 1.2x the tile at 32 rows
 // against 1.9x at 8); the source footprint (+ blur radius, replicated at the image border) is staged in LDS,

@@ -244,6 +244,8 @@ void launch_scale_plane(sfa_ctx *c, const Geo &g, float *p, float s);
 void launch_gauss_blur(sfa_ctx *c, const Geo &g, float *dst, float *tmp, const float *src, int nplanes, const float *taps, int radius);
 void launch_resize(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
                    int nplanes, int nb, float post_scale);
+void launch_resize_flow(sfa_ctx *c, float *dstx, float *dsty, int dw, int dh, int dpitch, long des, const float *srcx, const float *srcy, int sw, int sh, int spitch,
+                        long ses, int nb, float post_x, float post_y);   // both planes of a flow field, k_resize's arithmetic
 void launch_resize_scaled(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl,
                           long ses, int nplanes, int nb, float post_scale, double scale_x, double scale_y);
 bool launch_pyr_down(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dpl, long des, const float *src, int sw, int sh, int spitch, long spl, long ses,
