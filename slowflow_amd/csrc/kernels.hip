@@ -2009,6 +2009,7 @@ void launch_resize_flow(sfa_ctx *c, float *dstx, float *dsty, int dw, int dh, in
 #ifndef SFA_PYR_GROUP
 #define SFA_PYR_GROUP 4
 #endif
+constexpr int kPyrRB = 5;                                            // rows per item of the column pass
 template <int R>
 __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int dw, int dh, int dpitch, long dpl, long des, const float *__restrict__ src, int sw, int sh,
                                                   int spitch, long spl, long ses, int nplanes, double scale_x, double scale_y, Taps t, int CM, int RM, int td) {
@@ -2077,21 +2078,39 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
         if (cq >= CQ) { cq -= CQ; j++; }
     }
     __syncthreads();
-    // k_gauss_v, four columns per item
-    for (int j = tid / CQ, cq = tid % CQ; j < RM;) {
-        const int c = 4 * cq;
-        const float *col = Hb + (j + r) * CM + c;
-        const float4 ctr = *reinterpret_cast<const float4 *>(col);
-        float4 acc = make_float4(t.k[r] * ctr.x, t.k[r] * ctr.y, t.k[r] * ctr.z, t.k[r] * ctr.w);
+    // k_gauss_v, four columns of kPyrRB consecutive rows per item: the rows' 2r + kPyrRB inputs are read once (one row per item: 2r + 1 reads per output row --
+    // the column pass was 45 % of the kernel's LDS traffic)
+    constexpr int RB = kPyrRB;
+    for (int item = tid; item < (RM + RB - 1) / RB * CQ; item += 256) {
+        const int jg = item / CQ, c = 4 * (item % CQ), j0 = RB * jg;
+        float4 in[RB + 2 * r];
 #pragma unroll
-        for (int q = 1; q <= r; q++) {
-            const float4 up = *reinterpret_cast<const float4 *>(col - q * CM), dn = *reinterpret_cast<const float4 *>(col + q * CM);
-            const float kq = t.k[r + q];
-            acc.x += kq * (up.x + dn.x); acc.y += kq * (up.y + dn.y); acc.z += kq * (up.z + dn.z); acc.w += kq * (up.w + dn.w);
+        for (int i = 0; i < RB + 2 * r; i++) in[i] = *reinterpret_cast<const float4 *>(Hb + min(j0 + i, RS - 1) * CM + c);
+#pragma unroll
+        for (int o = 0; o < RB; o++) {
+            if (j0 + o >= RM) break;
+            const float4 ctr = in[o + r];
+            float4 acc = make_float4(t.k[r] * ctr.x, t.k[r] * ctr.y, t.k[r] * ctr.z, t.k[r] * ctr.w);
+#pragma unroll
+            for (int q = 1; q <= r; q++) {
+                const float4 up = in[o + r - q], dn = in[o + r + q];
+                const float kq = t.k[r + q];
+                acc.x += kq * (up.x + dn.x); acc.y += kq * (up.y + dn.y); acc.z += kq * (up.z + dn.z); acc.w += kq * (up.w + dn.w);
+            }
+            *reinterpret_cast<float4 *>(V + (j0 + o) * CM + c) = acc;
         }
-        *reinterpret_cast<float4 *>(V + j * CM + c) = acc;
-        cq += dcq; j += djq;
-        if (cq >= CQ) { cq -= CQ; j++; }
+    }
+    // the tile's rows: source rows and weight (k_resize's arithmetic), once per block
+    int *s_sy = reinterpret_cast<int *>(Hb + RS * CM), *s_sy1 = s_sy + td;
+    float *s_fy = reinterpret_cast<float *>(s_sy1 + td);
+    if (tid < td) {
+        const int dy = dy0 + tid;
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        s_sy[tid] = (sy - my0) * CM; s_sy1[tid] = ((sy + 1 < sh ? sy + 1 : sy) - my0) * CM; s_fy[tid] = fy;
     }
     __syncthreads();
     const int dx = dx0 + threadIdx.x;
@@ -2104,16 +2123,10 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
     const int sx1 = sx + 1 < sw ? sx + 1 : sx;
     const float a0 = 1.f - fx, a1 = fx;
     for (int k = 0; k < td / 4; k++) {
-        const int dy = dy0 + threadIdx.y + 4 * k;
+        const int ry = threadIdx.y + 4 * k, dy = dy0 + ry;
         if (dy >= dh) break;
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= sy;
-        if (sy < 0) { fy = 0; sy = 0; }
-        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
-        const int sy1 = sy + 1 < sh ? sy + 1 : sy;
-        const float *r0 = V + (sy - my0) * CM - mx0, *r1 = V + (sy1 - my0) * CM - mx0;
-        const float b0 = 1.f - fy, b1 = fy;
+        const float *r0 = V + s_sy[ry] - mx0, *r1 = V + s_sy1[ry] - mx0;
+        const float fy = s_fy[ry], b0 = 1.f - fy, b1 = fy;
         const float h0 = r0[sx] * a0 + r0[sx1] * a1;
         const float h1 = r1[sx] * a0 + r1[sx1] * a1;
         dst[b * des + pl * dpl + (size_t)dy * dpitch + dx] = h0 * b0 + h1 * b1;
@@ -2128,7 +2141,7 @@ bool launch_pyr_down(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dp
     size_t lds = 0;
     for (;; td /= 2) {                                               // the tallest tile whose footprint fits
         RM = (int)ceil(td * scale_y) + 2; RS = RM + 2 * radius;
-        lds = (size_t)(RS * CS + RS * CM) * sizeof(float);          // the column pass writes over the staged footprint (RM * CM <= RS * CS)
+        lds = (size_t)(RS * CS + RS * CM + 3 * td) * sizeof(float);  // the column pass writes over the staged footprint (RM * CM <= RS * CS); + the rows' sampling table
         if (lds <= 40 * 1024 || td == 8) break;                     // 40 KB: four blocks per CU
     }
     if (lds > 60 * 1024 || radius > 8) return false;
