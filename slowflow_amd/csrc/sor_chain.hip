@@ -136,7 +136,17 @@ struct ChainShape {
     // interval old); every stage of one sweep (the lone solve): the whole chunk at its top (PF1 = CH); 8 stages and more (register budget) or mixed with
     // one-sweep stages: one step.  tools/sim_sor_chain.py ring_prefetch / ring_hazards carry the same rule and check it against the barrier lockstep.
     static constexpr bool MULTI = FA >= 2 && (NB_ == 0 || FB >= 2) && NW < 8, LONE = FA == 1 && NB_ == 0 && NW < 8;
-    static constexpr int PF0 = MULTI ? SFA_CHAIN_PF : LONE ? SFA_CHAIN_PF1 : 1;       // first stage (for one-sweep stages: nothing is ring-fed there)
+    // INFILL (the one-sweep shapes: a lone solve): a FILL wave (wave NW + 2) copies the WHOLE operand row of every step -- the KG - 1 entries above the band and the
+    // band's own 64 -- from memory into the ring by LDS-DMA, four rows per interval, and the first stage reads the ring like every other stage.  With its operand
+    // loads, its two 16-byte ring writes per step and the refill arithmetic the first stage needed 1 080 cycles per chunk where the other stages need 810-840
+    // (tools/chain_timing.py, each wave alone on its SIMD), and everybody waited for it at the barrier.  (The same rows fetched by the IN wave through registers:
+    // correct, and 8 % slower -- that wave is busy 700 of an interval's 1 270 cycles as it is.)
+#ifndef SFA_CHAIN_INFILL
+#define SFA_CHAIN_INFILL 1
+#endif
+    static constexpr bool INFILL = SFA_CHAIN_INFILL && LONE && SFA_CHAIN_PF1 == 4;
+    static constexpr int NWAVES = NW + 2 + (INFILL ? 1 : 0);
+    static constexpr int PF0 = MULTI ? SFA_CHAIN_PF : LONE ? SFA_CHAIN_PF1 : 1;       // first stage (one-sweep stages: ring-fed only with INFILL)
     static constexpr int PFL = MULTI ? SFA_CHAIN_PFL : LONE ? SFA_CHAIN_PF1 : 1;      // stages 1 ..
     // Which stage a wave runs (wave 0 = IN, wave NW + 1 = OUT).  Waves i, i + 4, i + 8 of a workgroup share a SIMD.  Seven stages of 3,2,2,2,2,2,2 sweeps: nine
     // waves -- SIMD 0 takes the two I/O waves and the 3-sweep first stage (wave 4), the other three SIMDs two 2-sweep stages each: at most 4 sweeps on a SIMD where
@@ -186,7 +196,10 @@ struct ChainLds {
 #ifndef SFA_X_OPR_CUT      // timing experiment only (rows BELOW the derived minimum: a slot may be rewritten before its last read)
 #define SFA_X_OPR_CUT 0
 #endif
-    static constexpr int OPR = (OPR10 ? OPRMIN + 1 : OPR00 ? OPRMIN : OPRTIGHT) - SFA_X_OPR_CUT, OPPLANE = OPR * OPROWB;
+    // INFILL: a group of four rows (4 c .. 4 c + 3) is in flight from the start of interval c to the end of interval c + 1 (chain_fill), where the IN wave wrote the
+    // entries above the band in interval c + AH: the slot has to be free AH intervals = 4 AH rows earlier; a multiple of four rows, so that a group never wraps
+    static constexpr int OPRFILL = (OPRMIN + 1 + 4 * 2 + 3) / 4 * 4;
+    static constexpr int OPR = S::INFILL ? OPRFILL : (OPR10 ? OPRMIN + 1 : OPR00 ? OPRMIN : OPRTIGHT) - SFA_X_OPR_CUT, OPPLANE = OPR * OPROWB;
     static constexpr bool OPRING = SFA_CHAIN_OPRING && S::KG <= 16 && ops0 + 2 * OPPLANE + 32 <= 160 * 1024;
     static constexpr int ticket = ops0 + (OPRING ? 2 * OPPLANE : 0);
     static constexpr int total = ticket + 16;
@@ -577,7 +590,7 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
     unsigned char *const ldsb = lds;
     // operand ring (ChainLds): the KG - 1 entries above the band of the rows the first stage reads -- chunk I of its local steps is fetched at interval I
     // (lane = step of the chunk x entry) and written AH intervals later, one interval before the first stage uses (and writes) the rows themselves
-    constexpr bool OPX = L::OPRING;
+    constexpr bool OPX = L::OPRING && !S::INFILL;                    // (INFILL: the FILL wave brings whole rows)
     const int xj = lane >> 4, xe = lane & 15;
     const bool ox_on = OPX && xj < CH && xe < S::KG - 1;
     const long ox_e = G.U00 + (long)G.s_start0 * RP - (S::KG - 1);
@@ -661,6 +674,55 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
         o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
+}
+
+// ---- FILL wave (ChainShape::INFILL): the operand rows of the first stage's steps, memory -> ring by LDS-DMA ----------------------------------------------
+// Row r of the ring = the first stage's local step r = OPW consecutive entries of a diagonal of SA / SB (the KG - 1 rows above the band, then the band's 64): both
+// in memory and in the ring a row is one contiguous piece, and the four rows of a group (4 c .. 4 c + 3) follow each other in the ring (OPR is a multiple of 4).
+// Interval c: the group's 4 OPW quads per plane are issued (lane n of the k-th instruction: quad 64 k + n, i.e. row (64 k + n) / OPW, entry (64 k + n) % OPW);
+// before the next barrier everything but this interval's instructions has landed (counted vmcnt: nothing but these DMAs is in this wave's queue).  Group c is
+// therefore complete before interval c + 2 starts; the first stage reads rows 4 c + 1 .. 4 c + 4 at the top of its chunk c, in interval c + LEAD = c + AH + 1.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void chain_dma16(const void *sbase, unsigned voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <class S, int CH, int AH>
+__device__ __forceinline__ void chain_fill(const ChainArgs &a, unsigned char *lds, int job, int b, int g, int c_first, int lane) {
+    using L = ChainLds<S, CH>;
+    static_assert(AH == 2 && CH == 4 && L::OPR % CH == 0, "group c is read from interval c + AH + 1 on and complete before interval c + 2");
+    constexpr int NQ = CH * L::OPW, ND = (NQ + 63) / 64;
+    static_assert(2 * ND <= 63, "vmcnt is a 6-bit counter");
+    const ChainGeo<S, CH> G(a, b, g, c_first);
+    const long e0 = (long)job * a.ent + G.U00 + (long)G.s_start0 * G.RP - (S::KG - 1);       // entry 0 of row 0
+    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)(lds + L::ops0);
+    unsigned voff[ND];
+    bool on[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        const int n = 64 * k + lane, j = n / L::OPW, e = n % L::OPW;
+        on[k] = n < NQ;
+        voff[k] = (unsigned)((j * G.RP + e) * 16);
+    }
+    const float4 *pa = a.sa + e0, *pb = a.sb + e0;
+    const long step = (long)CH * G.RP;                               // entries per group
+    int row = 0;                                                     // ring row of the group issued next
+    for (int I = 0; I < a.NI; I++) {
+        SFA_CHAIN_BARRIER();
+        const unsigned dst = lds0 + (unsigned)row * (unsigned)L::OPROWB;
+#pragma unroll
+        for (int k = 0; k < ND; k++) {
+            if (on[k]) {
+                chain_dma16(pa, voff[k], dst + 1024u * k);
+                chain_dma16(pb, voff[k], dst + (unsigned)L::OPPLANE + 1024u * k);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ND) : "memory");
+        pa += step; pb += step;
+        row = row + CH >= L::OPR ? 0 : row + CH;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---- OUT wave: lane 63's iterates and the group's last iterate leave (sc1 write-through); the workgroup's progress word follows PUBD
@@ -780,7 +842,7 @@ template <int FA, int NA, int FB, int NB_, int CH, int PD, int AH, int PL, int P
 #ifdef SFA_CHAIN_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(SFA_CHAIN_WAVES_PER_EU, SFA_CHAIN_WAVES_PER_EU)))
 #endif
-__global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) {
+__global__ void __launch_bounds__((ChainShape<FA, NA, FB, NB_>::NWAVES * 64)) k_sor_chain(ChainArgs a) {
     using S = ChainShape<FA, NA, FB, NB_>;
     using L = ChainLds<S, CH>;
     constexpr int NW = S::NW, LEAD = AH + 1;
@@ -790,7 +852,7 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
     unsigned *s_ticket = reinterpret_cast<unsigned *>(smem + L::ticket);
     if (threadIdx.x == 0) *s_ticket = atomicAdd(a.gflags + (size_t)a.nb * a.NB * a.NG * kFlagStride, 1u);
     // the rings and staging areas are read before they are first written (start-up intervals): zeros, not garbage
-    for (int i = threadIdx.x; i < L::ticket / 8; i += (NW + 2) * 64) reinterpret_cast<unsigned long long *>(smem)[i] = 0ull;
+    for (int i = threadIdx.x; i < L::ticket / 8; i += S::NWAVES * 64) reinterpret_cast<unsigned long long *>(smem)[i] = 0ull;
     __syncthreads();
     const unsigned t = __builtin_amdgcn_readfirstlane(*s_ticket);
     if (t >= (unsigned)(a.nb * a.NB * a.NG)) return;
@@ -897,6 +959,7 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
 #endif
     if (wave == 0) { chain_in<S, CH, AH, PL>(a, smem, job, b, g, c_first, c_first_prev, lane); return; }
     if (wave == NW + 1) { chain_out<S, CH, AH, PUBD>(a, smem, job, b, g, c_first, lane); return; }
+    if (S::INFILL && wave == NW + 2) { if constexpr (S::INFILL) chain_fill<S, CH, AH>(a, smem, job, b, g, c_first, lane); return; }
     const int w = S::stage_of_wave(wave);
     const int st = g * NW + w, k0 = g * S::KG + S::kw(w), O = k0 - st + 1;
     const int s_start = c_first * CH - O;
@@ -905,7 +968,7 @@ __global__ void __launch_bounds__((NA + NB_ + 2) * 64) k_sor_chain(ChainArgs a) 
     constexpr bool SHORT = NW >= 8;                  // many waves per workgroup: fewer registers each
     constexpr int PF0 = S::PF0, PFL = S::PFL;              // read-ahead of the operand ring (ChainShape)
     if (L::OPRING) {
-        if (w == 0)      chain_compute<FA, CH, PD, SHORT, 1, L::ops0, L::OPR, L::OPROWB, S::KG, PF0>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, 0, 0);
+        if (w == 0)      chain_compute<FA, CH, PD, SHORT, S::INFILL ? 2 : 1, L::ops0, L::OPR, L::OPROWB, S::KG, PF0>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, 0, 0);
         else if (w < NA) chain_compute<FA, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PFL>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
         else             chain_compute<FB, CH, PD, SHORT, 2, L::ops0, L::OPR, L::OPROWB, S::KG, PFL>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane, S::kw(w), w);
     } else if (w < NA) chain_compute<FA, CH, PD, SHORT>(a, smem, ring_in, ring_out, tvb, esb, L::dummy0, job, b, k0, s_start, LEAD + w, lane);
@@ -944,6 +1007,8 @@ static const ChainShapeInfo kChainShapes[] = {
     {12, 2, 3, 3, 3, 2, 2, 2},     // 3 stages of 2 + 3 of 3         KG = 15
     {13, 3, 1, 2, 6, 2, 1, 1},     // 1 stage of 3 + 6 of 2          KG = 15: nine waves, at most 4 sweeps on a SIMD (ChainShape::stage_of_wave)
     {16, 1, 5, 1, 0, 4, 1, 1},     // 5 stages of 1, one-interval poll / publication lags: the lone solve
+    {17, 1, 3, 1, 0, 4, 1, 1},     // 3 stages of 1 with the same lags: every compute wave alone on its SIMD, ten groups per band
+    {19, 1, 6, 1, 0, 4, 1, 1},     // 6 stages of 1: five groups per band
 };
 
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
@@ -987,6 +1052,8 @@ int chain_shift(int id) {
         case 16: return shape_shift<1, 5, 1, 0>();
         case 12: return shape_shift<2, 3, 3, 3>();
         case 13: return shape_shift<3, 1, 2, 6>();
+        case 17: return shape_shift<1, 3, 1, 0>();
+        case 19: return shape_shift<1, 6, 1, 0>();
     }
     return 0;
 }
@@ -1012,7 +1079,7 @@ static int chain_launch_shape(sfa_ctx *c, const ChainArgs &a, int nwg) {
                              hipGetErrorString(e));
         attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, PL, PUBD>), dim3(nwg), dim3((S::NW + 2) * 64), lds, c->stream, a);
+    hipLaunchKernelGGL((k_sor_chain<FA, NA, FB, NB_, kChainCH, PD, kChainAH, PL, PUBD>), dim3(nwg), dim3(S::NWAVES * 64), lds, c->stream, a);
     return SFA_OK;
 }
 
@@ -1038,6 +1105,8 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
         case 16: return chain_launch_shape<1, 5, 1, 0, 4, 1, 1>(c, a, nwg);
         case 12: return chain_launch_shape<2, 3, 3, 3, 2>(c, a, nwg);
         case 13: return chain_launch_shape<3, 1, 2, 6, 2, 1, 1>(c, a, nwg);
+        case 17: return chain_launch_shape<1, 3, 1, 0, 4, 1, 1>(c, a, nwg);
+        case 19: return chain_launch_shape<1, 6, 1, 0, 4, 1, 1>(c, a, nwg);
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }
 }

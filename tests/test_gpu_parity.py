@@ -289,7 +289,9 @@ SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH":
                 # round 5: seven stages of 3,2,2,2,2,2,2 sweeps on nine waves (at most 4 sweeps on a SIMD), the operand ring at its tight depth of 51 rows
                 "chain_3x1_2x6": {"SFA_SOR_CHAIN": "13"},
                 # 1 x 5 with one-interval poll / publication lags (the lone-solve default; 11 runs with them too)
-                "chain_1x5_lags1": {"SFA_SOR_CHAIN": "16"}}
+                "chain_1x5_lags1": {"SFA_SOR_CHAIN": "16"},
+                # round 5: the one-sweep shapes take their operand rows from a FILL wave (LDS-DMA) and the first stage reads the ring too; 1 x 3 and 1 x 6 with the lone solve's lags
+                "chain_1x3_lags1": {"SFA_SOR_CHAIN": "17"}, "chain_1x6_lags1": {"SFA_SOR_CHAIN": "19"}}
 
 
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))

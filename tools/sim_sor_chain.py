@@ -51,6 +51,7 @@ def ring_rows(S):
     pfl = ring_prefetch(S)[1]
     tight = derived - (pfl - 1 if isinstance(pfl, int) else 0)     # ChainLds::OPRTIGHT: the bound itself, lowered by the later stages' read-ahead (3,2,2,2,2,2,2: 51 rows)
     opr = oprmin + 1 if fits(oprmin + 1) else oprmin if fits(oprmin) else tight
+    if ring_infill(S): opr = (oprmin + 1 + 4 * AH + 3) // 4 * 4   # ChainLds::OPRFILL: the FILL wave's groups of four rows are in flight AH intervals earlier than the IN wave wrote
     return (opr, derived) if KG <= 16 and fits(opr) else (0, derived)
 
 
@@ -63,29 +64,43 @@ def ring_prefetch(S):
     return (1, 1)
 
 
-def ring_hazards(S, OPR, PF, nsteps=600):
+def ring_infill(S):
+    """ChainShape::INFILL: a FILL wave copies whole operand rows (the entries above the band and the band's own) into the ring by LDS-DMA and the first stage is ring-fed
+    like the others (the one-sweep shapes)"""
+    return S.FA == 1 and S.NB_ == 0 and S.NW < 8
+
+
+def ring_hazards(S, OPR, PF, nsteps=600, infill=False):
     """The LDS operand ring of chain_compute under the barrier lockstep (compute wave w runs its chunk c in interval LEAD + w + c; accesses of DIFFERENT waves inside one
     interval are unordered, a wave's own accesses keep program order).  Row r (the first stage's step r) is written by the IN wave (the KG - 1 entries above the band) in
     interval r // CH + AH and by the first stage in its step r (interval LEAD + r // CH); sweep kappa of stage w uses row i + w - 2 kappa at its step i and reads it at
-    the END of step i - PF (before the first barrier when i < PF); row r + OPR lands in row r's slot.  Returns the violated dependencies."""
+    the END of step i - PF (before the first barrier when i < PF); row r + OPR lands in row r's slot.  Returns the violated dependencies.
+    infill (ChainShape::INFILL): nobody but the FILL wave writes the ring -- the DMA of rows 4 c .. 4 c + 3 is issued in interval c and has landed when interval c + 1
+    ends (chain_fill's counted wait): a row may change at any time in between --, and the first stage's sweep reads the ring like the others'."""
     bad = []
     w_in = lambda r: r // CH + AH
+    f_issue = lambda r: r // CH                                     # infill: the interval in which the DMA of row r is issued ...
+    f_done = lambda r: r // CH + 1                                  # ... and the one by whose end it has landed
     w_st = lambda r: LEAD + r // CH
     PF_of = PF if isinstance(PF, tuple) else (PF, PF)              # (first stage, later stages)
     for w in range(S.NW):
         PF = PF_of[0] if w == 0 else PF_of[1]
         for f in range(S.Fw(w)):
             kap = S.kw(w) + f
-            if w == 0 and f == 0: continue                                   # the group's first sweep loads from memory
+            if w == 0 and f == 0 and not infill: continue                    # the group's first sweep loads from memory
             for i in range(nsteps):
                 rho = i + w - 2 * kap
                 if PF == "chunk":                                            # read at the top of the chunk of step i - 1 (step 0: before the first barrier); ring-fed stages w >= 1 only
-                    if w == 0: bad.append(("raw-self", w, kap, i)); continue
+                    if w == 0 and not infill: bad.append(("raw-self", w, kap, i)); continue
                     issue = -1 if i == 0 else (i - 1) // CH * CH - 1         # "behind step issue": the chunk top lies behind the last step of the chunk before
                     t_read = 0 if i == 0 else LEAD + w + (i - 1) // CH
                 else:
                     issue = i - PF
                     t_read = 0 if issue < 0 else LEAD + w + issue // CH
+                if infill:
+                    if rho >= 0 and t_read > 0 and not f_done(rho) < t_read: bad.append(("raw-fill", w, kap, i))   # (reads before the first barrier see the initial zeros: steps in the guards)
+                    if rho + OPR >= 0 and not t_read < f_issue(rho + OPR): bad.append(("war", w, kap, i))
+                    continue
                 if rho >= 0:                                                 # read after write (rows < 0 are never written: the ring's initial zeros)
                     if w == 0 and not rho <= issue: bad.append(("raw-self", w, kap, i))          # the first stage's own trailing sweeps: program order inside the wave
                     if w > 0 and not w_st(rho) < t_read: bad.append(("raw", w, kap, i))
