@@ -282,7 +282,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     constexpr int kLag = kMaskLag, kRing = kMaskRing;
     const bool dbg = sw_given(Switches::DEBUG_ACTIVE);
     g.amask = c->d_amask;
-    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double), c->stream));
+    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned), c->stream));   // (+ the windows' finished-block counters of k_update_outer_x)
     launch_set_mask(c, all);
 
     for (int alter = 0; alter < p.niter_alter; alter++) {
@@ -491,7 +491,8 @@ int sfa_ctx_create(int device, sfa_ctx **out) {
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_red, kRedDoubles * sizeof(double)));
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, 2 * kMaxBatch * sizeof(double) + 64, hipHostMallocDefault));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_amask, 64));
-    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double)));
+    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned)));
+    SFA_HIP(c.get(), hipMemset(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned)));
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, kMaskRing * sizeof(WMask), hipHostMallocDefault));
     for (auto &e : c->ev_mask) SFA_HIP(c.get(), hipEventCreateWithFlags(&e, hipEventDisableTiming));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_err, 64));

@@ -1703,14 +1703,17 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ u
 // wx <- uu (:412-429) in one pass; the inner norms are not formed (nobody reads them after the last inner iteration)
 // The x plane is diagonal-major: a row-major reader would touch one 8-byte entry per 5 KB.  A block therefore takes 64x16 tiles, reads them
 // along the anti-diagonals (16 consecutive entries = 128 B each, as k_sor_prepare writes them) into LDS and works row-major from there.
+template <bool FUSE>
 __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ uu, float *__restrict__ vv, float *__restrict__ wx, float *__restrict__ wy,
-                                                            const unsigned long long *__restrict__ xs, long ent, int RP, int G, double *__restrict__ partial, Geo g) {
+                                                            const unsigned long long *__restrict__ xs, long ent, int RP, int G, double *__restrict__ partial,
+                                                            double *__restrict__ out, unsigned *__restrict__ done, Geo g) {
     __shared__ unsigned long long tX[16][67];                    // 67: the 16 rows of an anti-diagonal land on distinct banks (65 put them all on one: 69 % conflict cycles)
     const int b = blockIdx.z;
     const int tid = threadIdx.y * BX + threadIdx.x;
     const int c0 = blockIdx.x * 64;
     double sa = 0, sb = 0;
-    if (elem_active(g, b))
+    if (!elem_active(g, b)) return;                              // a passenger: its result words keep their last values
+    {
         for (int r0 = blockIdx.y * 16; r0 < g.h; r0 += gridDim.y * 16) {
             __syncthreads();
             for (int item = tid; item < (64 + 16 - 1) * 16; item += BX * BY) {
@@ -1737,11 +1740,47 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ u
                     wx[o] = u; wy[o] = v;                                                 // :428-429
                 }
         }
-    block_sum2(sa, sb);
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
     }
+    block_sum2(sa, sb);
+    if (!FUSE) {
+        if (tid == 0) {
+            const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            partial[2 * blk] = sa; partial[2 * blk + 1] = sb;
+        }
+        return;
+    }
+    // FUSE (launches of a few windows): the window's LAST block to finish sums the window's partials -- k_reduce_partials folded in (a launch of its own per iteration:
+    // 4.6 us, a quarter of what this kernel takes for a lone window), in that kernel's order: 256 strided sums, then the tree.  The partials cross XCDs, whose L2s are
+    // not coherent: they are written through and read past the L2 (agent-scope atomics = sc1), and the ticket is drawn behind the stores' completion (vmcnt counts
+    // stores on gfx9).  Not for large batches: 256 tickets per window on one word and a wait for the block's stores in front of each cost the 128-window launch
+    // 30 % (the whole path 1.5 %).
+    __shared__ unsigned s_last;
+    const int per_elem = gridDim.x * gridDim.y;
+    if (tid == 0) {
+        const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        __hip_atomic_store(&partial[2 * blk], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partial[2 * blk + 1], sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(&done[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(per_elem - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __hip_atomic_store(&done[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    double ra = 0, rb = 0;
+    for (int i = tid; i < per_elem; i += BX * BY) {
+        ra += __hip_atomic_load(&partial[2 * ((size_t)b * per_elem + i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rb += __hip_atomic_load(&partial[2 * ((size_t)b * per_elem + i) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static_assert(BX * BY == 256, "k_reduce_partials' order");
+    double *s0 = reinterpret_cast<double *>(&tX[0][0]), *s1 = s0 + 256;          // the tile is dead: 2 x 256 doubles of its 16 x 67
+    __syncthreads();
+    s0[tid] = ra; s1[tid] = rb;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) { s0[tid] += s0[tid + off]; s1[tid] += s1[tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) { out[2 * b] = s0[0]; out[2 * b + 1] = s1[0]; }
 }
 __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx, float *__restrict__ wy, const float *__restrict__ uu, const float *__restrict__ vv,
                                                           double *__restrict__ partial, Geo g) {
@@ -1825,10 +1864,16 @@ void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const
     hipLaunchKernelGGL(k_update_inner_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, old_du, old_dv, du_out, dv_out, partials_of(c), g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
+constexpr int kFuseReduceWindows = 4;      // launches of up to that many windows sum their partials in k_update_outer_x itself
 void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red) {
     dim3 grid((g.w + 63) / 64, std::min((g.h + 15) / 16, kRedRows), g.nb);
     const int per_elem = grid.x * grid.y;
-    hipLaunchKernelGGL(k_update_outer_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), g);
+    unsigned *done = reinterpret_cast<unsigned *>(c->d_last + 2 * kMaxBatch);
+    if (g.nb <= kFuseReduceWindows) {
+        hipLaunchKernelGGL(k_update_outer_x<true>, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), red, done, g);
+        return;
+    }
+    hipLaunchKernelGGL(k_update_outer_x<false>, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), red, done, g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red) {

@@ -57,7 +57,7 @@ struct sfa_ctx {
     // thresholds on the device (variational_mt.cpp:436): the windows still iterating, the norms of each window's last iteration, and a ring of pinned
     // copies of the mask (one per outer iteration in flight) with the events that say a copy has landed
     unsigned long long *d_amask = nullptr;         // kMaskWords words
-    double *d_last = nullptr;                      // 2 * kMaxBatch doubles
+    double *d_last = nullptr;                      // 2 * kMaxBatch doubles, then kMaxBatch counters (k_update_outer_x)
     sfa::WMask *h_amask = nullptr;                      // kMaskRing pinned masks
     hipEvent_t ev_mask[sfa::kMaskRing] = {};
     unsigned *d_err = nullptr;    // device error/timeout word
