@@ -170,10 +170,13 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
     //      both tools with system() (MATLAB + a binary, third-party); this build reads their outputs from the reference's own locations and says so if they are missing.
     const bool verbose_changes = params.verbosity(VER_CMD);       // the library prints the reference's "inner it / outer it ... avg change" lines (variational_mt.cpp:404-405, 431-432): per worker context
     const bool enable_dm = params.parameter<bool>("deep_matching");
+    // dm_scale (:396-402, :571-586, :801-843): DeepMatching and the edge detector ran on frames blurred (sigma = 1 / sqrt(2 dm_scale)) and resized by dm_scale; the
+    // interpolation then runs at that resolution (the saliency image, the edge map, the matches' coordinates) and its flow is resized to the frames and multiplied by the
+    // INTEGER ratio of the widths (:827-828: `float fx = im[ref]->width / wx->width` divides two ints).  dm_scale_run = dm_scale, halved by main() when max_flow > 150
+    const double dm_scale = params.exists("dm_scale_run") ? params.parameter<double>("dm_scale_run") : (double)params.parameter<float>("dm_scale", "1.0");
     auto edges_file = [&](int frame_number) { return params.output + "tmp/edges_" + std::to_string(frame_number) + ".dat"; };                    // :740-741
     auto matches_file = [&](int a, int b) { return params.output + "tmp/matches_" + std::to_string(a) + "_" + std::to_string(b) + ".dat"; };    // :742-743
     if (enable_dm) {
-        if (params.parameter<float>("dm_scale", "1.0") != 1.0f) { std::cerr << "deep_matching with dm_scale != 1 is not supported: provide matches and edges at the frames' resolution" << std::endl; return 2; }
         for (unsigned j = start_j; j < end_j; j++) {
             if (!jet_pending(j)) continue;                                           // -resume: a jet whose two flows exist is skipped below and needs no inputs
             const int a = (int)params.sequence_start + (int)j * steps * skip, b = a + ref * skip;
@@ -560,31 +563,63 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                 epic_params_t ep;
                 epic_params_default(&ep);
                 ep.pref_nn = 25; ep.nn = 160; ep.coef_kernel = 1.1f;         // :271-275
-                if (!read_matches((wd.backward ? matches_file(b, a) : matches_file(a, b)).c_str(), mt) ||
-                    !read_edges((wd.backward ? edges_file(b) : edges_file(a)).c_str(), width, height, ed)) rc = SFA_ERR_ARG;
+                // the resolution the interpolation runs at: cv::resize(img, img, Size(0, 0), dm_scale, dm_scale) makes cvRound(cols * dm_scale) x cvRound(rows * dm_scale)
+                const int ew = dm_scale != 1 ? (int)std::lrint(width * dm_scale) : (int)width, eh = dm_scale != 1 ? (int)std::lrint(height * dm_scale) : (int)height;
+                if (ew < 1 || eh < 1 || !read_matches((wd.backward ? matches_file(b, a) : matches_file(a, b)).c_str(), mt) ||
+                    !read_edges((wd.backward ? edges_file(b) : edges_file(a)).c_str(), ew, eh, ed)) rc = SFA_ERR_ARG;
                 else {
                     // the reference hands epic() un_seq: the frame after img.convertTo(CV_8U, norm), i.e. rounded to nearest and saturated to 0..255,
                     // 16-bit samples scaled by 1/255 first (slow_flow.cpp:472-474, :578-586) -- not the float frame the refinement reads
                     const int fi = wd.backward ? f + 2 * ref : f + ref;
-                    color_image_t *un8 = color_image_new(un_ref->width, un_ref->height);
+                    // :571-573: GaussianBlur(sigma = 1 / sqrt(2 dm_scale), BORDER_REPLICATE) then resize by dm_scale, on the float frame (the pyramid's two
+                    // operators: sfa_gaussian_blur, sfa_resize_linear_fx with cv::resize's fx / fy form of the coordinate scale)
+                    color_image_t *small = nullptr;
+                    if (dm_scale != 1) {
+                        small = color_image_new(ew, eh);
+                        std::vector<float> tmp((size_t)un_ref->stride * un_ref->height);
+                        const float sigma = (float)(1 / sqrt(2 * dm_scale));
+                        float *src3[3] = {un_ref->c1, un_ref->c2, un_ref->c3}, *dst3[3] = {small->c1, small->c2, small->c3};
+                        for (int ch = 0; ch < 3 && rc == SFA_OK; ch++) {
+                            rc = sfa_gaussian_blur(ctx, tmp.data(), src3[ch], un_ref->width, un_ref->height, un_ref->stride, sigma);
+                            if (rc == SFA_OK) rc = sfa_resize_linear_fx(ctx, dst3[ch], ew, eh, small->stride, tmp.data(), un_ref->width, un_ref->height, un_ref->stride, dm_scale, dm_scale);
+                        }
+                    }
+                    const color_image_t *un_src = small ? small : un_ref;
+                    color_image_t *un8 = color_image_new(un_src->width, un_src->height);
                     {
                         const float norm = seq_maxval[fi] > 255 ? 1.0f / 255 : 1.0f;
-                        const size_t n3 = (size_t)3 * un_ref->stride * un_ref->height;
+                        const size_t n3 = (size_t)3 * un_src->stride * un_src->height;
                         for (size_t i = 0; i < n3; i++) {
-                            const float v = nearbyintf(un_ref->c1[i] * norm);              // cvRound: to nearest, ties to even
+                            const float v = nearbyintf(un_src->c1[i] * norm);              // cvRound: to nearest, ties to even
                             un8->c1[i] = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);       // saturate_cast<uchar>
                         }
                     }
+                    if (small) color_image_delete(small);
                     color_image_t *lab = rgb_to_lab(un8);
                     color_image_delete(un8);
-                    iwx = image_new(width, height); iwy = image_new(width, height);
+                    iwx = image_new(ew, eh); iwy = image_new(ew, eh);
                     image_erase(iwx); image_erase(iwy);
-                    const int er = epic(ctx, iwx, iwy, lab, mt, ed, &ep);
+                    const int er = rc == SFA_OK ? epic(ctx, iwx, iwy, lab, mt, ed, &ep) : -1;
                     color_image_delete(lab);
-                    if (er < 0) rc = SFA_ERR_HIP;
+                    if (er < 0) rc = rc == SFA_OK ? SFA_ERR_HIP : rc;
                     else if (er > 0) { image_erase(iwx); image_erase(iwy); }  // no usable match: start from zero like deep_matching 0
-                    image_mul_scalar(iwx, 1.0f / steps);                    // :842-843
-                    image_mul_scalar(iwy, 1.0f / steps);
+                    // :826-843: rescale flow.  fx, fy are quotients of ints; only when fx != 1 is the field resized (cv::resize to the frame's size: the ratio form)
+                    const float fx = (float)((int)width / ew), fy = (float)((int)height / eh);
+                    if (rc == SFA_OK && fx != 1) {
+                        image_t *fwx = image_new(width, height), *fwy = image_new(width, height);
+                        rc = sfa_resize_linear(ctx, fwx->data, width, height, fwx->stride, iwx->data, ew, eh, iwx->stride);
+                        if (rc == SFA_OK) rc = sfa_resize_linear(ctx, fwy->data, width, height, fwy->stride, iwy->data, ew, eh, iwy->stride);
+                        image_delete(iwx); image_delete(iwy);
+                        iwx = fwx; iwy = fwy;
+                    } else if (rc == SFA_OK && (ew != (int)width || eh != (int)height)) {
+                        // the reference would hand a field of the reduced size to a solver of the frames' size here (1 < width ratio < 2): it has no defined result
+                        std::lock_guard<std::mutex> l(io_mu);
+                        std::cerr << "dm_scale " << dm_scale << ": the frames are " << width << " wide, the interpolation " << ew << " -- the reference rescales by the integer ratio "
+                                  << (int)width / ew << " (slow_flow.cpp:827) and would keep the reduced field; use a dm_scale of 1 / n" << std::endl;
+                        rc = SFA_ERR_ARG;
+                    }
+                    image_mul_scalar(iwx, fx / steps);                      // :842-843
+                    image_mul_scalar(iwy, fy / steps);
                     if (rc == SFA_OK && params.verbosity(WRITE_FILES) && !wd.backward)     // :845-858
                         png_write((params.output + "tmp/frame_" + std::to_string(a) + "_INIT.png").c_str(), flowColorImg(iwx, iwy, 0));
                 }
@@ -801,12 +836,19 @@ int main(int argc, char **argv) {
         }
         adaptive = params.parameter<bool>("adaptive", "0");
     }
+    // :197-200, :306: the bound on the flow DeepMatching may find -- it restricts the matcher's search (outside this build) and halves dm_scale beyond 150 px (:397-402)
+    double max_flow = params.exists("max_flow") ? std::max(5.0f, params.parameter<float>("max_flow")) : 50.0, orig_max_flow = 0;
+    const double scale_main = params.parameter<float>("scale", "1.0");
     const string qfstr = sequence_path + "/quantil.dat";
     if (!params.exists("max_flow") && file_exists(qfstr)) {
         std::ifstream f(qfstr.c_str());
         string line;
         std::getline(f, line);
         quantil = atof(line.c_str());
+        // :315-319: the flow bound is three times the file's second line (the maximum) if there is one, else three times the quantile
+        string line2;
+        orig_max_flow = 3.0 * (std::getline(f, line2) ? atof(line2.c_str()) : quantil);
+        if (!adaptive) max_flow = std::max(5.0, orig_max_flow * scale_main * steps * skip);   // :354 (ref = steps)
         if (adaptive) {
             const int keyframes = (int)(params.parameter<float>("max_fps") / params.parameter<float>("ref_fps"));   // :324
             rates = adaptive_rates(quantil, hfr_quantil, lfr_factor, keyframes, steps);
@@ -827,6 +869,15 @@ int main(int argc, char **argv) {
             adaptCfg.output += adFR == 0 ? "high_fr/" : "low_fr/";
             adaptCfg.insert("jet_fps", std::to_string(max_fps / rate), true);        // jet estimation fps
             skip = rate;
+            max_flow = std::max(5.0, orig_max_flow * scale_main * steps * rate);     // :382, :392
+        }
+        {   // :396-402: smaller resolution for deep matching
+            double dm_scale = params.parameter<float>("dm_scale", "1.0");
+            if (params.parameter<bool>("deep_matching") && max_flow > 150) dm_scale = 0.5 * dm_scale;
+            std::ostringstream o;
+            o.precision(17);
+            o << dm_scale;
+            adaptCfg.insert("dm_scale_run", o.str(), true);
         }
         const int rc = run_sequence(adaptCfg, sequence_path, format, skip, opt);
         if (rc != 0) rc_all = rc;

@@ -276,10 +276,7 @@ def test_driver_rejects_out_of_scope_inputs(host_build, tmp_path):
     cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t1\nstart\t1\nraw\t0\ndeep_matching\t1\n" % (tmp_path, tmp_path))
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg)], capture_output=True, text=True)
     assert r.returncode == 2 and "deep_matching" in r.stderr
-    # the limits that are narrower than the reference's: matches at another resolution than the frames' (dm_scale != 1) are refused by name, not misread
-    cfg.write_text("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t1\nstart\t1\nraw\t0\ndeep_matching\t1\ndm_scale\t0.5\n" % (tmp_path, tmp_path))
-    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg)], capture_output=True, text=True)
-    assert r.returncode == 2 and "dm_scale" in r.stderr
+    # (dm_scale != 1 was refused until round 5: test_driver_deep_matching_at_half_resolution)
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(tmp_path / "missing.cfg")], capture_output=True, text=True)
     assert r.returncode != 0 and "Couldn't find" in r.stderr
 
@@ -857,3 +854,91 @@ def test_driver_deep_matching_initialisation(host_build, tmp_path, bits):
     ctx.variational(p, wx, wy, fr[0:3], w)
     assert np.array_equal(u, wx[:, :w] * steps) and np.array_equal(v, wy[:, :w] * steps)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_driver_deep_matching_at_half_resolution(host_build, tmp_path):
+    """dm_scale 0.5 (slow_flow.cpp:396-402, 571-586, 801-843): matches and edge maps belong to frames blurred with sigma = 1 / sqrt(2 dm_scale) and resized by dm_scale; the
+    driver interpolates at that resolution from the same 8-bit copy (blur, resize, convertTo), resizes the field to the frames and multiplies it by the integer width
+    ratio (:827-828).  The .flo equals the binding run from an initial flow built from the library's own operators in that order; the motion is recovered; a dm_scale
+    whose integer ratio is 1 although the sizes differ (0.75) is refused by name (the reference would pass a field of the reduced size on); max_flow > 150 halves dm_scale
+    (:397-402): the same files serve `dm_scale 1.0` + `max_flow 200`.  OpenCV is not vendored: the blur / resize arithmetic is the pyramid's (parity unpinned there too)."""
+    import shutil
+    import slowflow_amd as sfa
+    from synth import texture_frame
+    w, h, jets, S = 128, 96, 1, 2
+    steps = S - 1
+    ew, eh = w // 2, h // 2
+    nframes = 1 + (jets + 2) * steps
+    DX, DY = 9.0, -6.0
+    frames = [np.clip(np.round(texture_frame(w, h, k, dx=DX, dy=DY)[:, :, :w]), 0, 255) for k in range(nframes)]
+    for k, f in enumerate(frames):
+        write_ppm(str(tmp_path / ("f_%03d.ppm" % (10 - steps + k))), f)
+    out = tmp_path / "out"
+    (out / "tmp").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for a, b, sx, sy in ((10, 11, DX, DY), (11, 10, -DX, -DY)):                           # matches in the coordinates of the half-size frames
+        with open(str(out / "tmp" / ("matches_%d_%d.dat" % (a, b))), "w") as f:
+            for _ in range(500):
+                x, y = rng.uniform(6, ew - 7), rng.uniform(4, eh - 5)
+                f.write("%.3f %.3f %.3f %.3f 3.1 1\n" % (x, y, x + sx / 2 + rng.normal(0, 0.1), y + sy / 2 + rng.normal(0, 0.1)))
+    for n in (10, 11):
+        (0.05 + 0.02 * rng.uniform(0, 1, (eh, ew))).astype(np.float32).tofile(str(out / "tmp" / ("edges_%d.dat" % n)))
+    cfg = tmp_path / "run.cfg"
+    cfg.write_text(("file\t%s/f_%%03i.ppm\noutput\t%s/out\nJets\t%d\nstart\t10\nmax_fps\t200\n16bit\t0\nraw\t0\nscale\t1.0\ndeep_matching\t1\ndm_scale\t0.5\nverbose\t00001\n"
+                    "slow_flow_S\t%d\nslow_flow_layers\t1\nslow_flow_niter_alter\t1\nslow_flow_niter_outer\t5\nslow_flow_occlusion_reasoning\t0\n"
+                    "slow_flow_thres_outer\t0\nslow_flow_thres_inner\t0\nslow_flow_rho_0\t1\nslow_flow_omega_0\t0\ngpus\t1\n") % (tmp_path, tmp_path, jets, S))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg), "-overwrite"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    u, v = read_flo(str(out / "f_010.flo"))
+    inner = (slice(10, h - 10), slice(14, w - 14))
+    assert abs(np.median(u[inner]) - DX) < 0.4 and abs(np.median(v[inner]) - DY) < 0.4
+    # the same initial flow from the library's operators, then the binding
+    ctx = sfa.Context(0)
+    st, est = sfa.stride_of(w), sfa.stride_of(ew)
+    sigma = np.float32(1 / np.sqrt(2 * 0.5))
+    rgb = np.zeros((3, eh, est), np.float32)
+    for ch in range(3):
+        pl = np.zeros((h, st), np.float32); pl[:, :w] = frames[1][ch]
+        small, dw = ctx.resize_linear_fx(ctx.gaussian_blur(pl, w, float(sigma)), w, 0.5, 0.5)
+        assert dw == ew and small.shape == (eh, est)
+        rgb[ch, :, :ew] = np.clip(np.rint(small[:, :ew]), 0, 255)                           # img.convertTo(CV_8U)
+    exe = _link_host_test(tmp_path, ["epic_tool.cpp"], "epic_tool")
+    rgb.tofile(str(tmp_path / "epic_rgb.bin"))
+    shutil.copy(str(out / "tmp" / "matches_10_11.dat"), str(tmp_path / "epic_matches.txt"))
+    shutil.copy(str(out / "tmp" / "edges_10.dat"), str(tmp_path / "epic_edges.bin"))
+    r = subprocess.run([exe, str(tmp_path), str(ew), str(eh), "LA", "0.045", "25", "5.0", "160", "1.1", "0.001", "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ex = np.fromfile(str(tmp_path / "epic_fx.bin"), dtype=np.float32).reshape(eh, est)
+    ey = np.fromfile(str(tmp_path / "epic_fy.bin"), dtype=np.float32).reshape(eh, est)
+    fac = np.float32(np.float32(w // ew) / np.float32(steps))                                # fx / steps: one float product (image_mul_scalar)
+    ix = ctx.resize_linear(np.ascontiguousarray(ex), ew, w, h) * fac
+    iy = ctx.resize_linear(np.ascontiguousarray(ey), ew, w, h) * fac
+    fr = []
+    for f in frames:
+        a = np.zeros((3, h, st), np.float32); a[:, :, :w] = f
+        fr.append(a)
+    avg, std = ctx.normalize(fr, w)
+    p = sfa.default_params()
+    p.S = S; p.layers = 1; p.niter_alter = 1; p.niter_outer = 5; p.occlusion_reasoning = 0; p.thres_outer = 0; p.thres_inner = 0; p.hbit = 0; p.smoothing = 1
+    p.rho[0] = 1; p.omega[0] = 0
+    for k in range(3):
+        p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    wx, wy = np.ascontiguousarray(ix), np.ascontiguousarray(iy)
+    ctx.variational(p, wx, wy, fr[0:3], w)
+    assert np.array_equal(u, wx[:, :w] * steps) and np.array_equal(v, wy[:, :w] * steps)
+    ctx.close()
+    # max_flow > 150 halves dm_scale: the same half-size files serve dm_scale 1.0
+    cfg2 = tmp_path / "run2.cfg"
+    cfg2.write_text(cfg.read_text().replace("dm_scale\t0.5", "dm_scale\t1.0\nmax_flow\t200"))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg2), "-overwrite"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    u2, v2 = read_flo(str(out / "f_010.flo"))
+    assert np.array_equal(u2, u) and np.array_equal(v2, v)
+    # 1 < width ratio < 2: refused by name
+    cfg3 = tmp_path / "run3.cfg"
+    cfg3.write_text(cfg.read_text().replace("dm_scale\t0.5", "dm_scale\t0.75"))
+    for n in (10, 11):
+        np.zeros((72, 96), np.float32).tofile(str(out / "tmp" / ("edges_%d.dat" % n)))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg3), "-overwrite"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "dm_scale" in r.stderr and "integer ratio" in r.stderr
