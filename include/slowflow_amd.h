@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define SFA_VERSION 1
-#define SFA_MAX_REF 4          /* slow_flow_S - 1 <= 4 */
+#define SFA_MAX_REF 8          /* slow_flow_S - 1 <= 8: windows of up to 17 frames (4 until round 5) */
 
 typedef enum {
     SFA_OK = 0,

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.environ.get("SFA_ORACLE_SO") or os.path.join(_HERE, "libslowflow_oracle.so")   # SFA_ORACLE_SO: e.g. the -fsanitize build (make -C oracle asan)
 REF_SO = os.path.join(_HERE, "_ref", "libslowflow_ref.so")
-MAX_REF = 4
+MAX_REF = 8
 
 _f = C.POINTER(C.c_float)
 

@@ -29,8 +29,8 @@ void orc_params_default(orc_params *p) {
     p->alpha = 4.0f; p->gamma = 6.0f; p->delta = 1.0f;
     p->robust_color.id = 1; p->robust_color.eps = 0.001f; p->robust_color.trunc = 0.5f;
     p->robust_grad = p->robust_color; p->robust_reg = p->robust_color;
-    p->rho[0] = 1; p->rho[1] = 1; p->rho[2] = 1; p->rho[3] = 1;
-    p->omega[0] = 0; p->omega[1] = 2; p->omega[2] = 1; p->omega[3] = 1;
+    for (int a = 0; a < ORC_MAX_REF; a++) { p->rho[a] = 1; p->omega[a] = 1; }
+    p->omega[0] = 0; p->omega[1] = 2;
     p->hbit = 1;
     for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
     p->occlusion_reasoning = 1;

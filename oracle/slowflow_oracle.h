@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_REF 4
+#define ORC_MAX_REF 8
 
 typedef struct {
     int id;        /* 0 quadratic, 2 lorentzian, 3 trunc mod-L1, 4 geman-mcclure, else mod-L1 */

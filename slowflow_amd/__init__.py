@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFA_LIB") or os.path.join(_HERE, "libslowflow_amd.so")     # SFA_LIB: an experimental build of the same C-ABI (tuning only)
-MAX_REF = 4
+MAX_REF = 8
 
 _f = C.POINTER(C.c_float)
 

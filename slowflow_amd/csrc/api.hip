@@ -541,8 +541,8 @@ void sfa_params_default(sfa_params *p) {           // slow_flow.cpp:64-128
     p->alpha = 4.0f; p->gamma = 6.0f; p->delta = 1.0f;
     p->robust_color = sfa_penalty{1, 0.001f, 0.5f};
     p->robust_grad = p->robust_color; p->robust_reg = p->robust_color;
-    p->rho[0] = 1; p->rho[1] = 1; p->rho[2] = 1; p->rho[3] = 1;
-    p->omega[0] = 0; p->omega[1] = 2; p->omega[2] = 1; p->omega[3] = 1;
+    for (int a = 0; a < SFA_MAX_REF; a++) { p->rho[a] = 1; p->omega[a] = 1; }       // variational_mt.cpp:561-568: "1.0" where the cfg names nothing ...
+    p->omega[0] = 0; p->omega[1] = 2;                                               // ... and slow_flow.cpp:96-99 for the first two
     p->hbit = 1;
     for (int k = 0; k < 3; k++) { p->norm_avg[k] = 0; p->norm_std[k] = 1; }
     p->occlusion_reasoning = 1; p->layers = 1; p->p_scale = 0.9f; p->presmooth_sigma = 0;

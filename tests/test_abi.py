@@ -37,7 +37,8 @@ def test_header_symbols_exported(libpath):
 def test_struct_layouts_match_reference_images():
     # image_t: int width,height,stride; float* data (epic_flow_extended/image.h:17-23)
     assert C.sizeof(sfa.Image) == 24 and sfa.Image.data.offset == 16
-    assert C.sizeof(sfa.Params) == C.sizeof(C.c_int) * 8 + 4 * 6 + 12 * 3 + 16 * 2 + 4 + 12 * 2 + 4 * 4 + 4 * 3 + 4      # + sor_order (additive)
+    assert C.sizeof(sfa.Params) == C.sizeof(C.c_int) * 8 + 4 * 6 + 12 * 3 + 2 * 4 * sfa.MAX_REF + 4 + 12 * 2 + 4 * 4 + 4 * 3 + 4      # rho, omega: SFA_MAX_REF floats each (8 since round 5); + sor_order (additive)
+    assert sfa.MAX_REF == 8
 
 
 def test_params_default_matches_driver_defaults(libpath):

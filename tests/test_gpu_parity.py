@@ -1537,19 +1537,20 @@ def test_cfg_schedule_at_the_metric_size_with_thresholds_and_occlusions(ctx, ora
     assert d <= TOL_LEVEL, (mode, d)
 
 
-@pytest.mark.parametrize("S,rho,omega", [(4, [1, 0.5, 0.25], [0, 2, 1]), (5, [1, 1, 0.5, 0.5], [0.5, 0, 1, 2])])
+@pytest.mark.parametrize("S,rho,omega", [(4, [1, 0.5, 0.25], [0, 2, 1]), (5, [1, 1, 0.5, 0.5], [0.5, 0, 1, 2]),
+                                         (6, [1, 1, 0.5, 0.5, 0.25], [0.5, 0, 1, 2, 1]), (9, [1, 1, 0.5, 0.5, 0.25, 0.25, 0.125, 0.125], [0.5, 0, 1, 2, 1, 0, 0.5, 1])])
 def test_level_with_seven_and_nine_frames(ctx, oracle, S, rho, omega):
-    """slow_flow_S = 4 and 5 (7 / 9 frames: SFA_MAX_REF = 4 is the widest window the boundary accepts): to-reference terms up to four frames from the reference
-    frame, the staged pairs of an odd and an even number of terms"""
+    """slow_flow_S = 4, 5, 6 and 9 (7 / 9 / 11 / 17 frames: SFA_MAX_REF = 8 is the widest window the boundary accepts since round 5, 4 before): to-reference terms up to
+    eight frames from the reference frame, the staged pairs of an odd and an even number of terms, up to 32 terms per assembly"""
     w, h = 96, 64
     frames, af, sf = normalized_frames(oracle, w, h, 2 * S - 1, seed=5)
     po, ps = mk_params(oracle, S=S, rho=rho, omega=omega, norm_avg=af, norm_std=sf, niter_outer=2)
     o, g = run_both(ctx, oracle, po, ps, frames, w, h)
     d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
     assert d <= max(TOL_LEVEL, 3 * oracle_sensitivity(oracle, po, frames, w, h)), (S, d)
-    _, bad = mk_params(oracle, S=6, rho=[1], omega=[0], norm_avg=af, norm_std=sf)
-    with pytest.raises(sfa.SlowflowError):                                                    # one more is refused, not truncated
-        ctx.compute_one_level(bad, np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32), [c_(f) for f in frames] + [c_(frames[0])] * 2, w)
+    _, bad = mk_params(oracle, S=10, rho=[1], omega=[0], norm_avg=af, norm_std=sf)
+    with pytest.raises(sfa.SlowflowError):                                                    # one more than SFA_MAX_REF + 1 is refused, not truncated
+        ctx.compute_one_level(bad, np.zeros((h, sfa.stride_of(w)), np.float32), np.zeros((h, sfa.stride_of(w)), np.float32), ([c_(f) for f in frames] * 19)[:19], w)
 
 
 def test_unknown_penalty_id_is_the_default_class(ctx, oracle):
