@@ -21,7 +21,7 @@ static const char *const kSwitchNames[Switches::N] = {
     "SFA_SOR_CHAIN", "SFA_SOR_BAND", "SFA_SOR_F", "SFA_SOR_CH", "SFA_SOR_LEAD", "SFA_CHAIN_LDS", "SFA_RB_TILE", "SFA_WARP_ALLJ", "SFA_NO_WARP_SMOOTH",
     "SFA_ASSEMBLE_GENERIC", "SFA_EXACT_DIV", "SFA_ASM_XCD", "SFA_NO_DIRECT_OPERANDS", "SFA_NO_UV_ALIAS", "SFA_DEBUG_ACTIVE", "SFA_UNFUSED", "SFA_SHARE_SOR",
     "SFA_PYRAMID_UNFUSED", "SFA_CUT_DISCHARGE", "SFA_CUT_INNER", "SFA_CUT_SUPER", "SFA_CUT_TAIL_INNER", "SFA_CUT_PER", "SFA_CUT_TAIL_PER", "SFA_CUT_TAIL_SUPER",
-    "SFA_CUT_DEBUG", "SFA_CUT_NO_TAIL", "SFA_CUT_TAIL"};
+    "SFA_CUT_DEBUG", "SFA_CUT_NO_TAIL", "SFA_CUT_TAIL", "SFA_NO_EXACT_BREAK"};
 static int set_switch(const char *name, const char *value) {
     for (int i = 0; i < Switches::N; i++)
         if (!strcmp(name, kSwitchNames[i])) {
@@ -282,7 +282,10 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     constexpr int kLag = kMaskLag, kRing = kMaskRing;
     const bool dbg = sw_given(Switches::DEBUG_ACTIVE);
     g.amask = c->d_amask;
-    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned), c->stream));   // (+ the windows' finished-block counters of k_update_outer_x)
+    // With an outer threshold the update leaves the per-pixel terms of the norms in the a11 / a12 planes (dead by then: the direct form never writes them, the other
+    // forms' solver has read them), so that a window whose fp64 norm lies within 1e-3 of the threshold can be decided by the reference's own fp32 running sums
+    float *const dfa = use_thres_out && !sw_given(Switches::NO_EXACT_BREAK) ? L.plane(P_A11) : nullptr, *const dfb = dfa ? L.plane(P_A12) : nullptr;
+    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long), c->stream));   // (+ the windows' finished-block counters of k_update_outer_x)
     launch_set_mask(c, all);
 
     for (int alter = 0; alter < p.niter_alter; alter++) {
@@ -345,7 +348,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 if (direct && inner + 1 == p.niter_inner && !verbose) {
                     // last inner iteration: nothing reads its inner norms or du/dv; the flow update and the outer update run as one pass (with the per-iteration
                     // lines on somebody does read the inner norms, :404-405: the two passes below)
-                    launch_update_outer_x(c, gi, uv_alias ? nullptr : L.plane(P_UU), uv_alias ? nullptr : L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, red);   // :396-397 + :412-429
+                    launch_update_outer_x(c, gi, uv_alias ? nullptr : L.plane(P_UU), uv_alias ? nullptr : L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, red, dfa, dfb);   // :396-397 + :412-429
                     outer_done = in_active;
                 } else if (direct) {
                     const bool keep = inner + 1 < p.niter_inner;      // du, dv are read again only by a further inner iteration
@@ -371,11 +374,11 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 // words of the windows of their Geo::active, so the norms of the windows updated above stay in `red`.
                 Geo go = g;
                 go.active = active.andnot(outer_done);
-                launch_update_outer(c, go, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red);                      // :412-429
+                launch_update_outer(c, go, L.plane(P_WX), L.plane(P_WY), L.plane(P_UU), L.plane(P_VV), red, dfa, dfb);            // :412-429
             }
             if (verbose) print_changes("outer it", outer, active);                                            // :431-432
             const bool last_iter = (alter == p.niter_alter - 1 && outer == p.niter_outer - 1);
-            if (use_thres_out || last_iter) launch_outer_threshold(c, g, red, use_thres_out ? p.thres_outer : 0.0f);   // :431-436
+            if (use_thres_out || last_iter) launch_outer_threshold(c, g, red, use_thres_out ? p.thres_outer : 0.0f, dfa, dfb);   // :431-436
             if (use_thres_out) {
                 const int slot = outer % kRing;
                 SFA_HIP(c, hipMemcpyAsync(&c->h_amask[slot], c->d_amask, sizeof(WMask), hipMemcpyDeviceToHost, c->stream));
@@ -491,8 +494,8 @@ int sfa_ctx_create(int device, sfa_ctx **out) {
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_red, kRedDoubles * sizeof(double)));
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, 2 * kMaxBatch * sizeof(double) + 64, hipHostMallocDefault));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_amask, 64));
-    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned)));
-    SFA_HIP(c.get(), hipMemset(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned)));
+    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long)));
+    SFA_HIP(c.get(), hipMemset(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long)));
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, kMaskRing * sizeof(WMask), hipHostMallocDefault));
     for (auto &e : c->ev_mask) SFA_HIP(c.get(), hipEventCreateWithFlags(&e, hipEventDisableTiming));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_err, 64));

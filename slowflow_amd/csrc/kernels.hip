@@ -1706,7 +1706,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ u
 template <bool FUSE>
 __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ uu, float *__restrict__ vv, float *__restrict__ wx, float *__restrict__ wy,
                                                             const unsigned long long *__restrict__ xs, long ent, int RP, int G, double *__restrict__ partial,
-                                                            double *__restrict__ out, unsigned *__restrict__ done, Geo g) {
+                                                            double *__restrict__ out, unsigned *__restrict__ done, float *__restrict__ dfa, float *__restrict__ dfb, Geo g) {
     __shared__ unsigned long long tX[16][67];                    // 67: the 16 rows of an anti-diagonal land on distinct banks (65 put them all on one: 69 % conflict cycles)
     const int b = blockIdx.z;
     const int tid = threadIdx.y * BX + threadIdx.x;
@@ -1737,6 +1737,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ u
                     sa += (double)fabsf(u - ox);                                         // :415-419
                     sb += (double)fabsf(v - oy);
                     if (uu) { uu[o] = u; vv[o] = v; }                                     // (null: the caller reads wx, wy in their place -- one inner iteration)
+                    if (dfa) { dfa[o] = fabsf(u - ox); dfb[o] = fabsf(v - oy); }         // the per-pixel terms of the norms, for k_exact_break
                     wx[o] = u; wy[o] = v;                                                 // :428-429
                 }
         }
@@ -1783,7 +1784,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ u
     if (tid == 0) { out[2 * b] = s0[0]; out[2 * b + 1] = s1[0]; }
 }
 __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx, float *__restrict__ wy, const float *__restrict__ uu, const float *__restrict__ vv,
-                                                          double *__restrict__ partial, Geo g) {
+                                                          double *__restrict__ partial, float *__restrict__ dfa, float *__restrict__ dfb, Geo g) {
     const int b = blockIdx.z;
     const int x = blockIdx.x * BX + threadIdx.x;
     double sa = 0, sb = 0;
@@ -1793,6 +1794,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer(float *__restrict__ wx,
             const float u = uu[o], v = vv[o];
             sa += (double)fabsf(u - wx[o]);                                              // :415-419
             sb += (double)fabsf(v - wy[o]);
+            if (dfa) { dfa[o] = fabsf(u - wx[o]); dfb[o] = fabsf(v - wy[o]); }
             wx[o] = u;                                                                   // :428-429
             wy[o] = v;
         }
@@ -1821,11 +1823,15 @@ __global__ void k_reduce_partials(const double *__restrict__ partial, int per_el
 
 // The outer break on the device (variational_mt.cpp:431-436): the norms of the windows that ran this outer iteration, and the windows that go on.
 // One wave per mask word; lane = window within the word.  `last` keeps every window's norms of ITS last iteration (what the caller gets back as the change).
+// `unsure` (or null): the windows whose norm lies within kBreakBand of the threshold.  The reference forms the norms as fp32 running sums in raster order
+// (variational_mt.cpp:412-425); the fp64 tree sum here differs from that by ~1e-5 of its value (random walk of 111 000 roundings; worst case 3.3e-3), so outside
+// the band the two decide alike, and inside it k_exact_break repeats the reference's own summation.  Their bits stay set here.
+constexpr double kBreakBand = 1e-3;
 __global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict__ red, double *__restrict__ last, unsigned long long *__restrict__ amask,
-                                                        WMask active, int nb, double npx, float thres) {
+                                                        WMask active, int nb, double npx, float thres, unsigned long long *__restrict__ unsure) {
     const int word = blockIdx.x, b = 64 * word + (int)threadIdx.x;
     const unsigned long long cur = amask[word] & active.w[word];
-    bool met = false;
+    bool met = false, close = false;
     if (b < nb && ((cur >> threadIdx.x) & 1ull)) {
         const double a = red[2 * b] / npx, d = red[2 * b + 1] / npx;
         last[2 * b] = a; last[2 * b + 1] = d;
@@ -1834,13 +1840,59 @@ __global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict
         const float fa = (float)a, fd = (float)d;
         const float mx = (fa < fd) ? fd : fa;
         met = thres > 0.0f && mx < thres;
+        const double dm = (a < d) ? d : a;
+        close = unsure && thres > 0.0f && fabs(dm - (double)thres) <= kBreakBand * (double)thres;
+        if (close) met = false;
     }
-    const unsigned long long m = __ballot(met);
-    if (threadIdx.x == 0) amask[word] = amask[word] & ~m;
+    const unsigned long long m = __ballot(met), u = __ballot(close);
+    if (threadIdx.x == 0) {
+        amask[word] = amask[word] & ~m;
+        if (unsure) unsure[word] = u;
+    }
+}
+// The reference's own norms for the windows k_outer_threshold could not decide (variational_mt.cpp:412-436): blocks of four pixels in raster order, the four
+// |differences| of a block added left to right, the block added to an fp32 running sum; then the fp32 division by height * width and max() as the reference writes
+// it.  One wave per window: the 64 lanes form 64 block sums at a time, the running sum walks through them lane by lane (v_readlane + one dependent v_add_f32 per
+// block: ~0.45 ms for 1024 x 436 -- which is why only the undecided windows come here, a handful per run).  dfa, dfb: the per-pixel |differences| left by the update.
+__global__ void __launch_bounds__(64) k_exact_break(const float *__restrict__ dfa, const float *__restrict__ dfb, double *__restrict__ last,
+                                                    unsigned long long *__restrict__ amask, const unsigned long long *__restrict__ unsure, Geo g, float thres) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (!((unsure[b >> 6] >> (b & 63)) & 1ull)) return;
+    const float *pa = dfa + b * g.es, *pb = dfb + b * g.es;
+    const int nblk = (g.w + 3) / 4;                                  // blocks of a row that hold a pixel (the reference's stride may hold more: they add +0)
+    float acc_a = 0.0f, acc_b = 0.0f;
+    for (int y = 0; y < g.h; y++)
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int blk = b0 + lane, x = 4 * blk;
+            float sa = 0.0f, sb = 0.0f;
+            if (blk < nblk) {
+                const float4 qa = *reinterpret_cast<const float4 *>(pa + (size_t)y * g.pitch + x), qb = *reinterpret_cast<const float4 *>(pb + (size_t)y * g.pitch + x);
+                const float a0 = qa.x, a1 = x + 1 < g.w ? qa.y : 0.0f, a2 = x + 2 < g.w ? qa.z : 0.0f, a3 = x + 3 < g.w ? qa.w : 0.0f;
+                const float c0 = qb.x, c1 = x + 1 < g.w ? qb.y : 0.0f, c2 = x + 2 < g.w ? qb.z : 0.0f, c3 = x + 3 < g.w ? qb.w : 0.0f;
+                sa = ((a0 + a1) + a2) + a3;
+                sb = ((c0 + c1) + c2) + c3;
+            }
+            const int n = min(64, nblk - b0);
+            for (int i = 0; i < n; i++) {
+                acc_a = acc_a + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sa), i));
+                acc_b = acc_b + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb), i));
+            }
+        }
+    if (lane == 0) {
+        const float npx = (float)(g.h * g.w);
+        const float fa = __fdiv_rn(acc_a, npx), fd = __fdiv_rn(acc_b, npx);
+        last[2 * b] = (double)fa; last[2 * b + 1] = (double)fd;
+        const float mx = (fa < fd) ? fd : fa;                      // std::max(a, b) = (a < b) ? b : a
+        if (mx < thres) atomicAnd(&amask[b >> 6], ~(1ull << (b & 63)));
+    }
 }
 __global__ void k_set_mask(unsigned long long *amask, WMask v) { for (int i = 0; i < kMaskWords; i++) amask[i] = v.w[i]; }
-void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres) {
-    hipLaunchKernelGGL(k_outer_threshold, dim3(kMaskWords), dim3(64), 0, c->stream, red, c->d_last, c->d_amask, g.active, g.nb, (double)g.h * g.w, thres);
+static unsigned long long *unsure_of(sfa_ctx *c) { return reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned *>(c->d_last + 2 * kMaxBatch) + kMaxBatch); }
+void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres, const float *dfa, const float *dfb) {
+    const bool exact = dfa && thres > 0.0f;
+    hipLaunchKernelGGL(k_outer_threshold, dim3(kMaskWords), dim3(64), 0, c->stream, red, c->d_last, c->d_amask, g.active, g.nb, (double)g.h * g.w, thres,
+                       exact ? unsure_of(c) : (unsigned long long *)nullptr);
+    if (exact) hipLaunchKernelGGL(k_exact_break, dim3(g.nb), dim3(64), 0, c->stream, dfa, dfb, c->d_last, c->d_amask, unsure_of(c), g, thres);
 }
 void launch_set_mask(sfa_ctx *c, const WMask &v) { hipLaunchKernelGGL(k_set_mask, dim3(1), dim3(1), 0, c->stream, c->d_amask, v); }
 
@@ -1865,21 +1917,21 @@ void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 constexpr int kFuseReduceWindows = 4;      // launches of up to that many windows sum their partials in k_update_outer_x itself
-void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red) {
+void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red, float *dfa, float *dfb) {
     dim3 grid((g.w + 63) / 64, std::min((g.h + 15) / 16, kRedRows), g.nb);
     const int per_elem = grid.x * grid.y;
     unsigned *done = reinterpret_cast<unsigned *>(c->d_last + 2 * kMaxBatch);
     if (g.nb <= kFuseReduceWindows) {
-        hipLaunchKernelGGL(k_update_outer_x<true>, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), red, done, g);
+        hipLaunchKernelGGL(k_update_outer_x<true>, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), red, done, dfa, dfb, g);
         return;
     }
-    hipLaunchKernelGGL(k_update_outer_x<false>, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), red, done, g);
+    hipLaunchKernelGGL(k_update_outer_x<false>, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), red, done, dfa, dfb, g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
-void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red) {
+void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red, float *dfa, float *dfb) {
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
-    hipLaunchKernelGGL(k_update_outer, grid, block2d(), 0, c->stream, wx, wy, uu, vv, partials_of(c), g);
+    hipLaunchKernelGGL(k_update_outer, grid, block2d(), 0, c->stream, wx, wy, uu, vv, partials_of(c), dfa, dfb, g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 

@@ -57,7 +57,7 @@ struct sfa_ctx {
     // thresholds on the device (variational_mt.cpp:436): the windows still iterating, the norms of each window's last iteration, and a ring of pinned
     // copies of the mask (one per outer iteration in flight) with the events that say a copy has landed
     unsigned long long *d_amask = nullptr;         // kMaskWords words
-    double *d_last = nullptr;                      // 2 * kMaxBatch doubles, then kMaxBatch counters (k_update_outer_x)
+    double *d_last = nullptr;                      // 2 * kMaxBatch doubles, then kMaxBatch counters (k_update_outer_x), then kMaskWords words (k_outer_threshold's undecided windows)
     sfa::WMask *h_amask = nullptr;                      // kMaskRing pinned masks
     hipEvent_t ev_mask[sfa::kMaskRing] = {};
     unsigned *d_err = nullptr;    // device error/timeout word
@@ -95,7 +95,7 @@ struct Switches {
     enum Id {
         SOR_CHAIN, SOR_BAND, SOR_F, SOR_CH, SOR_LEAD, CHAIN_LDS, RB_TILE, WARP_ALLJ, NO_WARP_SMOOTH, ASSEMBLE_GENERIC, EXACT_DIV, ASM_XCD, NO_DIRECT_OPERANDS,
         NO_UV_ALIAS, DEBUG_ACTIVE, UNFUSED, SHARE_SOR, PYRAMID_UNFUSED, CUT_DISCHARGE, CUT_INNER, CUT_SUPER, CUT_TAIL_INNER, CUT_PER, CUT_TAIL_PER, CUT_TAIL_SUPER,
-        CUT_DEBUG, CUT_NO_TAIL, CUT_TAIL, N
+        CUT_DEBUG, CUT_NO_TAIL, CUT_TAIL, NO_EXACT_BREAK, N
     };
     bool given[N] = {};
     int value[N] = {};
@@ -168,7 +168,9 @@ void launch_fill(sfa_ctx *c, float *p, size_t n, float v);
 void launch_division_chain(sfa_ctx *c, const float *a, const float *b, float *q_chain, float *q_exact, unsigned char *admitted, size_t n);
 void launch_fill_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes, float v);
 void launch_zero_planes(sfa_ctx *c, const Geo &g, float *p, int nplanes);
-void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres);   // updates *c->d_amask and c->d_last
+// updates *c->d_amask and c->d_last.  dfa, dfb (or null): the per-pixel |differences| of the two norms as the update left them -- windows whose norm lies within
+// 1e-3 of the threshold are then decided by the reference's own fp32 running sums (k_exact_break)
+void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres, const float *dfa = nullptr, const float *dfb = nullptr);
 void launch_set_mask(sfa_ctx *c, const WMask &v);
 
 // Where a kernel other than k_sor_prepare leaves the solver's operands (diagonal-major planes of a SorWorkspace)
@@ -234,9 +236,10 @@ void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const f
 void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const SorOperandOut &x, const float *old_du,
                            const float *old_dv, float *du_out, float *dv_out, double *red);
 // flow update of the LAST inner iteration straight from the x plane, fused with the outer update below (uu, vv, wx, wy all written)
-void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red);
+void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red, float *dfa = nullptr,
+                           float *dfb = nullptr);   // dfa, dfb: where to leave the per-pixel |differences| (launch_outer_threshold)
 // sum|uu-wx|, sum|vv-wy|; wx<-uu, wy<-vv (variational_mt.cpp:412-429)
-void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red);
+void launch_update_outer(sfa_ctx *c, const Geo &g, float *wx, float *wy, const float *uu, const float *vv, double *red, float *dfa = nullptr, float *dfb = nullptr);
 void launch_copy_planes(sfa_ctx *c, const Geo &g, float *dst, const float *src, int nplanes, long dst_es, long src_es);
 void launch_scale_plane(sfa_ctx *c, const Geo &g, float *p, float s);
 
