@@ -517,6 +517,17 @@ def test_break_decision_at_the_threshold_is_the_reference_arithmetic(ctx, oracle
             assert abs(g[2][0] - o[2][0]) <= 2e-5 * abs(o[2][0]) and abs(g[2][1] - o[2][1]) <= 2e-5 * abs(o[2][1]), (thres, g[2], o[2])
         d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
         assert d <= TOL_LEVEL, d
+    # the same decision inside a lockstep batch (two copies of the window around one that stops at once: the undecided windows share a mask word)
+    po, ps = mk_params(oracle, thres_outer=float(np.nextafter(m, np.float32(np.inf))), **kw)
+    o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+    job = sfa.Job(ctx, ps, w, h, 3)
+    for b, f in enumerate((frames, [frames[1]] * 3, frames)):
+        job.upload(b, [c_(x) for x in f])
+    job.run()
+    for b in (0, 2):
+        gx, gy, chg = job.download(b)
+        assert np.array_equal(gx, g[0]) and np.array_equal(gy, g[1]) and np.float32(chg[0]) == np.float32(o[2][0]) and np.float32(chg[1]) == np.float32(o[2][1]), b
+    job.close()
     switches.set("SFA_NO_EXACT_BREAK", "1")
     po, ps = mk_params(oracle, thres_outer=float(m), **kw)
     o, g = run_both(ctx, oracle, po, ps, frames, w, h)
