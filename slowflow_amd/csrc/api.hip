@@ -285,7 +285,8 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     // With an outer threshold the update leaves the per-pixel terms of the norms in the a11 / a12 planes (dead by then: the direct form never writes them, the other
     // forms' solver has read them), so that a window whose fp64 norm lies within 1e-3 of the threshold can be decided by the reference's own fp32 running sums
     float *const dfa = use_thres_out && !sw_given(Switches::NO_EXACT_BREAK) ? L.plane(P_A11) : nullptr, *const dfb = dfa ? L.plane(P_A12) : nullptr;
-    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long), c->stream));   // (+ the windows' finished-block counters of k_update_outer_x)
+    float *const ifa = use_thres_in && !sw_given(Switches::NO_EXACT_BREAK) ? L.plane(P_A11) : nullptr, *const ifb = ifa ? L.plane(P_A12) : nullptr;   // the inner break's
+    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long) + 2 * kMaxBatch * sizeof(float), c->stream));   // (+ the windows' finished-block counters of k_update_outer_x)
     launch_set_mask(c, all);
 
     for (int alter = 0; alter < p.niter_alter; alter++) {
@@ -318,6 +319,9 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 Geo gi = g;
                 gi.active = in_active;
                 const bool direct = direct_outer;
+                // an inner break is decided behind this iteration: the update leaves the per-pixel terms of its norms (a11 / a12 planes: dead, see dfa), so that a
+                // window whose fp64 norm lies within 1e-3 of the threshold can be decided by the reference's own fp32 sums
+                const bool decide_in = use_thres_in && inner + 1 < p.niter_inner && ifa;
                 const bool first_zero = direct && inner == 0;        // du = dv = 0 known, planes possibly stale
                 if (!first_zero) {
                     launch_copy_planes(c, gi, L.plane(P_ODU), L.plane(P_DU), 2, L.es, L.es);                // :329-330
@@ -353,19 +357,32 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 } else if (direct) {
                     const bool keep = inner + 1 < p.niter_inner;      // du, dv are read again only by a further inner iteration
                     launch_update_inner_x(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), aa.op, first_zero ? nullptr : L.plane(P_ODU),
-                                          first_zero ? nullptr : L.plane(P_ODV), keep ? L.plane(P_DU) : nullptr, keep ? L.plane(P_DV) : nullptr, red);   // :371-402
+                                          first_zero ? nullptr : L.plane(P_ODV), keep ? L.plane(P_DU) : nullptr, keep ? L.plane(P_DV) : nullptr, red, decide_in ? ifa : nullptr,
+                                          decide_in ? ifb : nullptr);                                       // :371-402
                 } else
                     launch_update_inner(c, gi, L.plane(P_UU), L.plane(P_VV), L.plane(P_WX), L.plane(P_WY), L.plane(P_DU), L.plane(P_DV), L.plane(P_ODU),
-                                        L.plane(P_ODV), red);                                               // :371-402
+                                        L.plane(P_ODV), red, decide_in ? ifa : nullptr, decide_in ? ifb : nullptr);   // :371-402
                 if (verbose) print_changes("\tinner it", inner, in_active);                                  // :404-405
                 if (use_thres_in && inner + 1 < p.niter_inner) {
                     SFA_HIP(c, hipMemcpyAsync(c->h_red, red, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                     SFA_HIP(c, hipStreamSynchronize(c->stream));
+                    WMask close = WMask::none();
                     for (int b = 0; b < L.nb; b++)
                         if (in_active.test(b)) {
-                            const float a = (float)(c->h_red[2 * b] / npx), d = (float)(c->h_red[2 * b + 1] / npx);
+                            const double ad = c->h_red[2 * b] / npx, dd = c->h_red[2 * b + 1] / npx, dm = (ad < dd) ? dd : ad;
+                            if (decide_in && fabs(dm - (double)p.thres_inner) <= 1e-3 * (double)p.thres_inner) { close.set(b); continue; }
+                            const float a = (float)ad, d = (float)dd;
                             if (std::max(a, d) < p.thres_inner) in_active.clear(b);                         // :407
                         }
+                    if (close.any()) {
+                        float *dx = reinterpret_cast<float *>(reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned *>(c->d_last + 2 * kMaxBatch) + kMaxBatch) + kMaskWords);
+                        float hx[2 * kMaxBatch];
+                        launch_exact_norms(c, gi, ifa, ifb, close, dx);
+                        SFA_HIP(c, hipMemcpyAsync(hx, dx, 2 * L.nb * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+                        SFA_HIP(c, hipStreamSynchronize(c->stream));
+                        for (int b = 0; b < L.nb; b++)
+                            if (close.test(b) && std::max(hx[2 * b], hx[2 * b + 1]) < p.thres_inner) in_active.clear(b);   // :407 on the reference's own sums
+                    }
                     if (!in_active.any()) break;
                 }
             }
@@ -494,8 +511,8 @@ int sfa_ctx_create(int device, sfa_ctx **out) {
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_red, kRedDoubles * sizeof(double)));
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, 2 * kMaxBatch * sizeof(double) + 64, hipHostMallocDefault));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_amask, 64));
-    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long)));
-    SFA_HIP(c.get(), hipMemset(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long)));
+    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long) + 2 * kMaxBatch * sizeof(float)));
+    SFA_HIP(c.get(), hipMemset(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long) + 2 * kMaxBatch * sizeof(float)));
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, kMaskRing * sizeof(WMask), hipHostMallocDefault));
     for (auto &e : c->ev_mask) SFA_HIP(c.get(), hipEventCreateWithFlags(&e, hipEventDisableTiming));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_err, 64));

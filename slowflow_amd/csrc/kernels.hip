@@ -1654,7 +1654,7 @@ __device__ __forceinline__ void block_sum2(double &a, double &b) {
 
 __global__ void __launch_bounds__(BX *BY) k_update_inner(float *__restrict__ uu, float *__restrict__ vv, const float *__restrict__ wx, const float *__restrict__ wy,
                                                           const float *__restrict__ du, const float *__restrict__ dv, const float *__restrict__ odu,
-                                                          const float *__restrict__ odv, double *__restrict__ partial, Geo g) {
+                                                          const float *__restrict__ odv, double *__restrict__ partial, float *__restrict__ dfa, float *__restrict__ dfb, Geo g) {
     const int b = blockIdx.z;
     const int x = blockIdx.x * BX + threadIdx.x;
     double sa = 0, sb = 0;
@@ -1664,6 +1664,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner(float *__restrict__ uu,
             const float d = du[o], e = dv[o];
             sa += (double)fabsf(odu[o] - d);                                             // :389-393
             sb += (double)fabsf(odv[o] - e);
+            if (dfa) { dfa[o] = fabsf(odu[o] - d); dfb[o] = fabsf(odv[o] - e); }         // the per-pixel terms of the norms, for k_exact_norms
             uu[o] = wx[o] + d;                                                           // :396-397
             vv[o] = wy[o] + e;
         }
@@ -1677,7 +1678,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner(float *__restrict__ uu,
 __global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ uu, float *__restrict__ vv, const float *__restrict__ wx, const float *__restrict__ wy,
                                                             const unsigned long long *__restrict__ xs, long ent, int RP, int G, const float *__restrict__ odu,
                                                             const float *__restrict__ odv, float *__restrict__ du_out, float *__restrict__ dv_out,
-                                                            double *__restrict__ partial, Geo g) {
+                                                            double *__restrict__ partial, float *__restrict__ dfa, float *__restrict__ dfb, Geo g) {
     const int b = blockIdx.z;
     const int x = blockIdx.x * BX + threadIdx.x;
     double sa = 0, sb = 0;
@@ -1689,6 +1690,7 @@ __global__ void __launch_bounds__(BX *BY) k_update_inner_x(float *__restrict__ u
             const float od = odu ? odu[o] : 0.0f, oe = odv ? odv[o] : 0.0f;
             sa += (double)fabsf(od - d);                                                 // :389-393
             sb += (double)fabsf(oe - e);
+            if (dfa) { dfa[o] = fabsf(od - d); dfb[o] = fabsf(oe - e); }
             uu[o] = wx[o] + d;                                                           // :396-397
             vv[o] = wy[o] + e;
             if (du_out) { du_out[o] = d; dv_out[o] = e; }
@@ -1854,11 +1856,7 @@ __global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict
 // |differences| of a block added left to right, the block added to an fp32 running sum; then the fp32 division by height * width and max() as the reference writes
 // it.  One wave per window: the 64 lanes form 64 block sums at a time, the running sum walks through them lane by lane (v_readlane + one dependent v_add_f32 per
 // block: ~0.45 ms for 1024 x 436 -- which is why only the undecided windows come here, a handful per run).  dfa, dfb: the per-pixel |differences| left by the update.
-__global__ void __launch_bounds__(64) k_exact_break(const float *__restrict__ dfa, const float *__restrict__ dfb, double *__restrict__ last,
-                                                    unsigned long long *__restrict__ amask, const unsigned long long *__restrict__ unsure, Geo g, float thres) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (!((unsure[b >> 6] >> (b & 63)) & 1ull)) return;
-    const float *pa = dfa + b * g.es, *pb = dfb + b * g.es;
+__device__ __forceinline__ void exact_norms(const float *__restrict__ pa, const float *__restrict__ pb, const Geo &g, int lane, float &fa, float &fd) {
     const int nblk = (g.w + 3) / 4;                                  // blocks of a row that hold a pixel (the reference's stride may hold more: they add +0)
     float acc_a = 0.0f, acc_b = 0.0f;
     for (int y = 0; y < g.h; y++)
@@ -1878,13 +1876,31 @@ __global__ void __launch_bounds__(64) k_exact_break(const float *__restrict__ df
                 acc_b = acc_b + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb), i));
             }
         }
+    const float npx = (float)(g.h * g.w);
+    fa = __fdiv_rn(acc_a, npx); fd = __fdiv_rn(acc_b, npx);
+}
+__global__ void __launch_bounds__(64) k_exact_break(const float *__restrict__ dfa, const float *__restrict__ dfb, double *__restrict__ last,
+                                                    unsigned long long *__restrict__ amask, const unsigned long long *__restrict__ unsure, Geo g, float thres) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (!((unsure[b >> 6] >> (b & 63)) & 1ull)) return;
+    float fa, fd;
+    exact_norms(dfa + b * g.es, dfb + b * g.es, g, lane, fa, fd);
     if (lane == 0) {
-        const float npx = (float)(g.h * g.w);
-        const float fa = __fdiv_rn(acc_a, npx), fd = __fdiv_rn(acc_b, npx);
         last[2 * b] = (double)fa; last[2 * b + 1] = (double)fd;
         const float mx = (fa < fd) ? fd : fa;                      // std::max(a, b) = (a < b) ? b : a
         if (mx < thres) atomicAnd(&amask[b >> 6], ~(1ull << (b & 63)));
     }
+}
+// the same sums for the inner break (:371-407), which is taken on the host: the norms of the windows named in `which`, as the reference forms them, into out[2 b], out[2 b + 1]
+__global__ void __launch_bounds__(64) k_exact_norms(const float *__restrict__ dfa, const float *__restrict__ dfb, float *__restrict__ out, WMask which, Geo g) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (!which.test(b)) return;
+    float fa, fd;
+    exact_norms(dfa + b * g.es, dfb + b * g.es, g, lane, fa, fd);
+    if (lane == 0) { out[2 * b] = fa; out[2 * b + 1] = fd; }
+}
+void launch_exact_norms(sfa_ctx *c, const Geo &g, const float *dfa, const float *dfb, const WMask &which, float *out) {
+    hipLaunchKernelGGL(k_exact_norms, dim3(g.nb), dim3(64), 0, c->stream, dfa, dfb, out, which, g);
 }
 __global__ void k_set_mask(unsigned long long *amask, WMask v) { for (int i = 0; i < kMaskWords; i++) amask[i] = v.w[i]; }
 static unsigned long long *unsure_of(sfa_ctx *c) { return reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned *>(c->d_last + 2 * kMaxBatch) + kMaxBatch); }
@@ -1903,17 +1919,17 @@ constexpr int kRedRows = 16;
 static inline dim3 red_grid(const Geo &g, int z) { return dim3((g.w + BX - 1) / BX, std::min((g.h + BY - 1) / BY, kRedRows), z); }
 
 void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const float *du, const float *dv,
-                         const float *old_du, const float *old_dv, double *red) {
+                         const float *old_du, const float *old_dv, double *red, float *dfa, float *dfb) {
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
-    hipLaunchKernelGGL(k_update_inner, grid, block2d(), 0, c->stream, uu, vv, wx, wy, du, dv, old_du, old_dv, partials_of(c), g);
+    hipLaunchKernelGGL(k_update_inner, grid, block2d(), 0, c->stream, uu, vv, wx, wy, du, dv, old_du, old_dv, partials_of(c), dfa, dfb, g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const SorOperandOut &x, const float *old_du,
-                           const float *old_dv, float *du_out, float *dv_out, double *red) {
+                           const float *old_dv, float *du_out, float *dv_out, double *red, float *dfa, float *dfb) {
     dim3 grid = red_grid(g, g.nb);
     const int per_elem = grid.x * grid.y;
-    hipLaunchKernelGGL(k_update_inner_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, old_du, old_dv, du_out, dv_out, partials_of(c), g);
+    hipLaunchKernelGGL(k_update_inner_x, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, old_du, old_dv, du_out, dv_out, partials_of(c), dfa, dfb, g);
     hipLaunchKernelGGL(k_reduce_partials, dim3(g.nb), dim3(256), 0, c->stream, partials_of(c), per_elem, red, g.active, g.amask);
 }
 constexpr int kFuseReduceWindows = 4;      // launches of up to that many windows sum their partials in k_update_outer_x itself

@@ -21,6 +21,7 @@ struct WMask {
     unsigned long long w[kMaskWords];
     __host__ __device__ bool test(int b) const { return (w[b >> 6] >> (b & 63)) & 1ull; }
     __host__ __device__ void clear(int b) { w[b >> 6] &= ~(1ull << (b & 63)); }
+    __host__ __device__ void set(int b) { w[b >> 6] |= 1ull << (b & 63); }
     __host__ __device__ bool any() const { unsigned long long o = 0; for (int i = 0; i < kMaskWords; i++) o |= w[i]; return o != 0; }
     __host__ __device__ bool operator==(const WMask &o) const { bool e = true; for (int i = 0; i < kMaskWords; i++) e = e && w[i] == o.w[i]; return e; }
     __host__ __device__ bool operator!=(const WMask &o) const { return !(*this == o); }
@@ -57,7 +58,7 @@ struct sfa_ctx {
     // thresholds on the device (variational_mt.cpp:436): the windows still iterating, the norms of each window's last iteration, and a ring of pinned
     // copies of the mask (one per outer iteration in flight) with the events that say a copy has landed
     unsigned long long *d_amask = nullptr;         // kMaskWords words
-    double *d_last = nullptr;                      // 2 * kMaxBatch doubles, then kMaxBatch counters (k_update_outer_x), then kMaskWords words (k_outer_threshold's undecided windows)
+    double *d_last = nullptr;                      // 2 * kMaxBatch doubles, then kMaxBatch counters (k_update_outer_x), kMaskWords words (k_outer_threshold's undecided windows), 2 * kMaxBatch floats (launch_exact_norms)
     sfa::WMask *h_amask = nullptr;                      // kMaskRing pinned masks
     hipEvent_t ev_mask[sfa::kMaskRing] = {};
     unsigned *d_err = nullptr;    // device error/timeout word
@@ -230,11 +231,14 @@ int run_grid_cut(sfa_ctx *c, const Geo &g, float *occ, long occ_es, const float 
 
 // du/dv -> uu,vv, zero padding, L1 change norms (variational_mt.cpp:371-402); red = per-element 2 doubles (sum|old_du-du|, sum|old_dv-dv|)
 void launch_update_inner(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const float *du, const float *dv,
-                         const float *old_du, const float *old_dv, double *red /* [nb][2] */);
+                         const float *old_du, const float *old_dv, double *red /* [nb][2] */, float *dfa = nullptr, float *dfb = nullptr);   // dfa, dfb: the per-pixel terms (launch_exact_norms)
 // the same with du,dv taken from a solver workspace's x plane (diagonal-major); old_du == nullptr: zeros; du_out == nullptr:
 // du,dv are not stored
 void launch_update_inner_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, const float *wx, const float *wy, const SorOperandOut &x, const float *old_du,
-                           const float *old_dv, float *du_out, float *dv_out, double *red);
+                           const float *old_dv, float *du_out, float *dv_out, double *red, float *dfa = nullptr, float *dfb = nullptr);
+// the norms of the windows `which` as the reference forms them (fp32 running sums over blocks of four pixels in raster order, the fp32 division) from the per-pixel terms an
+// update left in dfa, dfb: out[2 b], out[2 b + 1] (device)
+void launch_exact_norms(sfa_ctx *c, const Geo &g, const float *dfa, const float *dfb, const WMask &which, float *out);
 // flow update of the LAST inner iteration straight from the x plane, fused with the outer update below (uu, vv, wx, wy all written)
 void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red, float *dfa = nullptr,
                            float *dfb = nullptr);   // dfa, dfb: where to leave the per-pixel |differences| (launch_outer_threshold)

@@ -534,6 +534,32 @@ def test_break_decision_at_the_threshold_is_the_reference_arithmetic(ctx, oracle
     assert abs(g[2][0] - o[2][0]) <= 2e-4 * abs(o[2][0]) or abs(g[2][0] - outer[k][1]) <= 2e-4 * abs(outer[k][1])      # either side of the threshold, to the sums' difference
 
 
+def test_inner_break_decision_at_the_threshold_is_the_reference_arithmetic(ctx, oracle):
+    """the same for the inner break (variational_mt.cpp:371-407, taken on the host; `slow_flow_niter_inner` > 1): the threshold set to the oracle's own fp32 norm of the
+    first inner iteration (no break there: all three run) and to the next float above it (break: one runs) -- two different flows, and the GPU follows the oracle
+    into each"""
+    w, h = 67, 45
+    frames, af, sf = normalized_frames(oracle, w, h, 3)
+    kw = dict(S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=1, niter_inner=3, thres_outer=0)
+    po, ps = mk_params(oracle, thres_inner=1e-12, **kw)
+    oracle.change_log(64)
+    wxo, wyo = orc.plane(h, orc.stride_of(w)), orc.plane(h, orc.stride_of(w))
+    rc, _, _ = oracle.compute_one_level(po, wxo, wyo, frames, w)
+    rows = oracle.change_log_rows().copy()
+    oracle.change_log(0)
+    inner = [np.float32(max(np.float32(a), np.float32(b))) for kind, it, a, b in rows if kind == 0]
+    assert rc == 0 and len(inner) == 3 and inner[1] > inner[0]      # (at the threshold m the second iteration then does not break either: one against three iterations)
+    m = inner[0]
+    flows = []
+    for thres in (m, np.nextafter(m, np.float32(np.inf))):
+        po, ps = mk_params(oracle, thres_inner=float(thres), **kw)
+        o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+        d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+        assert d <= TOL_LEVEL, (thres, d)
+        flows.append(o)
+    assert np.abs(valid(flows[0][0], w) - valid(flows[1][0], w)).max() > 100 * TOL_LEVEL           # the decision matters: one inner iteration more or less
+
+
 def test_nan_norms_never_break(ctx, oracle):
     """std::max(a, b) = (a < b) ? b : a keeps a NaN first argument (variational_mt.cpp:407,436): a NaN change norm is never below a threshold, so neither
     side breaks, both report NaN norms, and the NaNs have spread over the same pixels"""
