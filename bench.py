@@ -78,13 +78,18 @@ def sor_launch_waves(kernel, nb):
         hs.append(h)
         w, h = int(np.floor(np.float32(w) * np.float32(0.9))), int(np.floor(np.float32(h) * np.float32(0.9)))
     bands = np.mean([(hh + SWEEPS - 1 + 63) // 64 for hh in hs])
-    return nb * bands * (SWEEPS // kg) * (na + nb_ + 2)
+    fill = 1 if (fa == 1 and nb_ == 0 and na < 8) else 0        # the one-sweep shapes carry a FILL wave (ChainShape::INFILL)
+    return nb * bands * (SWEEPS // kg) * (na + nb_ + 2 + fill)
 
 
 def limiter(kernel, batch, streams):
     """What the solver kernel waits for -- a statement measured for ONE configuration (k_sor_chain<3,5,3,0,...>, 64 windows per launch: what-if builds of
     DESIGN.md 5.1, profiles/r03_chain_whatif.txt) and printed only for it; any other shape or batch gets the plain label."""
     k = kernel.replace(" ", "")
+    if "k_sor_chain<2,6,3,1" in k and batch >= 10:
+        return ("VALU time of the busiest SIMDs: one 9-wave workgroup per CU (its operand ring fills the LDS), seven compute waves of 2,2,2,2,2,2,3 sweeps -- the first six "
+                "two to a SIMD (4 sweeps each), the last beside the two I/O waves; a packed operation takes two passes, so a pair of compute waves keeps its SIMD busy nearly "
+                "all of an interval (DESIGN.md 5.1: the six-stage shape of round 4 put 5 sweeps on two of the SIMDs)")
     if "k_sor_chain<3,3,2,3" in k and batch >= 16:
         return ("wave issue rate: one 8-wave workgroup per CU (its operand ring fills the LDS), six compute waves of 3,3,3,2,2,2 sweeps two to a SIMD -- the SIMDs that "
                 "carry 5 sweeps set the pace (the 5 x 3 shape of round 3, 6 sweeps on one SIMD, was within 6 % of its compute-only build: DESIGN.md 5.1)")

@@ -970,9 +970,12 @@ static int chain_choice(int K, int nb, int NBands) {
         // Round 4: shape 11 (six stages of 3,3,3,2,2,2 sweeps: with the two I/O waves eight waves, two per SIMD, at most 5 sweeps on a SIMD where 5 x 3 puts 6)
         //   16 windows 582 -> 523, 32: 859 -> 770, 64: 1515 -> 1408 (shape 12 = 2,2,2,3,3,3: 553 / 813 / 1470).
         //   shape 16 = shape 6 with one-interval poll / publication lags (sor_chain.hip kChainShapes): faster up to four windows, slower from eight on
-        static const int lone[] = {16, 6, 1, 2, 5, 3, 0}, few[] = {6, 1, 2, 5, 3, 0}, many[] = {11, 3, 5, 2, 6, 1, 0};
+        // Round 5: shape 14 (seven stages of 2,2,2,2,2,2,3 sweeps on nine waves: the first stage -- the one with the operand loads and the ring fill -- carries two
+        //   sweeps and shares a SIMD with a 2-sweep stage, the 3-sweep LAST stage sits beside the two I/O waves: at most 4 sweeps on a SIMD where shape 11 puts 5)
+        //   10 windows 455 -> 425 (1 x 5: 432), 12: 465 -> 430, 16: 480 -> 440, 32: 717 -> 670, 64: 1274 -> 1179-1200; 8 windows: 419 against 407 for 1 x 5
+        static const int lone[] = {16, 6, 1, 2, 5, 3, 0}, few[] = {6, 1, 2, 5, 3, 0}, many[] = {14, 11, 3, 5, 2, 6, 1, 0};
         int KG, NW, FMAX;
-        for (const int *cand = bands <= 32 ? lone : bands <= 84 ? few : many; *cand; cand++)          // 80 bands: 1 x 5 424 / 294 us (1024x436 / 670x284), six stages 488 / 327; 88-100: 512 / 371 against 492 / 333
+        for (const int *cand = bands <= 32 ? lone : bands <= 72 ? few : many; *cand; cand++)          // 64 bands: 1 x 5 407 us, seven stages 419; 80 bands: 432 against 425
             if (chain_shape(*cand, K, &KG, &NW, &FMAX)) { id = *cand; break; }
     }
     int KG, NW, FMAX;

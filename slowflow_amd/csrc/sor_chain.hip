@@ -152,6 +152,9 @@ struct ChainShape {
     // waves -- SIMD 0 takes the two I/O waves and the 3-sweep first stage (wave 4), the other three SIMDs two 2-sweep stages each: at most 4 sweeps on a SIMD where
     // the six-stage shape (3,3,3,2,2,2 on eight waves) puts 5.
     static constexpr bool PERM9 = NW == 7 && NA == 1;
+    // seven stages of 2,2,2,2,2,2,3 sweeps on nine waves: the LAST stage (3 ring-fed sweeps, no loads) shares SIMD 0 with the two I/O waves (wave 4); the first stage (2 sweeps +
+    // the operand loads + the ring fill) and the other five pair up on SIMDs 1-3: (st0, st3) (st1, st4) (st2, st5) -- at most 4 sweeps on a SIMD
+    static constexpr bool PERM9L = NW == 7 && NA == 6 && NB_ == 1;
 #ifndef SFA_CHAIN_PERM6
 #define SFA_CHAIN_PERM6 0
 #endif
@@ -161,7 +164,9 @@ struct ChainShape {
     __host__ __device__ static constexpr int stage_of_wave6(int wave) {
         return SFA_CHAIN_PERM6 == 1 ? (wave == 1 ? 2 : wave == 3 ? 0 : wave - 1) : SFA_CHAIN_PERM6 == 2 ? (wave == 4 ? 0 : wave == 1 ? 3 : wave - 1) : wave - 1;
     }
-    __host__ __device__ static constexpr int stage_of_wave(int wave) { return PERM9 ? (wave == 4 ? 0 : wave < 4 ? wave : wave - 1) : NW == 6 ? stage_of_wave6(wave) : wave - 1; }
+    __host__ __device__ static constexpr int stage_of_wave(int wave) {
+        return PERM9 ? (wave == 4 ? 0 : wave < 4 ? wave : wave - 1) : PERM9L ? (wave == 4 ? 6 : wave < 4 ? wave - 1 : wave - 2) : NW == 6 ? stage_of_wave6(wave) : wave - 1;
+    }
 };
 
 // LDS map of a workgroup (bytes).  rings: [NW+1][2][CH][64] u64 (ring w = input of compute wave w; ring NW = output of the last one);
@@ -1009,6 +1014,7 @@ static const ChainShapeInfo kChainShapes[] = {
     {16, 1, 5, 1, 0, 4, 1, 1},     // 5 stages of 1, one-interval poll / publication lags: the lone solve
     {17, 1, 3, 1, 0, 4, 1, 1},     // 3 stages of 1 with the same lags: every compute wave alone on its SIMD, ten groups per band
     {19, 1, 6, 1, 0, 4, 1, 1},     // 6 stages of 1: five groups per band
+    {14, 2, 6, 3, 1, 2, 1, 1},     // 6 stages of 2 + 1 of 3         KG = 15: nine waves, the last stage beside the I/O waves (ChainShape::PERM9L)
 };
 
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
@@ -1054,6 +1060,7 @@ int chain_shift(int id) {
         case 13: return shape_shift<3, 1, 2, 6>();
         case 17: return shape_shift<1, 3, 1, 0>();
         case 19: return shape_shift<1, 6, 1, 0>();
+        case 14: return shape_shift<2, 6, 3, 1>();
     }
     return 0;
 }
@@ -1107,6 +1114,7 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
         case 13: return chain_launch_shape<3, 1, 2, 6, 2, 1, 1>(c, a, nwg);
         case 17: return chain_launch_shape<1, 3, 1, 0, 4, 1, 1>(c, a, nwg);
         case 19: return chain_launch_shape<1, 6, 1, 0, 4, 1, 1>(c, a, nwg);
+        case 14: return chain_launch_shape<2, 6, 3, 1, 2, 1, 1>(c, a, nwg);
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }
 }

@@ -225,12 +225,12 @@ def test_sor_golden(ctx, w, h):
         assert np.array_equal(s["dv"][:, :w], G[f"sor_{w}x{h}_K{K}_dv"][:, :w])
 
 
-@pytest.mark.parametrize("nb,shape", [(1, "k_sor_chain<1,5,1,0,4,4,2,1,1"), (4, "k_sor_chain<1,5,1,0,4,4,2,1,1"), (8, "k_sor_chain<1,5,1,0,4,4,2,2,2"), (11, "k_sor_chain<3,3,2,3,4,2,2,1,1"),
-                                      (16, "k_sor_chain<3,3,2,3"), (64, "k_sor_chain<3,3,2,3")])
+@pytest.mark.parametrize("nb,shape", [(1, "k_sor_chain<1,5,1,0,4,4,2,1,1"), (4, "k_sor_chain<1,5,1,0,4,4,2,1,1"), (8, "k_sor_chain<1,5,1,0,4,4,2,2,2"), (9, "k_sor_chain<1,5,1,0,4,4,2,2,2"), (10, "k_sor_chain<2,6,3,1,4,2,2,1,1"),
+                                      (16, "k_sor_chain<2,6,3,1"), (64, "k_sor_chain<2,6,3,1")])
 def test_default_solver_shape_and_its_bits(ctx, oracle, nb, shape):
     """what the library launches by default at 1024x436 x 30 (8 bands per system) for 1 ... 64 systems per launch -- the chain kernel with the operand ring at every
-    batch size: five stages of one sweep up to 84 bands per launch (with one-interval poll / publication lags up to 32 bands), six stages of 3,3,3,2,2,2 sweeps
-    above (round 4) -- and that the first and the last system of the launch are the raster-order oracle's bits"""
+    batch size: five stages of one sweep up to 72 bands per launch (with one-interval poll / publication lags up to 32 bands), seven stages of 2,2,2,2,2,2,3 sweeps
+    on nine waves above (round 5; six stages of 3,3,3,2,2,2 in round 4) -- and that the first and the last system of the launch are the raster-order oracle's bits"""
     w, h, K = 1024, 436, 30
     rng = np.random.default_rng(100 + nb)
     systems = [sor_system(rng, w, h) for _ in range(2)]
@@ -291,7 +291,9 @@ SOR_VARIANTS = {"task_f1": {"SFA_SOR_BAND": "0", "SFA_SOR_F": "1", "SFA_SOR_CH":
                 # 1 x 5 with one-interval poll / publication lags (the lone-solve default; 11 runs with them too)
                 "chain_1x5_lags1": {"SFA_SOR_CHAIN": "16"},
                 # round 5: the one-sweep shapes take their operand rows from a FILL wave (LDS-DMA) and the first stage reads the ring too; 1 x 3 and 1 x 6 with the lone solve's lags
-                "chain_1x3_lags1": {"SFA_SOR_CHAIN": "17"}, "chain_1x6_lags1": {"SFA_SOR_CHAIN": "19"}}
+                "chain_1x3_lags1": {"SFA_SOR_CHAIN": "17"}, "chain_1x6_lags1": {"SFA_SOR_CHAIN": "19"},
+                # round 5: seven stages of 2,2,2,2,2,2,3 sweeps on nine waves, the last stage beside the I/O waves (the default from 73 bands on)
+                "chain_2x6_3x1": {"SFA_SOR_CHAIN": "14"}}
 
 
 @pytest.mark.parametrize("variant", sorted(SOR_VARIANTS))

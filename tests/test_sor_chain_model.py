@@ -22,7 +22,8 @@ def _sim(mode, slack, pubd=2):
 
 CASES = [(40, 70, 12, (2, 3, 2, 0), 1), (50, 130, 9, (1, 3, 1, 0), 2), (45, 100, 14, (4, 1, 3, 1), 1), (33, 150, 12, (3, 2, 3, 0), 1), (37, 200, 10, (2, 5, 2, 0), 1),
          (41, 140, 30, (3, 3, 2, 3), 1), (36, 90, 15, (2, 3, 3, 3), 2),          # round 4: the six-stage shapes of mixed width (3,3,3,2,2,2 is the default from 97 bands on)
-         (43, 150, 30, (3, 1, 2, 6), 1)]                                          # round 5: seven stages of 3,2,2,2,2,2,2 sweeps on nine waves
+         (43, 150, 30, (3, 1, 2, 6), 1),                                          # round 5: seven stages of 3,2,2,2,2,2,2 sweeps on nine waves
+         (43, 150, 30, (2, 6, 3, 1), 1), (37, 90, 15, (2, 6, 3, 1), 2)]           # ... and of 2,2,2,2,2,2,3: the default from 73 bands on
 
 
 @pytest.mark.parametrize("mode", ["raw", "war"])
@@ -40,7 +41,7 @@ def test_chain_protocol_thresholds_are_tight():
 
 
 @pytest.mark.parametrize("mode", ["raw", "war"])
-@pytest.mark.parametrize("w,h,K,shape,nb", [(41, 140, 30, (3, 3, 2, 3), 1), (50, 130, 10, (1, 5, 1, 0), 2), (40, 70, 12, (2, 3, 2, 0), 1)])
+@pytest.mark.parametrize("w,h,K,shape,nb", [(41, 140, 30, (3, 3, 2, 3), 1), (50, 130, 10, (1, 5, 1, 0), 2), (40, 70, 12, (2, 3, 2, 0), 1), (43, 150, 30, (2, 6, 3, 1), 1)])
 def test_chain_protocol_model_with_one_interval_of_publication_delay(mode, w, h, K, shape, nb):
     """round 4: the default shapes for one to four windows (1 x 5) and from 13 windows on (3,3,3,2,2,2) are launched with PUBD = 1 -- the progress word covers
     the stores of the previous interval (a counted vmcnt wait over T instead of 2 T memory instructions); the consumers' thresholds are in published counts and do
@@ -56,7 +57,7 @@ def test_chain_protocol_thresholds_are_tight_with_one_interval_too():
     assert bad > 0
 
 
-ALL_SHAPES = [(1, 3, 1, 0), (2, 3, 2, 0), (3, 5, 3, 0), (2, 5, 2, 0), (1, 5, 1, 0), (3, 2, 3, 0), (3, 3, 2, 3), (2, 3, 3, 3), (3, 1, 2, 6), (1, 6, 1, 0)]      # kChainShapes with an operand ring
+ALL_SHAPES = [(1, 3, 1, 0), (2, 3, 2, 0), (3, 5, 3, 0), (2, 5, 2, 0), (1, 5, 1, 0), (3, 2, 3, 0), (3, 3, 2, 3), (2, 3, 3, 3), (3, 1, 2, 6), (1, 6, 1, 0), (2, 6, 3, 1)]      # kChainShapes with an operand ring
 
 
 @pytest.mark.parametrize("shape", ALL_SHAPES)
@@ -81,5 +82,5 @@ def test_operand_ring_depth_and_read_ahead(shape):
     else:
         assert {b[0] for b in m.ring_hazards(S, opr, (pf[0] + 1, pf[1]))} & {"raw", "raw-self", "raw-in"}          # the first stage cannot read further ahead
         assert {b[0] for b in m.ring_hazards(S, opr - 1, pf)} == {"war"} or opr > oprmin - (pf[1] - 1)               # a shape at its tight depth has no row to spare
-    if shape == (3, 1, 2, 6):
+    if shape in ((3, 1, 2, 6), (2, 6, 3, 1)):
         assert opr == 51 and {b[0] for b in m.ring_hazards(S, opr, (2, 2))} == {"war"}                            # ... and needs the later stages' third step of read-ahead
