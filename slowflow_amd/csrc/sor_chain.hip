@@ -98,8 +98,8 @@ __device__ __forceinline__ void batomic_umax4(const RsrcWords &r, unsigned voff,
 #define SFA_CHAIN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 #ifdef SFA_CHAIN_TIMING
-// per-phase wave cycles (s_memtime) of the first workgroups of window 0: [wg < 64][wave < 8][16 words]
-__device__ unsigned long long g_chain_timing[64 * 8 * 16];
+// per-phase wave cycles (s_memtime) of the first workgroups of window 0: [wg < 64][wave < 16][16 words]
+__device__ unsigned long long g_chain_timing[64 * 16 * 16];
 #define SFA_CT_STAMP(t) do { t = __builtin_readcyclecounter(); } while (0)
 // stamped barrier: time spent waiting at the barrier goes to `acc`
 #define SFA_CHAIN_BARRIER_T(acc) do { unsigned long long _t0, _t1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); _t0 = __builtin_readcyclecounter(); \
@@ -461,7 +461,7 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
 #ifdef SFA_CHAIN_TIMING
     t_last = __builtin_readcyclecounter();
     if (job == 0 && lane == 0 && (int)blockIdx.x < 64) {
-        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16;
         o[0] = t_begin; o[1] = t_first; o[2] = t_last; o[3] = t_lead; o[4] = t_bar; o[5] = (unsigned long long)b; o[6] = (unsigned long long)k0; o[7] = (unsigned long long)a.nch;
         o[8] = t_ldsrd; o[9] = t_wr; o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
@@ -673,7 +673,7 @@ __device__ __forceinline__ void chain_in(const ChainArgs &a, unsigned char *lds,
     }
 #ifdef SFA_CHAIN_TIMING
     if (job == 0 && lane == 0 && (int)blockIdx.x < 64) {
-        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16;
         o[0] = t_begin; o[1] = __builtin_readcyclecounter(); o[2] = t_bar; o[6] = t_slow; o[8] = n_slow; o[3] = rt_begin; o[4] = __builtin_amdgcn_s_memrealtime();
         o[9] = (unsigned long long)b; o[10] = (unsigned long long)g; o[11] = (unsigned long long)a.NI; o[12] = 0x10ull;
         o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
@@ -829,7 +829,7 @@ __device__ __forceinline__ void chain_out(const ChainArgs &a, unsigned char *lds
     }
 #ifdef SFA_CHAIN_TIMING
     if (job == 0 && lane == 0 && (int)blockIdx.x < 64) {
-        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;
+        unsigned long long *o = g_chain_timing + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16;
         o[0] = t_begin; o[1] = __builtin_readcyclecounter(); o[2] = t_bar; o[4] = t_pub;
         o[9] = (unsigned long long)b; o[10] = (unsigned long long)g; o[11] = (unsigned long long)a.NI; o[12] = 0x20ull;
         o[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
@@ -1122,5 +1122,5 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
 }  // namespace sfa
 
 #ifdef SFA_CHAIN_TIMING
-extern "C" int sfa_debug_chain_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sfa::g_chain_timing), sizeof(unsigned long long) * 64 * 8 * 16); }
+extern "C" int sfa_debug_chain_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sfa::g_chain_timing), sizeof(unsigned long long) * 64 * 16 * 16); }
 #endif
