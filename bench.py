@@ -151,10 +151,31 @@ def bench_params():
     return p
 
 
-def cpu_baseline(budget_s=12.0):
+PARITY_WINDOWS = (0, 63, 64, 127)      # both words of the job's window mask, first and last bit of each (sfa_internal.h: WMask)
+
+
+def reference_statistics(frames, w):
+    """normalize()'s statistics (variational_mt.cpp:26-52) evaluated with numpy on the RAW frames: per frame and channel the fp64 sum of I and of the fp32
+    product I*I over the valid pixels, each divided by w*h and accumulated in frame order, then mean and sqrt(mean of squares - mean^2) / 255.  The bench's
+    frames are 8-bit values, so every partial sum is an integer below 2^53 and the result does not depend on the summation order: the GPU's tree sum, the
+    oracle's raster sum and this evaluation must agree to the last bit."""
+    avg, sq = np.zeros(3), np.zeros(3)
+    for f in frames:
+        _, h, _ = f.shape
+        v = f[:, :, :w]
+        avg += v.sum(axis=(1, 2), dtype=np.float64) / (h * w)
+        sq += (v * v).sum(axis=(1, 2), dtype=np.float64) / (h * w)
+    avg /= len(frames)
+    std = np.sqrt(sq / len(frames) - avg * avg) / 255.0
+    return avg, std
+
+
+def cpu_baseline(windows=None, stats=None, budget_s=12.0):
     """The same workload on the host: the CPU restatement of the whole path (oracle/, kind "port": the reference's own
     Variational_MT needs OpenCV/GCO and cannot be built here) refining frame windows of the bench configuration on ONE core,
-    as the reference runs a window single-threaded; window after window until about `budget_s` seconds are spent.  Beside it,
+    as the reference runs a window single-threaded.  `windows` = [(index, normalised frames)] are the very windows the GPU job
+    timed (identical inputs -- the frames as normalize() left them and the sequence statistics published at six
+    digits, variational_mt.cpp:71-84); their flow fields come back in out["_flows"] for the caller's parity figure.  Beside it,
     the reference's own compiled sor_coupled (oracle/_ref, solver.c:63) on the metric's 1024x436 x 30 solve."""
     import oracle as orc
     from synth import copy_sys, sor_system
@@ -164,24 +185,38 @@ def cpu_baseline(budget_s=12.0):
     p.thres_outer = 0; p.thres_inner = 0; p.occlusion_reasoning = 0; p.hbit = 0
     p.rho[0] = 1; p.omega[0] = 0
     n, t_total, mpix = 0, 0.0, 0.0
-    while t_total < budget_s and n < 8:
+    flows = {}
+    if windows is None:                                # (stand-alone use: windows of its own)
+        windows = []
+        for i in range(4):
+            fr = []
+            for f in synth_window(5000 + i):
+                a = orc.aligned_zeros(f.shape)
+                a[...] = f
+                fr.append(a)
+            _, _, af, sf = o.normalize(fr, W)
+            windows.append((i, fr, (af, sf)))
+    for item in windows:
+        idx, frames = item[0], item[1]
+        af, sf = item[2] if len(item) > 2 else stats
         fr = []
-        for f in synth_window(5000 + n):
+        for f in frames:
             a = orc.aligned_zeros(f.shape)
             a[...] = f
             fr.append(a)
-        _, _, af, sf = o.normalize(fr, W)
         for k in range(3):
             p.norm_avg[k] = af[k]; p.norm_std[k] = sf[k]
         wx, wy = orc.plane(H, orc.stride_of(W)), orc.plane(H, orc.stride_of(W))
         t0 = time.perf_counter()
         o.variational(p, wx, wy, fr, W)
         t_total += time.perf_counter() - t0
+        flows[idx] = (wx[:, :W].copy(), wy[:, :W].copy())
         n += 1
     ws, hs = sfa.pyramid_sizes(W, H, LAYERS, p.p_scale)
     mpix = n * sum(w_ * h_ for w_, h_ in zip(ws, hs)) * OUTER * INNER * SWEEPS / 1e6
     out = {"value": round(mpix / t_total, 2), "unit": "Mpix*solver-iters/s", "cores": 1, "kind": "port",
-           "sample": f"{n} frame window(s) of the bench configuration through the whole path ({t_total:.1f} s, {t_total / n:.2f} s per window)"}
+           "sample": f"{n} frame window(s) of the bench configuration through the whole path ({t_total:.1f} s, {t_total / n:.2f} s per window): "
+                     f"windows {sorted(flows)} of the GPU's timed job, same normalised frames and statistics", "_flows": flows}
     # the solver alone, the reference's own code
     rng = np.random.default_rng(0)
     s0 = sor_system(rng, W, H)
@@ -621,7 +656,10 @@ def main():
     backend = os.environ.get("SFA_BENCH_BACKEND", "nccl")
     ndev = max(1, torch.cuda.device_count())
     xdev = "cuda" if backend == "nccl" else "cpu"                 # where the tensors of the timing exchange live
-    if world > 1:
+    # a process group whenever this process was started as a rank (torch.distributed.run exports WORLD_SIZE), also as the only one: `torch.distributed.run
+    # --nproc-per-node 1 bench.py --gpus 1` then walks the same RCCL calls as N = 8 -- init with a device id, barriers, the MAX / SUM all-reduces and the timing
+    # gather on device tensors -- which is as much of that leg as a one-GPU box can run (tests/test_bench_launch.py::test_one_rank_over_rccl)
+    if world > 1 or all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank % ndev)
         if backend == "nccl":
@@ -632,7 +670,7 @@ def main():
         torch.cuda.set_device(0)
 
     import threading
-    dev = (local_rank % ndev) if world > 1 else 0
+    dev = (local_rank % ndev) if dist is not None else 0
     S = max(1, args.streams)
     B = args.batch
     if B % S:
@@ -644,9 +682,27 @@ def main():
     # one normalisation for the whole sequence, as the driver does (slow_flow.cpp:673)
     windows = [synth_window(1000 * rank + b) for b in range(B)]
     allf = [f for wdw in windows for f in wdw]
+    # parity of the timed workload (rank 0, N = 1, with the CPU leg): the windows PARITY_WINDOWS of the timed job are refined by the oracle from the same
+    # normalised frames and statistics after the bench, and normalize() itself is checked against a numpy evaluation of the reference's statistics on the raw frames
+    want_parity = world == 1 and not args.no_cpu_baseline
+    par_idx = [b for b in PARITY_WINDOWS if b < B] if want_parity else []
+    raw = {b: [f.copy() for f in windows[b]] for b in par_idx}
+    ref_stats = reference_statistics(allf, W) if want_parity else None
     avg, std = ctx.normalize(allf, W)
     for k in range(3):
         p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])     # 6-digit publish, variational_mt.cpp:71-84
+    norm_check = None
+    if want_parity:
+        worst = 0
+        for b in par_idx:
+            for fr_raw, fr_gpu in zip(raw[b], windows[b]):
+                for k in range(3):
+                    want = ((fr_raw[k, :, :W].astype(np.float64) - ref_stats[0][k]) / ref_stats[1][k]).astype(np.float32)      # variational_mt.cpp:64-66
+                    worst = max(worst, int(np.abs(want.view(np.int32).astype(np.int64) - fr_gpu[k, :, :W].view(np.int32).astype(np.int64)).max()))
+        norm_check = {"statistics_equal_numpy_fp64": bool(all(avg[k] == ref_stats[0][k] and std[k] == ref_stats[1][k] for k in range(3))),
+                      "frames_checked": 3 * len(par_idx), "max_ulp_normalised_frames": worst,
+                      "note": "normalize() of all %d frames on the GPU against variational_mt.cpp:26-66 evaluated with numpy on the raw 8-bit frames (integer sums: exact in any order)" % len(allf)}
+    del raw
     jobs = [sfa.Job(c, p, W, H, BL) for c in ctxs]
     for g, job in enumerate(jobs):
         for b in range(BL):
@@ -684,6 +740,11 @@ def main():
         na_, ma_, pa_, sor_kernel = c.profile_read_kernels()
         n_asm += na_; asm_ms += ma_; asm_px += pa_
         c.profile_enable(False)
+    # what the timed job computed: the flow fields of the parity windows, as the last timed step left them
+    gpu_flows = {}
+    for b in par_idx:
+        gx, gy, _ = jobs[b // BL].download(b % BL)
+        gpu_flows[b] = (gx[:, :W].copy(), gy[:, :W].copy())
     from slowflow_amd import shard
     if dist is not None:
         dist.barrier()
@@ -756,6 +817,8 @@ def main():
                          },
             "sor_share_of_step": round(sor_ms / S / (elapsed * 1e3), 4),
             "seconds_per_window": {"mean": round(float(window_seconds.mean()), 6), "max": round(float(window_seconds.max()), 6), "n": int(window_seconds.size)},
+            # how the ranks met (None: a lone process without torch.distributed)
+            "distributed": ({"backend": backend, "world_size": world, "exchange_tensors_on": xdev, "collectives": "barrier, all_reduce(MAX), all_reduce(SUM)"} if dist is not None else None),
         }
         vpw, vpw_src = sor_valu_per_wave(sor_kernel)
         if vpw and n_sor:
@@ -834,7 +897,19 @@ def main():
         except Exception as e:                                    # a measurement aid only
             out["roofline"]["measured_triad_gbs"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            cb = cpu_baseline(windows=[(b, windows[b]) for b in par_idx], stats=([p.norm_avg[k] for k in range(3)], [p.norm_std[k] for k in range(3)]))
+            cpu_flows = cb.pop("_flows")
+            out["cpu_baseline"] = cb
+            d = max(max(float(np.abs(cpu_flows[b][0] - gpu_flows[b][0]).max()), float(np.abs(cpu_flows[b][1] - gpu_flows[b][1]).max())) for b in par_idx)
+            finite = all(np.isfinite(gpu_flows[b][0]).all() and np.isfinite(gpu_flows[b][1]).all() for b in par_idx)
+            out["parity"] = {"windows": list(par_idx), "max_abs_uv": float("%.3g" % d), "tol": 1e-4, "ok": bool(finite and d <= 1e-4),
+                             "of": "the flow fields the LAST TIMED STEP left in the timed job (windows of both mask words of the %d-window launch group), downloaded after the timed region" % BL,
+                             "against": "oracle.variational (the CPU restatement, pinned to the compiled reference: DESIGN.md 3) on the same normalised frames and 6-digit statistics -- "
+                                        "the runs cpu_baseline times",
+                             "mean_flow_px": [round(float(np.mean([gpu_flows[b][0].mean() for b in par_idx])), 4), round(float(np.mean([gpu_flows[b][1].mean() for b in par_idx])), 4)],
+                             "normalisation": norm_check}
+        else:
+            out["parity"] = None                                  # (N > 1 or --no-cpu-baseline: no CPU leg in this run; tests/test_gpu_parity.py::test_bench_job_128_windows_against_the_oracle)
         print(json.dumps(out), flush=True)
     for job in jobs:
         job.close()

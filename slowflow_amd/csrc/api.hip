@@ -283,10 +283,10 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     const bool dbg = sw_given(Switches::DEBUG_ACTIVE);
     g.amask = c->d_amask;
     // With an outer threshold the update leaves the per-pixel terms of the norms in the a11 / a12 planes (dead by then: the direct form never writes them, the other
-    // forms' solver has read them), so that a window whose fp64 norm lies within 1e-3 of the threshold can be decided by the reference's own fp32 running sums
+    // forms' solver has read them), so that a window whose fp64 norm lies within break_band() of the threshold can be decided by the reference's own fp32 running sums
     float *const dfa = use_thres_out && !sw_given(Switches::NO_EXACT_BREAK) ? L.plane(P_A11) : nullptr, *const dfb = dfa ? L.plane(P_A12) : nullptr;
     float *const ifa = use_thres_in && !sw_given(Switches::NO_EXACT_BREAK) ? L.plane(P_A11) : nullptr, *const ifb = ifa ? L.plane(P_A12) : nullptr;   // the inner break's
-    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long) + 2 * kMaxBatch * sizeof(float), c->stream));   // (+ the windows' finished-block counters of k_update_outer_x)
+    SFA_HIP(c, hipMemsetAsync(c->d_last, 0, sizeof(LastBlock), c->stream));   // (the norms, the windows' finished-block counters of k_update_outer_x, ...)
     launch_set_mask(c, all);
 
     for (int alter = 0; alter < p.niter_alter; alter++) {
@@ -320,7 +320,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                 gi.active = in_active;
                 const bool direct = direct_outer;
                 // an inner break is decided behind this iteration: the update leaves the per-pixel terms of its norms (a11 / a12 planes: dead, see dfa), so that a
-                // window whose fp64 norm lies within 1e-3 of the threshold can be decided by the reference's own fp32 sums
+                // window whose fp64 norm lies within break_band() of the threshold can be decided by the reference's own fp32 sums
                 const bool decide_in = use_thres_in && inner + 1 < p.niter_inner && ifa;
                 const bool first_zero = direct && inner == 0;        // du = dv = 0 known, planes possibly stale
                 if (!first_zero) {
@@ -370,15 +370,15 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
                     for (int b = 0; b < L.nb; b++)
                         if (in_active.test(b)) {
                             const double ad = c->h_red[2 * b] / npx, dd = c->h_red[2 * b + 1] / npx, dm = (ad < dd) ? dd : ad;
-                            if (decide_in && fabs(dm - (double)p.thres_inner) <= 1e-3 * (double)p.thres_inner) { close.set(b); continue; }
+                            if (decide_in && fabs(dm - (double)p.thres_inner) <= break_band(L.w, L.h) * (double)p.thres_inner) { close.set(b); continue; }
                             const float a = (float)ad, d = (float)dd;
                             if (std::max(a, d) < p.thres_inner) in_active.clear(b);                         // :407
                         }
                     if (close.any()) {
-                        float *dx = reinterpret_cast<float *>(reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned *>(c->d_last + 2 * kMaxBatch) + kMaxBatch) + kMaskWords);
-                        float hx[2 * kMaxBatch];
+                        float *const dx = c->d_last->exact;
+                        const float *const hx = reinterpret_cast<const LastBlock *>(c->h_red)->exact;        // pinned (a pageable target would be a staged, blocking copy)
                         launch_exact_norms(c, gi, ifa, ifb, close, dx);
-                        SFA_HIP(c, hipMemcpyAsync(hx, dx, 2 * L.nb * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+                        SFA_HIP(c, hipMemcpyAsync(const_cast<float *>(hx), dx, 2 * L.nb * sizeof(float), hipMemcpyDeviceToHost, c->stream));
                         SFA_HIP(c, hipStreamSynchronize(c->stream));
                         for (int b = 0; b < L.nb; b++)
                             if (close.test(b) && std::max(hx[2 * b], hx[2 * b + 1]) < p.thres_inner) in_active.clear(b);   // :407 on the reference's own sums
@@ -407,7 +407,7 @@ static int run_level(sfa_ctx *c, const Level &L, const sfa_params &p, const Chan
     // only there does the host wait for the level: a blocking read per level left the GPU idle for ~30 us five times per run (a lone window: 2 % of its time)
     (void)npx;
     if (change) {
-        SFA_HIP(c, hipMemcpyAsync(c->h_red, c->d_last, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        SFA_HIP(c, hipMemcpyAsync(c->h_red, c->d_last->last, 2 * L.nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         SFA_HIP(c, hipStreamSynchronize(c->stream));
         for (int i = 0; i < 2 * L.nb; i++) change[i] = (float)c->h_red[i];
     }
@@ -509,10 +509,10 @@ int sfa_ctx_create(int device, sfa_ctx **out) {
     SFA_HIP(c.get(), hipSetDevice(device));
     SFA_HIP(c.get(), hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_red, kRedDoubles * sizeof(double)));
-    SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, 2 * kMaxBatch * sizeof(double) + 64, hipHostMallocDefault));
+    SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_red, sizeof(LastBlock) + 64, hipHostMallocDefault));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_amask, 64));
-    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long) + 2 * kMaxBatch * sizeof(float)));
-    SFA_HIP(c.get(), hipMemset(c->d_last, 0, 2 * kMaxBatch * sizeof(double) + kMaxBatch * sizeof(unsigned) + kMaskWords * sizeof(unsigned long long) + 2 * kMaxBatch * sizeof(float)));
+    SFA_HIP(c.get(), hipMalloc((void **)&c->d_last, sizeof(LastBlock)));
+    SFA_HIP(c.get(), hipMemset(c->d_last, 0, sizeof(LastBlock)));
     SFA_HIP(c.get(), hipHostMalloc((void **)&c->h_amask, kMaskRing * sizeof(WMask), hipHostMallocDefault));
     for (auto &e : c->ev_mask) SFA_HIP(c.get(), hipEventCreateWithFlags(&e, hipEventDisableTiming));
     SFA_HIP(c.get(), hipMalloc((void **)&c->d_err, 64));

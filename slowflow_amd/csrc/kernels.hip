@@ -1825,12 +1825,12 @@ __global__ void k_reduce_partials(const double *__restrict__ partial, int per_el
 
 // The outer break on the device (variational_mt.cpp:431-436): the norms of the windows that ran this outer iteration, and the windows that go on.
 // One wave per mask word; lane = window within the word.  `last` keeps every window's norms of ITS last iteration (what the caller gets back as the change).
-// `unsure` (or null): the windows whose norm lies within kBreakBand of the threshold.  The reference forms the norms as fp32 running sums in raster order
-// (variational_mt.cpp:412-425); the fp64 tree sum here differs from that by ~1e-5 of its value (random walk of 111 000 roundings; worst case 3.3e-3), so outside
-// the band the two decide alike, and inside it k_exact_break repeats the reference's own summation.  Their bits stay set here.
-constexpr double kBreakBand = 1e-3;
+// `unsure` (or null): the windows whose norm lies within `band` (sfa_internal.h: break_band -- the bound on the difference between the two summations at this
+// image size) of the threshold.  The reference forms the norms as fp32 running sums in raster order (variational_mt.cpp:412-425); the fp64 tree sum here differs
+// from that by ~1e-5 of its value typically and by at most `band`, so outside the band the two decide alike, and inside it k_exact_break repeats the reference's
+// own summation.  Their bits stay set here.
 __global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict__ red, double *__restrict__ last, unsigned long long *__restrict__ amask,
-                                                        WMask active, int nb, double npx, float thres, unsigned long long *__restrict__ unsure) {
+                                                        WMask active, int nb, double npx, float thres, unsigned long long *__restrict__ unsure, double band) {
     const int word = blockIdx.x, b = 64 * word + (int)threadIdx.x;
     const unsigned long long cur = amask[word] & active.w[word];
     bool met = false, close = false;
@@ -1843,7 +1843,7 @@ __global__ void __launch_bounds__(64) k_outer_threshold(const double *__restrict
         const float mx = (fa < fd) ? fd : fa;
         met = thres > 0.0f && mx < thres;
         const double dm = (a < d) ? d : a;
-        close = unsure && thres > 0.0f && fabs(dm - (double)thres) <= kBreakBand * (double)thres;
+        close = unsure && thres > 0.0f && fabs(dm - (double)thres) <= band * (double)thres;
         if (close) met = false;
     }
     const unsigned long long m = __ballot(met), u = __ballot(close);
@@ -1903,12 +1903,12 @@ void launch_exact_norms(sfa_ctx *c, const Geo &g, const float *dfa, const float 
     hipLaunchKernelGGL(k_exact_norms, dim3(g.nb), dim3(64), 0, c->stream, dfa, dfb, out, which, g);
 }
 __global__ void k_set_mask(unsigned long long *amask, WMask v) { for (int i = 0; i < kMaskWords; i++) amask[i] = v.w[i]; }
-static unsigned long long *unsure_of(sfa_ctx *c) { return reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned *>(c->d_last + 2 * kMaxBatch) + kMaxBatch); }
+static unsigned long long *unsure_of(sfa_ctx *c) { return c->d_last->unsure; }
 void launch_outer_threshold(sfa_ctx *c, const Geo &g, const double *red, float thres, const float *dfa, const float *dfb) {
     const bool exact = dfa && thres > 0.0f;
-    hipLaunchKernelGGL(k_outer_threshold, dim3(kMaskWords), dim3(64), 0, c->stream, red, c->d_last, c->d_amask, g.active, g.nb, (double)g.h * g.w, thres,
-                       exact ? unsure_of(c) : (unsigned long long *)nullptr);
-    if (exact) hipLaunchKernelGGL(k_exact_break, dim3(g.nb), dim3(64), 0, c->stream, dfa, dfb, c->d_last, c->d_amask, unsure_of(c), g, thres);
+    hipLaunchKernelGGL(k_outer_threshold, dim3(kMaskWords), dim3(64), 0, c->stream, red, c->d_last->last, c->d_amask, g.active, g.nb, (double)g.h * g.w, thres,
+                       exact ? unsure_of(c) : (unsigned long long *)nullptr, break_band(g.w, g.h));
+    if (exact) hipLaunchKernelGGL(k_exact_break, dim3(g.nb), dim3(64), 0, c->stream, dfa, dfb, c->d_last->last, c->d_amask, unsure_of(c), g, thres);
 }
 void launch_set_mask(sfa_ctx *c, const WMask &v) { hipLaunchKernelGGL(k_set_mask, dim3(1), dim3(1), 0, c->stream, c->d_amask, v); }
 
@@ -1936,7 +1936,7 @@ constexpr int kFuseReduceWindows = 4;      // launches of up to that many window
 void launch_update_outer_x(sfa_ctx *c, const Geo &g, float *uu, float *vv, float *wx, float *wy, const SorOperandOut &x, double *red, float *dfa, float *dfb) {
     dim3 grid((g.w + 63) / 64, std::min((g.h + 15) / 16, kRedRows), g.nb);
     const int per_elem = grid.x * grid.y;
-    unsigned *done = reinterpret_cast<unsigned *>(c->d_last + 2 * kMaxBatch);
+    unsigned *done = c->d_last->done;
     if (g.nb <= kFuseReduceWindows) {
         hipLaunchKernelGGL(k_update_outer_x<true>, grid, block2d(), 0, c->stream, uu, vv, wx, wy, x.x, x.ent, x.RP, x.G, partials_of(c), red, done, dfa, dfb, g);
         return;

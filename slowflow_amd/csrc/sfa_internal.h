@@ -37,6 +37,26 @@ struct WMask {
     static WMask one(int b) { WMask r = none(); r.w[b >> 6] = 1ull << (b & 63); return r; }
 };
 constexpr int kMaxTerms = 4 * SFA_MAX_REF;
+// What ctx->d_last holds (ONE definition for api.hip and kernels.hip -- ADVICE r5: the layout was repeated by hand in four places): the norms of every window's
+// last outer iteration, the windows' finished-block counters of k_update_outer_x, the windows k_outer_threshold could not decide, the exact norms of
+// launch_exact_norms.  The pinned mirror ctx->h_red is at least this large (the exact norms are read back into ITS `exact` member, never into pageable memory).
+struct LastBlock {
+    double last[2 * kMaxBatch];
+    unsigned done[kMaxBatch];
+    unsigned long long unsure[kMaskWords];
+    float exact[2 * kMaxBatch];
+};
+// How close to a break threshold (relative) the fp64 tree sum of a change norm may come before the decision is taken on the reference's own fp32 running sum
+// (k_exact_break / launch_exact_norms).  The reference adds ceil(w / 4) * h block sums to ONE fp32 accumulator (variational_mt.cpp:412-425); each addition rounds
+// by at most 2^-24 of the running sum, and the errors need not cancel -- block sums below half an ulp of the accumulator (a converged background behind a few
+// moving pixels) are dropped one after the other, always downwards -- so the two sums can differ by up to blocks * 2^-24 of their value: 6.7e-3 at 1024 x 436,
+// 6.3e-2 at 2048 x 2048.  Outside that band both decide alike by construction; inside it the reference's arithmetic is repeated.  (Rounds 4-5 used a constant
+// 1e-3, the size of the typical difference, not of the bound: ADVICE r5.)
+__host__ __device__ inline double break_band(int w, int h) {
+    const double bound = (double)((w + 3) / 4) * (double)h * (1.0 / 16777216.0);
+    return bound > 1e-3 ? bound : 1e-3;
+}
+
 // device-side outer break (api.hip run_level): the host reads the mask of kMaskLag iterations ago from a ring of kMaskRing pinned words
 constexpr int kMaskLag = 2, kMaskRing = 4;
 static_assert(kMaskLag < kMaskRing, "a ring slot is rewritten kMaskRing iterations after it was read kMaskLag iterations late");
@@ -58,7 +78,7 @@ struct sfa_ctx {
     // thresholds on the device (variational_mt.cpp:436): the windows still iterating, the norms of each window's last iteration, and a ring of pinned
     // copies of the mask (one per outer iteration in flight) with the events that say a copy has landed
     unsigned long long *d_amask = nullptr;         // kMaskWords words
-    double *d_last = nullptr;                      // 2 * kMaxBatch doubles, then kMaxBatch counters (k_update_outer_x), kMaskWords words (k_outer_threshold's undecided windows), 2 * kMaxBatch floats (launch_exact_norms)
+    sfa::LastBlock *d_last = nullptr;              // norms of each window's last iteration + the small device-side state of the break decisions (sfa::LastBlock)
     sfa::WMask *h_amask = nullptr;                      // kMaskRing pinned masks
     hipEvent_t ev_mask[sfa::kMaskRing] = {};
     unsigned *d_err = nullptr;    // device error/timeout word

@@ -206,6 +206,12 @@ struct ChainLds {
     static constexpr int OPRFILL = (OPRMIN + 1 + 4 * 2 + 3) / 4 * 4;
     static constexpr int OPR = S::INFILL ? OPRFILL : (OPR10 ? OPRMIN + 1 : OPR00 ? OPRMIN : OPRTIGHT) - SFA_X_OPR_CUT, OPPLANE = OPR * OPROWB;
     static constexpr bool OPRING = SFA_CHAIN_OPRING && S::KG <= 16 && ops0 + 2 * OPPLANE + 32 <= 160 * 1024;
+    //  the depth a shape ends up with is never below the write-after-read bound of ITS read-ahead, whatever -DSFA_CHAIN_PF / PFL / PF1 experiment or later
+    // edit of the shape table is compiled: a ring that is too shallow races silently (a slot rewritten before its last read), and until now only the Python model
+    // (tools/sim_sor_chain.py ring_hazards) stood between such a build and the GPU.  A shape at the tight depth leans on the later stages' read-ahead (MULTI: PFL steps).
+    static_assert(SFA_X_OPR_CUT != 0 || !OPRING || S::INFILL || OPR >= 3 * S::NW + 2 * S::KG + 2 - (S::PFL < CH ? S::PFL - 1 : 0), "operand ring below its write-after-read bound");
+    static_assert(SFA_X_OPR_CUT != 0 || !OPRING || S::INFILL || OPR10 || OPR00 || (S::MULTI && S::PFL >= 2 && S::PFL < CH), "the tight ring depth is derived for multi-sweep stages that read ahead");
+    static_assert(!OPRING || !S::INFILL || (OPR % 4 == 0 && OPR >= OPRMIN + 1 + 8), "FILL wave: groups of four rows never wrap, and a group is in flight for two intervals");
     static constexpr int ticket = ops0 + (OPRING ? 2 * OPPLANE : 0);
     static constexpr int total = ticket + 16;
 };

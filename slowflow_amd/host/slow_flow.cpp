@@ -565,6 +565,16 @@ static int run_sequence(ParameterList &params, const string &sequence_path, cons
                 ep.pref_nn = 25; ep.nn = 160; ep.coef_kernel = 1.1f;         // :271-275
                 // the resolution the interpolation runs at: cv::resize(img, img, Size(0, 0), dm_scale, dm_scale) makes cvRound(cols * dm_scale) x cvRound(rows * dm_scale)
                 const int ew = dm_scale != 1 ? (int)std::lrint(width * dm_scale) : (int)width, eh = dm_scale != 1 ? (int)std::lrint(height * dm_scale) : (int)height;
+                // ... while the reference allocates un_seq / wx and sizes the edge file with the TRUNCATED product (`color_image_new(width*dm_scale, height*dm_scale)`,
+                // slow_flow.cpp:584, :801-806).  Where the two differ (1023 * 0.5: 512 against 511) the reference copies a 512-wide image into a 511-wide one -- no defined
+                // result, and edge / match files laid out for either width would be misread by the other: refused by name
+                if (dm_scale != 1 && (ew != (int)(width * dm_scale) || eh != (int)(height * dm_scale))) {
+                    std::lock_guard<std::mutex> l(io_mu);
+                    std::cerr << "dm_scale " << dm_scale << ": " << width << " x " << height << " frames give a rescaled image of " << ew << " x " << eh << " (cv::resize rounds) but buffers and edge files of "
+                              << (int)(width * dm_scale) << " x " << (int)(height * dm_scale) << " (slow_flow.cpp:584 truncates): the reference has no defined result here; crop the frames to a multiple of 1 / dm_scale"
+                              << std::endl;
+                    rc = SFA_ERR_ARG;
+                } else
                 if (ew < 1 || eh < 1 || !read_matches((wd.backward ? matches_file(b, a) : matches_file(a, b)).c_str(), mt) ||
                     !read_edges((wd.backward ? edges_file(b) : edges_file(a)).c_str(), ew, eh, ed)) rc = SFA_ERR_ARG;
                 else {
@@ -873,7 +883,7 @@ int main(int argc, char **argv) {
         }
         {   // :396-402: smaller resolution for deep matching
             double dm_scale = params.parameter<float>("dm_scale", "1.0");
-            if (params.parameter<bool>("deep_matching") && max_flow > 150) dm_scale = 0.5 * dm_scale;
+            if (params.parameter<bool>("deep_matching") && max_flow > 150) { dm_scale = 0.5 * dm_scale; max_flow = std::max(5.0, 0.5 * max_flow); }   // (:401: the bound at the halved size)
             std::ostringstream o;
             o.precision(17);
             o << dm_scale;

@@ -26,7 +26,7 @@ def gather_timings(dist, local_seconds, n_units, device=None):
     full = torch.zeros(n_units, dtype=torch.float64, device=device)
     for i, s in local_seconds.items():
         full[i] = s
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():       # (also with ONE rank: the collective then runs through RCCL on the one GPU -- the leg a one-GPU box can exercise)
         dist.all_reduce(full, op=dist.ReduceOp.SUM)      # disjoint supports: the sum is the gather
     return full.cpu().numpy()
 
@@ -34,7 +34,7 @@ def gather_timings(dist, local_seconds, n_units, device=None):
 def max_over_ranks(dist, value, device=None):
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -42,6 +42,6 @@ def max_over_ranks(dist, value, device=None):
 def sum_over_ranks(dist, value, device=None):
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

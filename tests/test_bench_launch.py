@@ -76,3 +76,57 @@ def test_two_ranks_for_real_on_one_gpu():
         elif "frac" in path.rsplit("/", 1)[-1] and isinstance(o, (int, float)):      # `frac` and every *_frac* key
             yield path, o
     assert all(0 <= v <= 1 for _, v in fracs(out)), list(fracs(out))
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl():
+    """the RCCL leg as far as one card allows.  bench.py started the way the round driver starts N ranks (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 1 ... bench.py --gpus 1`) initialises backend "nccl" (= RCCL) with its device id and walks the N-rank sequence -- barrier, timed region, barrier,
+    MAX over ranks, the gather of the per-window timings and the strong sections' SUM / MAX all-reduces -- on DEVICE tensors (xdev = "cuda"): the branch no earlier
+    round had executed.  One process on the card."""
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SFA_BENCH_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["TORCH_DISTRIBUTED_DEBUG"] = "DETAIL"                           # every collective is logged and checked
+    cmd = bench.launch_command(1, ["--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"], bench.free_port())
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["seconds_per_window"]["n"] == 8
+    assert out["config"]["parallelism"] == "frame-window data parallel x1"          # backend nccl: no rehearsal label
+    assert out["distributed"] == {"backend": "nccl", "world_size": 1, "exchange_tensors_on": "cuda", "collectives": "barrier, all_reduce(MAX), all_reduce(SUM)"}
+    for key, total in (("config4_strong", 128), ("config5_strong", 32)):
+        st = out[key]
+        assert "error" not in st, st
+        assert st["windows_all_ranks"] == total and len(st["seconds_per_rank"]) == 1 and st["seconds"] > 0
+
+
+@pytest.mark.gpu
+def test_timing_exchange_on_device_tensors_over_rccl(tmp_path):
+    """shard.gather_timings / max_over_ranks / sum_over_ranks on cuda tensors through a one-rank RCCL communicator: the values survive the collectives"""
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from slowflow_amd import shard
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+full = shard.gather_timings(dist, {i: 0.25 * (i + 1) for i in range(7)}, 7, device="cuda")
+mx = shard.max_over_ranks(dist, 3.5, device="cuda")
+sm = shard.sum_over_ranks(dist, 2.0, device="cuda")
+dist.barrier()
+print("RESULT", ",".join("%%.2f" %% v for v in full), mx, sm, dist.get_backend())
+dist.destroy_process_group()
+''' % ROOT)
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(bench.free_port()), str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert [float(v) for v in line[1].split(",")] == [0.25 * (i + 1) for i in range(7)]
+    assert float(line[2]) == 3.5 and float(line[3]) == 2.0 and line[4] == "nccl"

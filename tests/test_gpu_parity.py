@@ -226,11 +226,12 @@ def test_sor_golden(ctx, w, h):
 
 
 @pytest.mark.parametrize("nb,shape", [(1, "k_sor_chain<1,5,1,0,4,4,2,1,1"), (4, "k_sor_chain<1,5,1,0,4,4,2,1,1"), (8, "k_sor_chain<1,5,1,0,4,4,2,2,2"), (9, "k_sor_chain<1,5,1,0,4,4,2,2,2"), (10, "k_sor_chain<2,6,3,1,4,2,2,1,1"),
-                                      (16, "k_sor_chain<2,6,3,1"), (64, "k_sor_chain<2,6,3,1")])
+                                      (16, "k_sor_chain<2,6,3,1"), (64, "k_sor_chain<2,6,3,1"), (128, "k_sor_chain<2,6,3,1")])
 def test_default_solver_shape_and_its_bits(ctx, oracle, nb, shape):
     """what the library launches by default at 1024x436 x 30 (8 bands per system) for 1 ... 64 systems per launch -- the chain kernel with the operand ring at every
     batch size: five stages of one sweep up to 72 bands per launch (with one-interval poll / publication lags up to 32 bands), seven stages of 2,2,2,2,2,2,3 sweeps
-    on nine waves above (round 5; six stages of 3,3,3,2,2,2 in round 4) -- and that the first and the last system of the launch are the raster-order oracle's bits"""
+    on nine waves above (round 5; six stages of 3,3,3,2,2,2 in round 4) -- and that the first and the last system of the launch are the raster-order oracle's bits.
+    128 systems = the launch the bench times at level 0 (2 048 workgroups, both words of the window mask): also the two systems around the word boundary"""
     w, h, K = 1024, 436, 30
     rng = np.random.default_rng(100 + nb)
     systems = [sor_system(rng, w, h) for _ in range(2)]
@@ -242,7 +243,7 @@ def test_default_solver_shape_and_its_bits(ctx, oracle, nb, shape):
     kernel = ctx.profile_read_kernels()[3]
     ctx.profile_enable(False)
     assert kernel.startswith(shape), kernel
-    for b in sorted({0, nb - 1}):
+    for b in sorted({0, nb - 1} | ({63, 64} if nb > 64 else set())):
         a = copy_sys(systems[b % 2])
         oracle.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, K, 1.9)
         du, dv = sb.download(b)
@@ -492,7 +493,7 @@ def test_thresholds_break_like_the_oracle(ctx, oracle):
 @pytest.mark.parametrize("w,h", [(67, 45), (200, 150)])
 def test_break_decision_at_the_threshold_is_the_reference_arithmetic(ctx, oracle, switches, w, h):
     """VERDICT r4 "missing" 3: the reference decides the outer break on fp32 running sums in raster order (variational_mt.cpp:412-436), the GPU on fp64 tree sums -- which
-    can fall on the other side of a threshold that the norm all but touches.  Round 5: a window whose fp64 norm lies within 1e-3 of the threshold is decided by the
+    can fall on the other side of a threshold that the norm all but touches.  Round 5: a window whose fp64 norm lies within the band (1e-3 at these sizes) of the threshold is decided by the
     reference's own summation (k_exact_break).  The sharpest case there is: the threshold set to the oracle's own fp32 norm of outer iteration k (then `norm < thres` is
     false there and the run goes on) and to the next float above it (true: the run stops at k) -- both sides stop where the oracle stops and report the oracle's norm bit
     for bit; with the exact decision switched off (SFA_NO_EXACT_BREAK) the norms agree only to the fp64 / fp32 difference"""
@@ -534,6 +535,40 @@ def test_break_decision_at_the_threshold_is_the_reference_arithmetic(ctx, oracle
     po, ps = mk_params(oracle, thres_outer=float(m), **kw)
     o, g = run_both(ctx, oracle, po, ps, frames, w, h)
     assert abs(g[2][0] - o[2][0]) <= 2e-4 * abs(o[2][0]) or abs(g[2][0] - outer[k][1]) <= 2e-4 * abs(outer[k][1])      # either side of the threshold, to the sums' difference
+
+
+def test_break_band_follows_the_image_size(ctx, oracle):
+    """how far the reference's fp32 running sum of a change norm can lie from the fp64 sum grows with the number of additions -- ceil(w / 4) * h * 2^-24 of
+    its value, 6.7e-3 at 1024 x 436 -- and need not average out (small block sums dropped one after the other, always downwards).  The band inside which the break is
+    decided on the reference's own summation is that bound since round 6 (sfa_internal.h: break_band; a constant 1e-3 before).  At 1024 x 436 a threshold 3e-3 above the
+    oracle's norm of outer iteration k -- outside the old band, inside the new one -- is decided by k_exact_break: the GPU stops at k like the oracle AND reports the
+    oracle's fp32 norms bit for bit (the fp64 sums would differ in their last digits); a threshold 3e-2 above is outside the band: same stop, norms to the sums' difference"""
+    w, h = 1024, 436
+    frames, af, sf = normalized_frames(oracle, w, h, 3, seed=21)
+    kw = dict(S=2, rho=[1], omega=[0], norm_avg=af, norm_std=sf, niter_outer=6, thres_inner=1e-9)
+    po, ps = mk_params(oracle, thres_outer=0, **kw)
+    oracle.change_log(64)
+    wxo, wyo = orc.plane(h, orc.stride_of(w)), orc.plane(h, orc.stride_of(w))
+    rc, _, _ = oracle.compute_one_level(po, wxo, wyo, frames, w)
+    rows = oracle.change_log_rows().copy()
+    oracle.change_log(0)
+    outer = [(float(max(np.float32(a), np.float32(b))), np.float32(a), np.float32(b)) for kind, it, a, b in rows if kind == 1]
+    assert rc == 0 and len(outer) == 6
+    # the first iteration k whose norm lies clearly below every earlier one: every threshold used below is then met at k and nowhere before
+    ks = [i for i in range(1, 6) if all(outer[j][0] > 1.1 * outer[i][0] for j in range(i))]
+    assert ks, [o[0] for o in outer]
+    k = ks[0]
+    for rel, exact in ((3e-3, True), (3e-2, False)):
+        thres = np.float32(outer[k][0] * (1.0 + rel))
+        po, ps = mk_params(oracle, thres_outer=float(thres), **kw)
+        o, g = run_both(ctx, oracle, po, ps, frames, w, h)
+        assert np.float32(o[2][0]) == outer[k][1] and np.float32(o[2][1]) == outer[k][2]                     # the oracle stopped at k
+        if exact:
+            assert np.float32(g[2][0]) == outer[k][1] and np.float32(g[2][1]) == outer[k][2], (rel, g[2], outer[k])
+        else:
+            assert abs(g[2][0] - o[2][0]) <= 1e-4 * abs(o[2][0]) and abs(g[2][1] - o[2][1]) <= 1e-4 * abs(o[2][1]), (rel, g[2], o[2])
+        d = max(np.abs(valid(o[0], w) - valid(g[0], w)).max(), np.abs(valid(o[1], w) - valid(g[1], w)).max())
+        assert d <= TOL_LEVEL, (rel, d)
 
 
 def test_inner_break_decision_at_the_threshold_is_the_reference_arithmetic(ctx, oracle):
@@ -650,14 +685,34 @@ def test_job_batch_equals_single(ctx, oracle):
 
 
 def test_normalize(ctx, oracle):
+    """normalize() (variational_mt.cpp:17-85).  The reference sums I and the fp32 product I*I in fp64 in raster order; the GPU forms the same fp64 terms and adds them as
+    a tree.  (1) For what the path is actually fed -- 8- and 16-bit pixel values, as every image file delivers them -- each term and each partial sum is an integer below
+    2^53, fp64 addition is exact whatever its order, and statistics AND frames are the reference's to the last bit: asserted with ==.  (2) For arbitrary fp32 input the two
+    summation orders round differently (~1e-13 relative on the statistics); the normalised pixel is a double expression stored to float on both sides, so a pixel whose
+    exact value lies within 1e-13 of a rounding boundary can come out one ulp apart -- rare, and the only way to remove it would be a sequential sum on the GPU.  That
+    case keeps the 1-ulp bound, counted in ulps."""
     w, h = 67, 45
+    rng = np.random.default_rng(3)
+    for top in (255, 65535):
+        fo = []
+        for k in range(5):
+            f = orc.aligned_zeros((3, h, orc.stride_of(w)))
+            f[:, :, :w] = rng.integers(0, top + 1, size=(3, h, w)).astype(np.float32)
+            fo.append(f)
+        fg = [c_(f).copy() for f in fo]
+        avg_o, std_o, _, _ = oracle.normalize(fo, w)
+        avg_g, std_g = ctx.normalize(fg, w)
+        assert list(avg_o) == list(avg_g) and list(std_o) == list(std_g), top
+        for a, b in zip(fo, fg):
+            assert np.array_equal(valid(a, w), valid(b, w)), top
     fo = [texture_frame(w, h, k) for k in range(3)]
     fg = [c_(f).copy() for f in fo]
     avg_o, std_o, _, _ = oracle.normalize(fo, w)
     avg_g, std_g = ctx.normalize(fg, w)
-    assert np.allclose(avg_o, avg_g, rtol=1e-12) and np.allclose(std_o, std_g, rtol=1e-10)
+    assert np.allclose(avg_o, avg_g, rtol=1e-12, atol=0) and np.allclose(std_o, std_g, rtol=1e-12, atol=0)
     for a, b in zip(fo, fg):
-        assert np.max(np.abs(valid(a, w) - valid(b, w))) <= 7e-5      # |I| ~ 700: 1 ulp = 6e-5
+        ulp = np.abs(valid(a, w).view(np.int32).astype(np.int64) - valid(b, w).view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1 and (ulp > 0).mean() < 1e-3
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -1086,6 +1141,54 @@ def test_full_batch_of_128_with_thresholds(ctx, oracle):
         job.close()
     with pytest.raises(sfa.SlowflowError):
         sfa.Job(ctx, ps, w, h, 129)
+
+
+def test_bench_job_128_windows_against_the_oracle(ctx, oracle):
+    """THE TIMED GEOMETRY: what bench.py times is one lockstep group of 128 windows of 1024x436, 5 levels, 5 outer x 30 sweeps
+    -- both words of the window mask, 2 048 solver workgroups at level 0 on the seven-stage shape, the path of more than four windows (k_update_outer_x<false> +
+    k_reduce_partials).  Built from bench.py's own workload (synth_window, bench_params, the sequence statistics at six digits): (1) windows 0, 63, 64 and 127 of
+    the 128-window job against oracle.variational on the same normalised frames, <= 1e-4 (north_star); (2) EVERY window of the job bit for bit what the same windows
+    give as two jobs of 64 -- the geometry every full-size oracle comparison of rounds 1-5 ran at or below."""
+    import bench
+    w, h, nb = bench.W, bench.H, 128
+    distinct = 12
+    wins = [bench.synth_window(1000 + b) for b in range(distinct)]
+    pick = lambda b: {0: 0, 63: 1, 64: 2, 127: 3}.get(b, 4 + b % (distinct - 4))
+    avg, std = ctx.normalize([f for wdw in wins for f in wdw], w)
+    ps = bench.bench_params()
+    po = oracle.default_params()
+    for p in (ps, po):
+        p.S = bench.S; p.layers = bench.LAYERS; p.niter_alter = 1; p.niter_outer = bench.OUTER; p.niter_inner = bench.INNER; p.niter_solver = bench.SWEEPS
+        p.thres_outer = 0; p.thres_inner = 0; p.occlusion_reasoning = 0; p.hbit = 0; p.rho[0] = 1; p.omega[0] = 0
+        for k in range(3):
+            p.norm_avg[k] = float("%g" % avg[k]); p.norm_std[k] = float("%g" % std[k])
+    job = sfa.Job(ctx, ps, w, h, nb)
+    for b in range(nb):
+        job.upload(b, wins[pick(b)])
+    job.run(); job.run()                                                  # the bench re-runs its resident job: the second pass is what it times
+    got = [job.download(b) for b in range(nb)]
+    job.close()
+    for half in (0, 1):
+        j64 = sfa.Job(ctx, ps, w, h, 64)
+        for b in range(64):
+            j64.upload(b, wins[pick(64 * half + b)])
+        j64.run()
+        for b in range(64):
+            gx, gy, chg = j64.download(b)
+            assert np.array_equal(gx, got[64 * half + b][0]) and np.array_equal(gy, got[64 * half + b][1]) and chg == got[64 * half + b][2], (half, b)
+        j64.close()
+    stride = orc.stride_of(w)
+    for b in (0, 63, 64, 127):
+        fr = []
+        for f in wins[pick(b)]:
+            a = orc.aligned_zeros(f.shape); a[...] = f
+            fr.append(a)
+        wxo, wyo = orc.plane(h, stride), orc.plane(h, stride)
+        rc, _ = oracle.variational(po, wxo, wyo, fr, w)
+        assert rc == 0
+        d = max(np.abs(valid(wxo, w) - valid(got[b][0], w)).max(), np.abs(valid(wyo, w) - valid(got[b][1], w)).max())
+        assert d <= TOL_UV, (b, d)
+        assert abs(np.median(valid(got[b][0], w)) - 2.0) < 0.5              # and the synthetic sequence's motion (2 +- 1 px in x) was found
 
 
 def test_solver_batch_beyond_one_mask_word(ctx, oracle):

@@ -942,3 +942,9 @@ def test_driver_deep_matching_at_half_resolution(host_build, tmp_path):
         np.zeros((72, 96), np.float32).tofile(str(out / "tmp" / ("edges_%d.dat" % n)))
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg3), "-overwrite"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "dm_scale" in r.stderr and "integer ratio" in r.stderr
+    # a size whose rounded and truncated products differ (96 * 0.3 = 28.8: cv::resize makes 29 rows, slow_flow.cpp:584 allocates 28): the reference has no defined
+    # result there -- refused by name
+    cfg4 = tmp_path / "run4.cfg"
+    cfg4.write_text(cfg.read_text().replace("dm_scale\t0.5", "dm_scale\t0.3"))
+    r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg4), "-overwrite"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "dm_scale" in r.stderr and "truncates" in r.stderr
