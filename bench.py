@@ -116,6 +116,69 @@ def sor_valu_per_wave(kernel):
     return None, None
 
 
+def valu_model():
+    """profiles/<tag>_valu_model.json of the newest round that has one (tools/valu_time_model.py: the VALU mix of the solver's stages and of the assembly kernel from
+    their ISA, priced with the measured pass costs of tools/ubench/valu_rates.hip)"""
+    for tag in ("r06",):
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_valu_model.json")) as f:
+                return json.load(f), "profiles/%s_valu_model.json" % tag
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def solver_valu_floor(kernel, nb):
+    """VALU-time floor of the mean solver launch of the bench workload (one launch per level and outer iteration, nb windows each): for every level the launch's
+    workgroups / 256 CUs x the VALU cycles the BUSIEST SIMD of a workgroup needs over the workgroup's life (its waves' instruction mix x the measured pass costs; a
+    SIMD executes one VALU instruction at a time whichever wave it comes from) / clock -- the time the launch would take if that SIMD never waited.  Also the mean
+    over the four SIMDs.  Returns (seconds busiest, seconds mean, per-SIMD cycles per step at level 0, source) or None when the model has no such shape."""
+    model, src = valu_model()
+    if not model:
+        return None
+    k = kernel.replace(" ", "")
+    m = next((v for name, v in model["solver"].items() if k.startswith(name.replace(" ", ""))), None)
+    if not m:
+        return None
+    sh = m["shape"]
+    KG, NW, CH, FA, NA, FB = sh["KG"], sh["NW"], sh["CH"], sh["FA"], sh["NA"], sh["FB"]
+    if SWEEPS % KG:
+        return None
+    FMAX, AH = max(FA, FB if sh["NB"] else FA), 2
+    LEAD, shift = AH + 1, (2 if KG <= 10 else 4)                          # sor_chain.hip: chain_start_shift (every default shape has an operand ring)
+    cyc = {}
+    for st in m["stages"]:
+        cyc[(st["F"], st["role"].startswith("first"))] = st["valu_cycles_per_step"]
+
+    def stage_cycles(F, first):
+        return cyc.get((F, first), cyc.get((F, False)))
+    io = {who: v["valu_cycles_per_interval"] for who, v in m["io_waves"].items()}
+    ws, hs = sfa.pyramid_sizes(W, H, LAYERS, np.float32(0.9))
+    rnd = lambda a, b: (a + b - 1) // b * b
+    busiest = mean = 0.0
+    per_step0 = None
+    for w_, h_ in zip(ws, hs):
+        NB = (h_ + SWEEPS - 1 + 63) // 64
+        NCH = rnd((w_ + 64 + KG - NW + 2 * CH + FMAX + CH - 1) // CH + shift, 4)          # sor.hip: chunks per stage
+        NI = rnd(NCH + LEAD + NW + 2, AH)                                                    # barrier intervals per workgroup
+        simd = []
+        for roles in m["simd_placement"]:
+            c = 0.0
+            for r in roles:
+                if r in io:
+                    c += io[r] * NI
+                elif r.startswith("stage"):
+                    idx, F = int(r.split()[1]), int(r.split("F=")[1].rstrip(")"))
+                    c += stage_cycles(F, idx == 0) * NCH * CH
+            simd.append(c)
+        if per_step0 is None:
+            per_step0 = [round(c / (NCH * CH), 1) for c in simd]
+        nwg = nb * NB * (SWEEPS // KG)
+        busiest += nwg / 256.0 * max(simd) / (CLOCK_GHZ * 1e9)
+        mean += nwg / 256.0 * (sum(simd) / 4.0) / (CLOCK_GHZ * 1e9)
+    return busiest / len(ws), mean / len(ws), per_step0, src
+
+
 def synth_window(seed, w=W, h=H, n=3):
     """Config-2 stand-in: seeded band-limited noise texture moved by a smooth flow field of at most
     3 px per frame, 8-bit quantised; returns n (3,h,stride) fp32 frames."""
@@ -820,6 +883,20 @@ def main():
             # how the ranks met (None: a lone process without torch.distributed)
             "distributed": ({"backend": backend, "world_size": world, "exchange_tensors_on": xdev, "collectives": "barrier, all_reduce(MAX), all_reduce(SUM)"} if dist is not None else None),
         }
+        # the roof that BINDS: the VALU time of the busiest SIMD.  `bound` names it for the batch that ran; the HBM figures above stay as they are
+        vf = solver_valu_floor(sor_kernel, BL) if n_sor else None
+        if vf and avg_launch_s > 0:
+            out["roofline"]["valu_time_floor_frac"] = round(vf[0] / avg_launch_s, 4)
+            out["roofline"]["valu_time_floor_frac_mean_simd"] = round(vf[1] / avg_launch_s, 4)
+            out["roofline"]["valu_time_floor_ms"] = round(vf[0] * 1e3, 4)
+            out["roofline"]["valu_cycles_per_step_by_simd"] = vf[2]
+            out["roofline"]["valu_time_floor_note"] = ("mean over the 5 levels of: workgroups / 256 CUs x VALU cycles of the busiest SIMD of a workgroup (its waves' ISA mix x the measured pass costs: "
+                                                        "v_pk_*_f32 and DPP moves 4.4 cycles, plain VALU 2.3; %s, tools/valu_time_model.py) / %.1f GHz, over the live launch duration -- 1.0 = that "
+                                                        "SIMD never waits; `_mean_simd`: the same with the mean of the four SIMDs" % (vf[3], CLOCK_GHZ))
+            if BL >= 16:
+                out["roofline"]["bound"] = "valu"
+                out["roofline"]["bound_note"] = ("the roof that binds at %d windows per launch is the VALU time of the busiest SIMD (`valu_time_floor_frac`); achieved / peak / frac / traffic are the "
+                                                 "HBM figures the contract asks for (bytes the fused solve has to move / duration / 8 TB/s) and are not what limits the kernel" % BL)
         vpw, vpw_src = sor_valu_per_wave(sor_kernel)
         if vpw and n_sor:
             # VALU issue floor of the solver: instructions per wave (SQ counters) x waves of the mean launch x 2 cycles per wave64 instruction on a SIMD-32
@@ -868,10 +945,20 @@ def main():
                                         # the SIMDs' own view from the same counter pass: SQ_ACTIVE_INST_VALU x 4 / SIMD cycles when the kernel runs alone.  The counter
                                         # charges a quad-cycle (4 cycles) per wave instruction where the SIMD-32 needs 2, so it reads about twice the issue-slot use
                                         # (six waves per SIMD: the raw ratio passes 1 -- carried as a ratio, and halved as the issue-slot use at 2 cycles per instruction)
+                                        "valu_time_floor_frac": None,
                                         "valu_quadcycle_ratio_alone": valu_active,
                                         "valu_issue_slot_frac_alone": (round(valu_active / 2.0, 4) if valu_active else None),
                                         "share_of_step": round(asm_ms / S / (elapsed * 1e3), 4),
                                         "note": "launch durations are those inside the timed region, where the other stream's kernels share the GPU (alone: about half)"}
+            vm, vm_src = valu_model()
+            if vm and ach:
+                inst = vm["assemble"].get("k_assemble_images<8,512,6,true,1,true>")      # the instance the bench's first (and only) inner iteration runs: du = dv = 0, cfg defaults folded in
+                if inst:
+                    cpi = inst["cycles_per_valu_instruction_term_loop"]
+                    out["roofline_assemble"]["valu_time_floor_frac"] = round(ach * cpi / (256 * 4 * CLOCK_GHZ * 1e9), 4)
+                    out["roofline_assemble"]["valu_time_floor_note"] = ("dynamic VALU instructions (SQ counters) x %.3f cycles per instruction of the term loop's static mix (%s: plain 2.3, "
+                                                                        "v_rcp / v_sqrt 4.6; no packed operations in this kernel) / (1024 SIMDs x %.1f GHz) over the live launch durations; "
+                                                                        "`frac` prices an instruction at the guide's 2 cycles" % (cpi, vm_src, CLOCK_GHZ))
         if strong is not None:
             out["config4_strong"] = strong
         if strong5 is not None:

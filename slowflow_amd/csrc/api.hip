@@ -16,7 +16,10 @@ namespace sfa {
 thread_local std::string g_thread_err;
 
 // ---- the process-wide switch record (sfa_internal.h) ----------------------------------------------------------------
+#ifndef SFA_RELEASE
 Switches g_switches;
+#endif
+#ifndef SFA_RELEASE
 static const char *const kSwitchNames[Switches::N] = {
     "SFA_SOR_CHAIN", "SFA_SOR_BAND", "SFA_SOR_F", "SFA_SOR_CH", "SFA_SOR_LEAD", "SFA_CHAIN_LDS", "SFA_RB_TILE", "SFA_WARP_ALLJ", "SFA_NO_WARP_SMOOTH",
     "SFA_ASSEMBLE_GENERIC", "SFA_EXACT_DIV", "SFA_ASM_XCD", "SFA_NO_DIRECT_OPERANDS", "SFA_NO_UV_ALIAS", "SFA_DEBUG_ACTIVE", "SFA_UNFUSED", "SFA_SHARE_SOR",
@@ -41,6 +44,9 @@ static void switches_from_environment() {
             if (const char *e = getenv(kSwitchNames[i])) (void)set_switch(kSwitchNames[i], e);
     });
 }
+#else
+static void switches_from_environment() {}      // (release build: there are no switches, sfa_internal.h)
+#endif
 
 int set_error(sfa_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
@@ -627,9 +633,14 @@ int sfa_profile_read(sfa_ctx *c, int *n, double *ms_total, double *bytes_total) 
 }
 int sfa_debug_set(const char *name, const char *value) {
     if (!name) return set_error(nullptr, SFA_ERR_ARG, "sfa_debug_set: null name");
+#ifdef SFA_RELEASE
+    (void)value;
+    return set_error(nullptr, SFA_ERR_ARG, "sfa_debug_set('%s'): this is the release build of the library -- it has no cross-check / what-if paths (build the full library: make -C slowflow_amd/csrc)", name);
+#else
     switches_from_environment();                    // so that a later first sfa_ctx_create cannot overwrite what is set here
     if (set_switch(name, value) != SFA_OK) return set_error(nullptr, SFA_ERR_ARG, "sfa_debug_set: unknown switch '%s'", name);
     return SFA_OK;
+#endif
 }
 int sfa_ctx_set_verbose(sfa_ctx *c, int on) {
     if (!c) return SFA_ERR_ARG;

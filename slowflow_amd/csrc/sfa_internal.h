@@ -121,9 +121,24 @@ struct Switches {
     bool given[N] = {};
     int value[N] = {};
 };
+// code of the full build only
+#ifdef SFA_RELEASE
+#define SFA_FULL(...)
+#else
+#define SFA_FULL(...) __VA_ARGS__
+#endif
+#ifdef SFA_RELEASE
+// RELEASE BUILD (make -C slowflow_amd/csrc release -> build_release/libslowflow_amd.so): no switch exists -- every cross-check / what-if branch
+// is dead code the compiler removes, the environment is never read (not even behind SFA_DEBUG=1), sfa_debug_set refuses by name, and only the solver shapes the
+// library picks by default are compiled (sor_chain.hip: 2,2,2,2,2,2,3 / 1 x 5 with either lag pair; sor.hip: the task kernel as the one fallback for sweep counts
+// no chain shape divides).  Same C-ABI, same results as the full build's defaults; the tests run the full build.
+constexpr bool sw_given(Switches::Id) { return false; }
+constexpr int sw_int(Switches::Id, int dflt) { return dflt; }
+#else
 extern Switches g_switches;
 inline bool sw_given(Switches::Id i) { return g_switches.given[i]; }                                   // what `getenv(name) != nullptr` used to say
 inline int sw_int(Switches::Id i, int dflt) { return g_switches.given[i] ? g_switches.value[i] : dflt; }   // `getenv(name) ? atoi(getenv(name)) : dflt`
+#endif
 
 #define SFA_HIP(ctx, call)                                                                         \
     do {                                                                                           \

@@ -899,12 +899,15 @@ int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float
     const bool prof = c->profile && c->ev_used + 2 <= c->ev.size();
     if (prof) (void)hipEventRecord(c->ev[c->ev_used], c->stream);
     const int mode = sw_int(Switches::RB_TILE, 5);      // sweeps per tile visit (3 or 5); 0: one launch per colour pass (the round-2 form)
+#ifndef SFA_RELEASE
     if (mode == 0) {
         const dim3 grid((g.w + 127) / 128, (g.h + 3) / 4, g.nb);
         for (int k = 0; k < K; k++)
             for (int color = 0; color < 2; color++)
                 hipLaunchKernelGGL(k_rb_pass, grid, blk, 0, c->stream, du, dv, a11, a12, a22, b1, b2, sh, sv, g, color, omega);
-    } else {
+    } else
+#endif
+    {
         const int T = mode == 3 ? 3 : 5;
         const long pl = (long)g.pitch * g.h;
         const size_t need = (size_t)2 * g.nb * pl * sizeof(float);
@@ -923,8 +926,11 @@ int sor_rb_run(sfa_ctx *c, const Geo &g, float *du, float *dv, float *a11, float
             const float *iu = in_tmp ? tu : du, *iv = in_tmp ? tv : dv;
             float *ou = in_tmp ? du : tu, *ov = in_tmp ? dv : tv;
             const long ei = in_tmp ? pl : g.es, eo = in_tmp ? g.es : pl;
+#ifndef SFA_RELEASE
             if (T == 3) hipLaunchKernelGGL((k_rb_tile<3>), grid, dim3(256), 0, c->stream, iu, iv, ei, g.pitch, ou, ov, eo, g.pitch, a11, a12, a22, b1, b2, sh, sv, g, ns, omega);
-            else        hipLaunchKernelGGL((k_rb_tile<5>), grid, dim3(256), 0, c->stream, iu, iv, ei, g.pitch, ou, ov, eo, g.pitch, a11, a12, a22, b1, b2, sh, sv, g, ns, omega);
+            else
+#endif
+                        hipLaunchKernelGGL((k_rb_tile<5>), grid, dim3(256), 0, c->stream, iu, iv, ei, g.pitch, ou, ov, eo, g.pitch, a11, a12, a22, b1, b2, sh, sv, g, ns, omega);
             in_tmp = !in_tmp;
         }
         if (in_tmp) {                                                                     // an odd number of visits: the result comes home
@@ -984,6 +990,10 @@ static int chain_choice(int K, int nb, int NBands) {
 }
 // band kernel (all K sweeps of a band in one workgroup): F fused sweeps per wave, NW = K/F waves; 0 = not applicable
 static int band_shape(int K, int nb) {
+#ifdef SFA_RELEASE
+    (void)K; (void)nb;
+    return 0;                                                 // release build: the task kernel is the one fallback (the band kernels are not compiled)
+#endif
     // default: batches (>= 8 systems in lockstep: the two kernels tie at 8, and the band kernel leaves most CUs to a second stream) take
     // the band kernel, single solves the task kernel whose K stages
     // spread over K CUs (shorter critical path); SFA_SOR_BAND = 0 (never) / 1..3 (always, that many fused sweeps)
@@ -1172,7 +1182,9 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
     else snprintf(c->sor_kernel, sizeof c->sor_kernel, "k_sor_solve<%d,%d>", ws.F, ws.CHK);
     if (ws.chain) {
         SFA_TRY(sor_chain_launch(c, ws, g, K, omega));
-    } else if (ws.band) {
+    }
+#ifndef SFA_RELEASE
+    else if (ws.band) {
         BandArgs ba;
         ba.sa = p.sa; ba.sb = p.sb; ba.x = p.x; ba.edge = (unsigned long long *)ws.edge.p; ba.gflags = p.flags; ba.err = c->d_err;
         ba.ent = ws.ent; ba.edge_job = ws.edge_job; ba.W = g.w; ba.H = g.h; ba.K = K; ba.NB = ws.NB; ba.NW = ws.NG; ba.RP = ws.RP; ba.G = ws.G;
@@ -1190,13 +1202,17 @@ static int sor_launch_solve(sfa_ctx *c, SorWorkspace &ws, const Geo &g, float *d
         else if (ws.F == 3) hipLaunchKernelGGL((k_sor_band<3, 10, band_ch(3), band_mc(3), 16>), bgrid, bblock, lds, c->stream, ba);
         else if (ws.F == 2) hipLaunchKernelGGL((k_sor_band<2, 16, band_ch(2), band_mc(2), 8>), bgrid, bblock, lds, c->stream, ba);
         else                hipLaunchKernelGGL((k_sor_band<1, 16, band_ch(1), band_mc(1), 16>), bgrid, bblock, lds, c->stream, ba);
-    } else {
+    }
+#endif
+    else {
     const dim3 sgrid(g.nb * ws.ntasks), sblock(64);
+    // (release build: sor_shape's two defaults -- one sweep per wave in chunks of 16 for few waves, two in chunks of 8 for many)
     if (ws.F == 1 && ws.CHK == 16)      hipLaunchKernelGGL((k_sor_solve<1, 16>), sgrid, sblock, 0, c->stream, a);
-    else if (ws.F == 1)                 hipLaunchKernelGGL((k_sor_solve<1, 8>), sgrid, sblock, 0, c->stream, a);
+    SFA_FULL(else if (ws.F == 1)                 hipLaunchKernelGGL((k_sor_solve<1, 8>), sgrid, sblock, 0, c->stream, a);)
     else if (ws.F == 2 && ws.CHK == 8)  hipLaunchKernelGGL((k_sor_solve<2, 8>), sgrid, sblock, 0, c->stream, a);
-    else if (ws.F == 2)                 hipLaunchKernelGGL((k_sor_solve<2, 4>), sgrid, sblock, 0, c->stream, a);
-    else                                hipLaunchKernelGGL((k_sor_solve<3, 4>), sgrid, sblock, 0, c->stream, a);
+    SFA_FULL(else if (ws.F == 2)                 hipLaunchKernelGGL((k_sor_solve<2, 4>), sgrid, sblock, 0, c->stream, a);)
+    SFA_FULL(else if (ws.F == 3)                 hipLaunchKernelGGL((k_sor_solve<3, 4>), sgrid, sblock, 0, c->stream, a);)
+    else return set_error(c, SFA_ERR_ARG, "sor_launch_solve: no task kernel of %d sweeps per wave in chunks of %d in this build", ws.F, ws.CHK);
     }
     if (prof) {
         (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);

@@ -1005,21 +1005,23 @@ constexpr int kChainCH = 4, kChainAH = SFA_CHAIN_AH, kChainPL = SFA_CHAIN_PL, kC
 // trade latency against stalls: 2 / 2 everywhere until round 4; 1 / 1 for the lone-solve shape (one window 276 -> 265 us) and the six-stage shape (64 windows 1398 -> 1379 us,
 // 16: 529 -> 514), NOT for 1 x 5 at 8-12 windows (+2 .. +12 %): id 16 is 1 x 5 with 1 / 1 and serves launches of up to 32 bands.
 struct ChainShapeInfo { int id, FA, NA, FB, NB_, PD, PL, PUBD; };
+// SFA_RELEASE (sfa_internal.h): only the shapes the library picks by default are compiled -- 14 from 73 bands per launch on, 6 / 16 below (sor.hip chain_choice; sweep
+// counts that 5 does not divide take the task kernel)
 static const ChainShapeInfo kChainShapes[] = {
-    {1, 1, 3, 1, 0, 4, 2, 2},      // 3 stages of 1 sweep            KG = 3
-    {2, 2, 3, 2, 0, 2, 2, 2},      // 3 stages of 2                  KG = 6
-    {3, 3, 5, 3, 0, 2, 2, 2},      // 5 stages of 3                  KG = 15
-    {5, 2, 5, 2, 0, 2, 2, 2},      // 5 stages of 2                  KG = 10
+    SFA_FULL({1, 1, 3, 1, 0, 4, 2, 2},)      // 3 stages of 1 sweep            KG = 3
+    SFA_FULL({2, 2, 3, 2, 0, 2, 2, 2},)      // 3 stages of 2                  KG = 6
+    SFA_FULL({3, 3, 5, 3, 0, 2, 2, 2},)      // 5 stages of 3                  KG = 15
+    SFA_FULL({5, 2, 5, 2, 0, 2, 2, 2},)      // 5 stages of 2                  KG = 10
     {6, 1, 5, 1, 0, 4, 2, 2},      // 5 stages of 1                  KG = 5
-    {8, 3, 2, 3, 0, 2, 2, 2},      // 2 stages of 3                  KG = 6
-    {9, 5, 6, 5, 0, 2, 2, 2},      // 6 stages of 5                  KG = 30: a whole band per workgroup (large batches)
-    {10, 3, 10, 3, 0, 2, 2, 2},    // 10 stages of 3                 KG = 30
-    {11, 3, 3, 2, 3, 2, 1, 1},     // 3 stages of 3 + 3 of 2         KG = 15: with the I/O waves 8 waves, two per SIMD, at most 5 sweeps on a SIMD (5 x 3: 6)
-    {12, 2, 3, 3, 3, 2, 2, 2},     // 3 stages of 2 + 3 of 3         KG = 15
-    {13, 3, 1, 2, 6, 2, 1, 1},     // 1 stage of 3 + 6 of 2          KG = 15: nine waves, at most 4 sweeps on a SIMD (ChainShape::stage_of_wave)
+    SFA_FULL({8, 3, 2, 3, 0, 2, 2, 2},)      // 2 stages of 3                  KG = 6
+    SFA_FULL({9, 5, 6, 5, 0, 2, 2, 2},)      // 6 stages of 5                  KG = 30: a whole band per workgroup (large batches)
+    SFA_FULL({10, 3, 10, 3, 0, 2, 2, 2},)    // 10 stages of 3                 KG = 30
+    SFA_FULL({11, 3, 3, 2, 3, 2, 1, 1},)     // 3 stages of 3 + 3 of 2         KG = 15: with the I/O waves 8 waves, two per SIMD, at most 5 sweeps on a SIMD (5 x 3: 6)
+    SFA_FULL({12, 2, 3, 3, 3, 2, 2, 2},)     // 3 stages of 2 + 3 of 3         KG = 15
+    SFA_FULL({13, 3, 1, 2, 6, 2, 1, 1},)     // 1 stage of 3 + 6 of 2          KG = 15: nine waves, at most 4 sweeps on a SIMD (ChainShape::stage_of_wave)
     {16, 1, 5, 1, 0, 4, 1, 1},     // 5 stages of 1, one-interval poll / publication lags: the lone solve
-    {17, 1, 3, 1, 0, 4, 1, 1},     // 3 stages of 1 with the same lags: every compute wave alone on its SIMD, ten groups per band
-    {19, 1, 6, 1, 0, 4, 1, 1},     // 6 stages of 1: five groups per band
+    SFA_FULL({17, 1, 3, 1, 0, 4, 1, 1},)     // 3 stages of 1 with the same lags: every compute wave alone on its SIMD, ten groups per band
+    SFA_FULL({19, 1, 6, 1, 0, 4, 1, 1},)     // 6 stages of 1: five groups per band
     {14, 2, 6, 3, 1, 2, 1, 1},     // 6 stages of 2 + 1 of 3         KG = 15: nine waves, the last stage beside the I/O waves (ChainShape::PERM9L)
 };
 
@@ -1052,20 +1054,20 @@ void chain_kernel_name(int id, int NG, char *buf, size_t n) {
 template <int FA, int NA, int FB, int NB_> static int shape_shift() { using S = ChainShape<FA, NA, FB, NB_>; return ChainLds<S, kChainCH>::OPRING ? chain_start_shift(S::KG) : 0; }
 int chain_shift(int id) {
     switch (id) {
-        case 1: return shape_shift<1, 3, 1, 0>();
-        case 2: return shape_shift<2, 3, 2, 0>();
-        case 3: return shape_shift<3, 5, 3, 0>();
-        case 5: return shape_shift<2, 5, 2, 0>();
+        SFA_FULL(case 1: return shape_shift<1, 3, 1, 0>();)
+        SFA_FULL(case 2: return shape_shift<2, 3, 2, 0>();)
+        SFA_FULL(case 3: return shape_shift<3, 5, 3, 0>();)
+        SFA_FULL(case 5: return shape_shift<2, 5, 2, 0>();)
         case 6: return shape_shift<1, 5, 1, 0>();
-        case 8: return shape_shift<3, 2, 3, 0>();
-        case 9: return shape_shift<5, 6, 5, 0>();
-        case 10: return shape_shift<3, 10, 3, 0>();
-        case 11: return shape_shift<3, 3, 2, 3>();
+        SFA_FULL(case 8: return shape_shift<3, 2, 3, 0>();)
+        SFA_FULL(case 9: return shape_shift<5, 6, 5, 0>();)
+        SFA_FULL(case 10: return shape_shift<3, 10, 3, 0>();)
+        SFA_FULL(case 11: return shape_shift<3, 3, 2, 3>();)
         case 16: return shape_shift<1, 5, 1, 0>();
-        case 12: return shape_shift<2, 3, 3, 3>();
-        case 13: return shape_shift<3, 1, 2, 6>();
-        case 17: return shape_shift<1, 3, 1, 0>();
-        case 19: return shape_shift<1, 6, 1, 0>();
+        SFA_FULL(case 12: return shape_shift<2, 3, 3, 3>();)
+        SFA_FULL(case 13: return shape_shift<3, 1, 2, 6>();)
+        SFA_FULL(case 17: return shape_shift<1, 3, 1, 0>();)
+        SFA_FULL(case 19: return shape_shift<1, 6, 1, 0>();)
         case 14: return shape_shift<2, 6, 3, 1>();
     }
     return 0;
@@ -1106,20 +1108,20 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
     a.nch = ws.NCH; a.NI = ws.NS; a.omega = omega; a.active = g.active; a.amask = g.amask;
     const int nwg = g.nb * ws.NB * ws.NG;
     switch (ws.chain) {
-        case 1: return chain_launch_shape<1, 3, 1, 0, 4>(c, a, nwg);
-        case 2: return chain_launch_shape<2, 3, 2, 0, 2>(c, a, nwg);
-        case 3: return chain_launch_shape<3, 5, 3, 0, 2>(c, a, nwg);
-        case 5: return chain_launch_shape<2, 5, 2, 0, 2>(c, a, nwg);
+        SFA_FULL(case 1: return chain_launch_shape<1, 3, 1, 0, 4>(c, a, nwg);)
+        SFA_FULL(case 2: return chain_launch_shape<2, 3, 2, 0, 2>(c, a, nwg);)
+        SFA_FULL(case 3: return chain_launch_shape<3, 5, 3, 0, 2>(c, a, nwg);)
+        SFA_FULL(case 5: return chain_launch_shape<2, 5, 2, 0, 2>(c, a, nwg);)
         case 6: return chain_launch_shape<1, 5, 1, 0, 4>(c, a, nwg);
-        case 8: return chain_launch_shape<3, 2, 3, 0, 2>(c, a, nwg);
-        case 9: return chain_launch_shape<5, 6, 5, 0, 2>(c, a, nwg);
-        case 10: return chain_launch_shape<3, 10, 3, 0, 2>(c, a, nwg);
-        case 11: return chain_launch_shape<3, 3, 2, 3, 2, 1, 1>(c, a, nwg);
+        SFA_FULL(case 8: return chain_launch_shape<3, 2, 3, 0, 2>(c, a, nwg);)
+        SFA_FULL(case 9: return chain_launch_shape<5, 6, 5, 0, 2>(c, a, nwg);)
+        SFA_FULL(case 10: return chain_launch_shape<3, 10, 3, 0, 2>(c, a, nwg);)
+        SFA_FULL(case 11: return chain_launch_shape<3, 3, 2, 3, 2, 1, 1>(c, a, nwg);)
         case 16: return chain_launch_shape<1, 5, 1, 0, 4, 1, 1>(c, a, nwg);
-        case 12: return chain_launch_shape<2, 3, 3, 3, 2>(c, a, nwg);
-        case 13: return chain_launch_shape<3, 1, 2, 6, 2, 1, 1>(c, a, nwg);
-        case 17: return chain_launch_shape<1, 3, 1, 0, 4, 1, 1>(c, a, nwg);
-        case 19: return chain_launch_shape<1, 6, 1, 0, 4, 1, 1>(c, a, nwg);
+        SFA_FULL(case 12: return chain_launch_shape<2, 3, 3, 3, 2>(c, a, nwg);)
+        SFA_FULL(case 13: return chain_launch_shape<3, 1, 2, 6, 2, 1, 1>(c, a, nwg);)
+        SFA_FULL(case 17: return chain_launch_shape<1, 3, 1, 0, 4, 1, 1>(c, a, nwg);)
+        SFA_FULL(case 19: return chain_launch_shape<1, 6, 1, 0, 4, 1, 1>(c, a, nwg);)
         case 14: return chain_launch_shape<2, 6, 3, 1, 2, 1, 1>(c, a, nwg);
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }

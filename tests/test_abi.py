@@ -128,3 +128,32 @@ def test_the_assembly_kernel_keeps_three_blocks_per_cu():
         pytest.skip("hipcc not available")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_occupancy.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "three blocks per CU for every folded instance" in r.stdout, r.stdout + r.stderr
+
+
+def test_release_build_is_the_same_abi_without_the_switches(libpath):
+    """`make -C slowflow_amd/csrc release` (-DSFA_RELEASE) compiles out every cross-check / what-if path, the SFA_DEBUG environment gate and the
+    non-default solver shapes.  The result exports exactly the functions of the full build (= include/slowflow_amd.h), refuses sfa_debug_set by name, holds no
+    switch name and no getenv, and is smaller; tools/release_report.py prints both builds side by side (its GPU half: tests/test_host.py)."""
+    import shutil
+    import subprocess
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "slowflow_amd", "csrc"), "-j4", "release"], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rel = os.path.join(ROOT, "slowflow_amd", "csrc", "build_release", "libslowflow_amd.so")
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        return sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert exported(rel) == exported(libpath)
+    L = C.CDLL(rel)
+    assert not [n for n in declared_symbols() if not hasattr(L, n)]
+    L.sfa_last_error.restype = C.c_char_p
+    assert L.sfa_debug_set(b"SFA_UNFUSED", b"1") != 0 and b"release build" in L.sfa_last_error(None)
+    blob = open(rel, "rb").read()
+    full = open(libpath, "rb").read()
+    assert b"SFA_SOR_CHAIN" in full and b"SFA_DEBUG" in full                       # (the full build does carry the table and the gate)
+    assert b"SFA_SOR_CHAIN" not in blob and b"SFA_UNFUSED" not in blob and b"SFA_DEBUG\0" not in blob
+    und = subprocess.run(["nm", "-D", "--undefined-only", rel], capture_output=True, text=True).stdout
+    assert "getenv" not in und
+    assert len(blob) < 0.75 * len(full)

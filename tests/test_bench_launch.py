@@ -50,6 +50,34 @@ def test_world_size_mismatch_is_refused():
 import pytest
 
 
+def _fracs(o, path=""):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            yield from _fracs(v, path + "/" + k)
+    elif "frac" in path.rsplit("/", 1)[-1] and isinstance(o, (int, float)):      # `frac` and every *_frac* key
+        yield path, o
+
+
+def test_valu_time_model_is_the_shipped_kernels():
+    """`roofline.valu_time_floor_frac` is derived from the ISA of the shipped kernels (tools/valu_time_model.py -> profiles/r06_valu_model.json).  The committed
+    model must be what the current sources compile to -- a kernel edit without a new model fails here --, and with it the default 128-window launch of the last
+    round's record (1.58 ms mean launch) lies between a third and all of its VALU-time floor"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import valu_time_model
+    fresh = valu_time_model.build_model()
+    with open(os.path.join(ROOT, "profiles", "r06_valu_model.json")) as f:
+        committed = json.load(f)
+    for name, m in fresh["solver"].items():
+        assert [(s["F"], s["role"], s["valu_cycles_per_step"]) for s in m["stages"]] == [(s["F"], s["role"], s["valu_cycles_per_step"]) for s in committed["solver"][name]["stages"]], name
+        assert {k: v["valu_cycles_per_interval"] for k, v in m["io_waves"].items()} == {k: v["valu_cycles_per_interval"] for k, v in committed["solver"][name]["io_waves"].items()}, name
+        assert m["simd_placement"] == committed["solver"][name]["simd_placement"]
+    for name, m in fresh["assemble"].items():
+        assert m["cycles_per_valu_instruction_term_loop"] == committed["assemble"][name]["cycles_per_valu_instruction_term_loop"], name
+    busiest, mean, per_simd, _ = bench.solver_valu_floor("k_sor_chain<2,6,3,1,4,2,2,1,1> (6 stages of 2 + 1 of 3 sweeps, 2 groups per band)", 128)
+    assert 0.33 < busiest / 1.58e-3 < 1.0 and mean <= busiest and max(per_simd) == per_simd[1]          # stage 0 (loads + ring fill) and its partner: the busiest SIMD
+
+
 @pytest.mark.gpu
 def test_two_ranks_for_real_on_one_gpu():
     """the whole N = 2 path of the real bench -- child launch, two ranks with two contexts each, the timed region, max over ranks, the gather of the
@@ -69,13 +97,7 @@ def test_two_ranks_for_real_on_one_gpu():
         assert len(st["seconds_per_rank"]) == 2 and all(v > 0 for v in st["seconds_per_rank"])
         assert abs(st["seconds"] - max(st["seconds_per_rank"])) < 1e-3 and st["scaling"] == "strong"
     # no key named frac above 1 anywhere in the line (a fraction is a fraction)
-    def fracs(o, path=""):
-        if isinstance(o, dict):
-            for k, v in o.items():
-                yield from fracs(v, path + "/" + k)
-        elif "frac" in path.rsplit("/", 1)[-1] and isinstance(o, (int, float)):      # `frac` and every *_frac* key
-            yield path, o
-    assert all(0 <= v <= 1 for _, v in fracs(out)), list(fracs(out))
+    assert all(0 <= v <= 1 for _, v in _fracs(out)), list(_fracs(out))
 
 
 @pytest.mark.gpu
@@ -97,6 +119,8 @@ def test_one_rank_over_rccl():
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["seconds_per_window"]["n"] == 8
     assert out["config"]["parallelism"] == "frame-window data parallel x1"          # backend nccl: no rehearsal label
     assert out["distributed"] == {"backend": "nccl", "world_size": 1, "exchange_tensors_on": "cuda", "collectives": "barrier, all_reduce(MAX), all_reduce(SUM)"}
+    assert all(0 <= v <= 1 for _, v in _fracs(out)), list(_fracs(out))
+    assert out["roofline"]["valu_time_floor_frac"] is not None or out["config"]["windows_per_launch"] < 10
     for key, total in (("config4_strong", 128), ("config5_strong", 32)):
         st = out[key]
         assert "error" not in st, st

@@ -4,6 +4,7 @@ import json
 import os
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -948,3 +949,21 @@ def test_driver_deep_matching_at_half_resolution(host_build, tmp_path):
     cfg4.write_text(cfg.read_text().replace("dm_scale\t0.5", "dm_scale\t0.3"))
     r = subprocess.run([os.path.join(HOST, "slow_flow"), str(cfg4), "-overwrite"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "dm_scale" in r.stderr and "truncates" in r.stderr
+
+
+@pytest.mark.gpu
+def test_release_build_runs_the_path(tmp_path):
+    """the release build of the library (-DSFA_RELEASE, tests/test_abi.py) on the GPU, each build in a process of its own (tools/release_report.py): the smoke parity
+    (SOR bit-identical, a two-level refinement within 1e-4 of the oracle) through it, the default solver shapes at 1 and 16 systems of 1024x436 are the full build's,
+    a sweep count that no chain shape divides (K = 7) takes the one fallback kernel each build has and is bit-identical to the oracle in both"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "release_report.py")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = json.loads(r.stdout[r.stdout.index("["):])
+    full, rel = rows
+    assert "error" not in full and "error" not in rel, rows
+    assert full["debug_set_rc"] == 0 and rel["debug_set_rc"] != 0
+    assert rel["solver_kernels_1_16_K7"][:2] == full["solver_kernels_1_16_K7"][:2] and rel["solver_kernels_1_16_K7"][1].startswith("k_sor_chain<2,6,3,1")
+    assert rel["solver_kernels_1_16_K7"][2].startswith("k_sor_solve") and full["solver_kernels_1_16_K7"][2].startswith("k_sor_band")
+    assert full["fallback_K7_bit_identical"] and rel["fallback_K7_bit_identical"]
+    assert rel["bytes"] < 0.75 * full["bytes"] and (rel["gpu_kernels"] is None or rel["gpu_kernels"] < full["gpu_kernels"])
+    print(json.dumps(rows))
