@@ -41,7 +41,7 @@ def assemble_valu_per_pixel_term():
     from the SQ counter pass of the newest profile round that has it: SQ_INSTS_VALU / SQ_WAVES (both counters sample the same subset of the launch's waves, so
     their ratio is per wave; rounds 1-3 divided the raw instruction count by ALL pixels and reported 440 where a wave really issues ~1950 for its 64 pixels x 2
     terms) / 2 terms.  Returns (instructions, source, share of SIMD time with a VALU instruction in flight when the kernel runs alone)."""
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
                 j = json.load(f)
@@ -105,7 +105,7 @@ def sor_valu_per_wave(kernel):
     """(VALU instructions per wave of the SOR kernel, waves per workgroup, source) from the newest SQ pass whose kernel shape is the one that ran."""
     def norm(k):
         return k.replace("void ", "").replace("sfa::", "").split("(")[0].replace(" ", "")
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_sq.json")) as f:
                 j = json.load(f)
@@ -393,7 +393,7 @@ def measured_traffic(batch, kernel=None):
     so the committed measurement of the same command is reported, and only when it was taken at this batch size.
     Returns (bytes per launch, source, valu_busy) -- valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (SIMDs x kernel cycles) of the SOR kernel
     when the SQ pass of the same round is there (profiles/<tag>_sq.json), else None."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", tag + "_traffic.json")
         try:
             with open(path) as f:

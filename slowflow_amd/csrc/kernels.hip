@@ -1133,6 +1133,9 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
 #ifndef SFA_ASM_PAIR
 #define SFA_ASM_PAIR 0
 #endif
+#ifndef SFA_ASM_DMA_BARRIER
+#define SFA_ASM_DMA_BARRIER 1
+#endif
 #ifndef SFA_ASM_TY
 #define SFA_ASM_TY 8
 #endif
@@ -1305,7 +1308,12 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
             if (!ZUV) asm volatile("" : "+v"(u[k]), "+v"(v[k]));
         }
         AT_MARK(3);
-        __syncthreads();                                           // the DMA of every wave has landed
+        // Round 6, measured and NOT kept (-DSFA_ASM_DMA_BARRIER=0): the conversion pass below touches exactly the quads this wave's own DMA brought (a wave issues the
+        // parts ty, ty + NR, ... and converts the items ty * 64 + tx + i * NT: the same 16-byte slots, in the tile-interior path and in the border path alike), so the
+        // wave's own `s_waitcnt vmcnt(0)` above is all the conversion needs and this barrier -- one of four per term -- can go.  Bit-identical (60 parity tests) and
+        // worth nothing: 110.0 / 109.3 ms per bench step without it against 109.8 / 109.5 with it, same box: the waves of a block reach the barrier in front of
+        // stage 1 together either way.
+        if (SFA_ASM_DMA_BARRIER || kAsmPair) __syncthreads();      // the DMA of every wave has landed
         AT_MARK(4);
         if (t == 0) {
 #pragma unroll
