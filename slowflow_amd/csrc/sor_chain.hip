@@ -164,8 +164,18 @@ struct ChainShape {
     __host__ __device__ static constexpr int stage_of_wave6(int wave) {
         return SFA_CHAIN_PERM6 == 1 ? (wave == 1 ? 2 : wave == 3 ? 0 : wave - 1) : SFA_CHAIN_PERM6 == 2 ? (wave == 4 ? 0 : wave == 1 ? 3 : wave - 1) : wave - 1;
     }
+    // WHAT-IF ONLY (-DSFA_WHATIF_SHAPE20 -DSFA_X_OPR_CUT=18, tools/whatif_third_wave.sh; wrong results by construction, never shipped): TEN compute waves -- five
+    // stages of 2 sweeps, then five of 1 -- with the two I/O waves twelve waves, three per SIMD: what VERDICT r5 #2 asks to spend a smaller operand ring on.  The ring
+    // this shape needs (62 rows) does not fit by far; the what-if cuts it to the 44 rows the LDS has room for (a slot is then rewritten before its last read: the
+    // values are wrong, the instruction stream and the LDS traffic are the real ones).  Waves 0 (IN), 4, 8 / 1, 5, 9 / 2, 6, 10 / 3, 7, 11 (OUT) share a SIMD:
+    // IN + stages 1, 3 (4 sweeps) / stages 0, 5, 6 (4) / stages 2, 7, 8 (4) / stages 4, 9 + OUT (3)
+    static constexpr bool PERM12 = NW == 10 && NA == 5 && NB_ == 5 && FA == 2 && FB == 1;
+    __host__ __device__ static constexpr int stage_of_wave12(int wave) {
+        constexpr int m[11] = {-1, 0, 2, 4, 1, 5, 7, 9, 3, 6, 8};
+        return m[wave];
+    }
     __host__ __device__ static constexpr int stage_of_wave(int wave) {
-        return PERM9 ? (wave == 4 ? 0 : wave < 4 ? wave : wave - 1) : PERM9L ? (wave == 4 ? 6 : wave < 4 ? wave - 1 : wave - 2) : NW == 6 ? stage_of_wave6(wave) : wave - 1;
+        return PERM12 ? stage_of_wave12(wave) : PERM9 ? (wave == 4 ? 0 : wave < 4 ? wave : wave - 1) : PERM9L ? (wave == 4 ? 6 : wave < 4 ? wave - 1 : wave - 2) : NW == 6 ? stage_of_wave6(wave) : wave - 1;
     }
 };
 
@@ -1023,6 +1033,9 @@ static const ChainShapeInfo kChainShapes[] = {
     SFA_FULL({17, 1, 3, 1, 0, 4, 1, 1},)     // 3 stages of 1 with the same lags: every compute wave alone on its SIMD, ten groups per band
     SFA_FULL({19, 1, 6, 1, 0, 4, 1, 1},)     // 6 stages of 1: five groups per band
     {14, 2, 6, 3, 1, 2, 1, 1},     // 6 stages of 2 + 1 of 3         KG = 15: nine waves, the last stage beside the I/O waves (ChainShape::PERM9L)
+#ifdef SFA_WHATIF_SHAPE20
+    {20, 2, 5, 1, 5, 2, 1, 1},     // what-if only: 5 stages of 2 + 5 of 1: twelve waves, three per SIMD (ChainShape::PERM12)
+#endif
 };
 
 bool chain_shape(int id, int K, int *KG, int *NW, int *FMAX) {
@@ -1069,6 +1082,9 @@ int chain_shift(int id) {
         SFA_FULL(case 17: return shape_shift<1, 3, 1, 0>();)
         SFA_FULL(case 19: return shape_shift<1, 6, 1, 0>();)
         case 14: return shape_shift<2, 6, 3, 1>();
+#ifdef SFA_WHATIF_SHAPE20
+        case 20: static_assert(ChainLds<ChainShape<2, 5, 1, 5>, kChainCH>::OPRING, "the what-if needs -DSFA_X_OPR_CUT=18: its ring does not fit"); return shape_shift<2, 5, 1, 5>();
+#endif
     }
     return 0;
 }
@@ -1123,6 +1139,9 @@ int sor_chain_launch(sfa_ctx *c, SorWorkspace &ws, const Geo &g, int K, float om
         SFA_FULL(case 17: return chain_launch_shape<1, 3, 1, 0, 4, 1, 1>(c, a, nwg);)
         SFA_FULL(case 19: return chain_launch_shape<1, 6, 1, 0, 4, 1, 1>(c, a, nwg);)
         case 14: return chain_launch_shape<2, 6, 3, 1, 2, 1, 1>(c, a, nwg);
+#ifdef SFA_WHATIF_SHAPE20
+        case 20: return chain_launch_shape<2, 5, 1, 5, 2, 1, 1>(c, a, nwg);
+#endif
         default: return set_error(c, SFA_ERR_ARG, "sor_chain_launch: unknown shape %d", ws.chain);
     }
 }
