@@ -364,6 +364,11 @@ __device__ __forceinline__ void chain_compute(const ChainArgs &a, unsigned char 
 #ifdef SFA_CHAIN_TIMING
     unsigned long long t_begin = __builtin_readcyclecounter(), t_lead = 0, t_bar = 0, t_first = 0, t_last = 0, t_ldsrd = 0, t_wr = 0;
 #endif
+    // wave priority of the compute waves against the I/O waves of their SIMD (0 = none; the I/O waves stay at 0)
+#ifndef SFA_CHAIN_CPRIO
+#define SFA_CHAIN_CPRIO 0
+#endif
+    if (SFA_CHAIN_CPRIO) __builtin_amdgcn_s_setprio(SFA_CHAIN_CPRIO);
     for (; I < lead; I++) SFA_CHAIN_BARRIER_T(t_lead);
 #ifdef SFA_CHAIN_TIMING
     t_first = __builtin_readcyclecounter();
