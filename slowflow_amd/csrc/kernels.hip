@@ -426,21 +426,68 @@ void launch_smoothness(sfa_ctx *c, const Geo &g, int method, float *sh, float *s
 // get_derivatives' warps (variational_mt.cpp:100-109) and compute_smoothness (:333) of the same flow field in one pass: both read wx, wy of every pixel, the
 // smoothness kernel alone is bound by its two IEEE square-root / division chains per pixel (2.8 TB/s) and the warp by its traffic -- together the arithmetic runs
 // under the gathers and the flow tile is read once.  Same per-pixel operations as k_smoothness_tiled and k_warp_jobs (bit-identical: test_fused_warp_smoothness).
-__global__ void __launch_bounds__(256) k_warp_smooth(WarpJobs J, float *__restrict__ base, int method, float *__restrict__ sh, float *__restrict__ sv,
+// rows of the tile in flight (= waves per block); a thread works on SM_Y / WS_ROWS pixels one after the other.  Round 6: 8 (one pixel per thread: no gather of a
+// second pixel queues behind the first one's stores in the wave's in-order memory counter; 4 until then)
+#ifndef SFA_WS_ROWS
+#define SFA_WS_ROWS 8
+#endif
+#ifndef SFA_WS_NT
+#define SFA_WS_NT 1
+#endif
+constexpr int WS_ROWS = SFA_WS_ROWS;
+static_assert(SM_Y % WS_ROWS == 0, "whole pixels per thread");
+__global__ void __launch_bounds__(64 * WS_ROWS) k_warp_smooth(WarpJobs J, float *__restrict__ base, int method, float *__restrict__ sh, float *__restrict__ sv,
                                                      const float *__restrict__ uu_, const float *__restrict__ vv_, const float *__restrict__ dps_, Geo g, float alpha,
                                                      PenaltyDev reg) {
     __shared__ float tU[SM_R * SM_W], tV[SM_R * SM_W], tD[SM_R * SM_W];
+    // what-if (-DSFA_WS_XCD=1, round 6; round 5 had measured the time only): a 1-D grid whose workgroup i works on tile (i % 8) * ceil(N / 8) + i / 8 of the row-major
+    // (window, tile row, tile column) order, as k_assemble_images does -- every XCD walks a contiguous eighth of the tiles, so the third 128-byte line a shifted
+    // 64-column gather footprint touches is its horizontal neighbour's line in the SAME L2
+#if defined(SFA_WS_XCD) && SFA_WS_XCD
+    int bx_, by_, b_;
+    {
+        const unsigned nx = (unsigned)((g.pitch + SM_X - 1) / SM_X), ny = (unsigned)((g.h + SM_Y - 1) / SM_Y), nxy = nx * ny, total = nxy * (unsigned)g.nb;
+        const unsigned chunk = (total + 7u) / 8u;
+        const unsigned j = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+        if (j >= total) return;
+        b_ = (int)(j / nxy);
+        const unsigned r = j - (unsigned)b_ * nxy;
+        by_ = (int)(r / nx); bx_ = (int)(r - (unsigned)by_ * nx);
+    }
+    const int b = b_;
+    if (!elem_active(g, b)) return;
+    const int x0 = bx_ * SM_X - 1, y0 = by_ * SM_Y - 1;
+#else
     const int b = blockIdx.z;
     if (!elem_active(g, b)) return;
     const int x0 = blockIdx.x * SM_X - 1, y0 = blockIdx.y * SM_Y - 1;
+#endif
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const long eb = b * g.es;
+    // Round 6: every address of this kernel is a WAVE-UNIFORM base (window, plane, image set: scalar registers) + a 32-bit byte offset per lane (a plane is < 2^32 bytes:
+    // the launcher checks it): the loads and stores take the scalar-base form.  Written with size_t indices the compiler formed every one of the 24 gather
+    // addresses of a pixel in 64-bit VALU arithmetic -- per gather set 2 v_mad_i64_i32, 4 v_lshlrev_b64 and 18 v_lshl_add_u64: 127 VALU instructions and 13 registers less.
+    // What bounds the kernel is neither that nor its traffic (what-if builds of this round, 128 windows, 650-680 us per launch as shipped before): the XCD-contiguous
+    // tile order halves the fetched bytes (2.57 -> 1.42 GB: the over-fetch IS the cross-XCD duplicate of the gathers' third line) and leaves the time at 662; without
+    // the smoothness weights' fp64 square roots and divisions it takes 823 (!); without the gathers 431; without the stores of the warped images 289 -- the
+    // write path is what it waits for, and what moved it is how the stores leave (non-temporal, below) and that no load queues behind them (one pixel per thread)
+    // timing-only what-if builds (-DSFA_X_WS=bits, wrong results, never shipped): 1 every tap of a gather reads ONE address (the pixel's own), 2 the smoothness weights
+    // without their fp64 square root and division, 4 no stores of the warped images, 8 no gathers at all, 32 masks, sh, sv as non-temporal stores too
+#ifndef SFA_X_WS
+#define SFA_X_WS 0
+#endif
+    auto ld = [](const float *ubase, unsigned boff) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + boff); };
+    auto st = [](float *ubase, unsigned boff, float v) {
+        if (SFA_X_WS & 32) __builtin_nontemporal_store(v, reinterpret_cast<float *>(reinterpret_cast<char *>(ubase) + boff));      // what-if: masks, sh, sv as streaming stores too
+        else *reinterpret_cast<float *>(reinterpret_cast<char *>(ubase) + boff) = v;
+    };
+    const unsigned pitch4 = 4u * (unsigned)g.pitch;
     const float *pu = uu_ + eb, *pv = vv_ + eb, *pd = dps_ + eb;
-    for (int i = tid; i < SM_R * SM_W; i += 256) {
+    for (int i = tid; i < SM_R * SM_W; i += 64 * WS_ROWS) {
         const int gx = x0 + i % SM_W, gy = y0 + i / SM_W;
         if (gx >= 0 && gx < g.w && gy >= 0 && gy < g.h) {
-            const size_t o = (size_t)gy * g.pitch + gx;
-            tU[i] = pu[o]; tV[i] = pv[o]; tD[i] = pd[o];
+            const unsigned o4 = (unsigned)gy * pitch4 + 4u * (unsigned)gx;
+            tU[i] = ld(pu, o4); tV[i] = ld(pv, o4); tD[i] = ld(pd, o4);
         }
     }
     __syncthreads();
@@ -448,11 +495,11 @@ __global__ void __launch_bounds__(256) k_warp_smooth(WarpJobs J, float *__restri
     const int w = g.w, h = g.h;
     const int x = x0 + 1 + threadIdx.x;
     sh += eb; sv += eb;
-    for (int k = 0; k < SM_Y / 4; k++) {
-        const int y = y0 + 1 + threadIdx.y + 4 * k;
+    for (int k = 0; k < SM_Y / WS_ROWS; k++) {
+        const int y = y0 + 1 + threadIdx.y + WS_ROWS * k;
         if (x >= g.pitch || y >= h) continue;
-        const size_t o = (size_t)y * g.pitch + x;
-        if (x >= w) { sh[o] = 0.0f; sv[o] = 0.0f; continue; }        // padding lanes stay zero
+        const unsigned o4 = (unsigned)y * pitch4 + 4u * (unsigned)x;
+        if (x >= w) { st(sh, o4, 0.0f); st(sv, o4, 0.0f); continue; }        // padding lanes stay zero
         // ---- the warps of this pixel: the gathers of the first two jobs are issued here, the smoothness arithmetic runs while they are in flight ---------
         const float fx0 = uu(x, y), fy0 = vv(x, y);
         auto gather = [&](int j, float(&out)[3]) {
@@ -462,21 +509,31 @@ __global__ void __launch_bounds__(256) k_warp_smooth(WarpJobs J, float *__restri
             const float yy = y + factor * fy0;
             const int xi = (int)floorf(xx), yi = (int)floorf(yy);
             const float dx = xx - xi, dy = yy - yi;
-            if (J.job[j].mask_off >= 0) base[eb + J.job[j].mask_off + o] = (xx >= 0 && xx <= g.w - 1 && yy >= 0 && yy <= g.h - 1) ? 1.0f : 0.0f;   // :742
+            if (J.job[j].mask_off >= 0) st(base + eb + J.job[j].mask_off, o4, (xx >= 0 && xx <= g.w - 1 && yy >= 0 && yy <= g.h - 1) ? 1.0f : 0.0f);   // :742
             const int x1 = clampi(xi, 0, g.w - 1), x2 = clampi(xi + 1, 0, g.w - 1);
             const int y1 = clampi(yi, 0, g.h - 1), y2 = clampi(yi + 1, 0, g.h - 1);
             const float ax = 1.0f - dx, ay = 1.0f - dy;
+            const unsigned r1 = (unsigned)y1 * pitch4, r2 = (unsigned)y2 * pitch4, c1 = 4u * (unsigned)x1, c2 = 4u * (unsigned)x2;
+            const unsigned o11 = (SFA_X_WS & 1) ? o4 : r1 + c1, o12 = (SFA_X_WS & 1) ? o4 : r1 + c2, o21 = (SFA_X_WS & 1) ? o4 : r2 + c1, o22 = (SFA_X_WS & 1) ? o4 : r2 + c2;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 const float *sp = src3 + ch * g.pl;
-                out[ch] = sp[(size_t)y1 * g.pitch + x1] * ax * ay + sp[(size_t)y1 * g.pitch + x2] * dx * ay
-                        + sp[(size_t)y2 * g.pitch + x1] * ax * dy + sp[(size_t)y2 * g.pitch + x2] * dx * dy;               // :748-753
+                if (SFA_X_WS & 8) { out[ch] = ax * ay + dx * dy; continue; }
+                out[ch] = ld(sp, o11) * ax * ay + ld(sp, o12) * dx * ay + ld(sp, o21) * ax * dy + ld(sp, o22) * dx * dy;               // :748-753
             }
         };
         auto put = [&](int j, const float(&out)[3]) {
             float *dst3 = base + eb + J.job[j].dst_off;
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) dst3[ch * g.pl + o] = out[ch];
+            for (int ch = 0; ch < 3; ch++) {
+                if (SFA_X_WS & 4) continue;
+                // Round 6: the warped images leave as NON-TEMPORAL stores (24 of the kernel's 40 written bytes per pixel; the data-term kernel reads them back by DMA,
+                // from memory either way: 0.94 GB per 128-window launch).  Same box, whole path: 111.5 / 112.0 -> 110.6 / 110.6 ms per step together with the eight-row
+                // block below (-DSFA_WS_NT=0: plain stores).  NOT for the solver's operand tile in k_assemble_images: the solver reads that from the caches (+3-5 % of
+                // the whole path as non-temporal stores, -DSFA_ASM_NT=1)
+                if (SFA_WS_NT) __builtin_nontemporal_store(out[ch], reinterpret_cast<float *>(reinterpret_cast<char *>(dst3 + ch * g.pl) + o4));
+                else st(dst3 + ch * g.pl, o4, out[ch]);
+            }
         };
         float out0[3] = {0, 0, 0}, out1[3] = {0, 0, 0};
         gather(0, out0);
@@ -493,7 +550,7 @@ __global__ void __launch_bounds__(256) k_warp_smooth(WarpJobs J, float *__restri
             t = ux1 * ux1 + t * t;                                                       // :61-64
             t2 = vx1 * vx1 + t2 * t2;
             t = t + t2;
-            outh = (dps(x, y) + dps(x + 1, y)) * alpha * psi_scalar(reg, t);              // :66
+            outh = (dps(x, y) + dps(x + 1, y)) * alpha * ((SFA_X_WS & 2) ? t : psi_scalar(reg, t));              // :66
         }
         if (y < h - 1) {
             const float uy1 = uu(x, y + 1) - uu(x, y), vy1 = vv(x, y + 1) - vv(x, y);     // :35-36
@@ -505,10 +562,10 @@ __global__ void __launch_bounds__(256) k_warp_smooth(WarpJobs J, float *__restri
             t = uy1 * uy1 + t * t;                                                       // :84-87
             t2 = vy1 * vy1 + t2 * t2;
             t = t + t2;
-            outv = (dps(x, y) + dps(x, y + 1)) * alpha * psi_scalar(reg, t);              // :89
+            outv = (dps(x, y) + dps(x, y + 1)) * alpha * ((SFA_X_WS & 2) ? t : psi_scalar(reg, t));              // :89
         }
-        sh[o] = outh;                                                                    // :68 zero last column
-        sv[o] = outv;                                                                    // :92 zero last row
+        st(sh, o4, outh);                                                                // :68 zero last column
+        st(sv, o4, outv);                                                                // :92 zero last row
         put(0, out0);
         if (J.n > 1) put(1, out1);
         for (int j = 2; j < J.n; j++) {                                                  // S >= 3: the further jobs one after the other
@@ -523,8 +580,14 @@ bool launch_warp_smooth(sfa_ctx *c, const Geo &g, const WarpJobs &J, float *base
                         const float *dpsis, float alpha, PenaltyDev reg) {
     const bool off = sw_given(Switches::NO_WARP_SMOOTH);
     if (off || method > 1 || J.n <= 0) return false;
-    hipLaunchKernelGGL(k_warp_smooth, dim3((g.pitch + SM_X - 1) / SM_X, (g.h + SM_Y - 1) / SM_Y, g.nb), dim3(64, 4), 0, c->stream, J, base, method, sh, sv, wx, wy,
+    if ((unsigned long long)g.pl * 4ull >= (1ull << 32)) return false;      // the kernel's 32-bit byte offsets inside a plane (the two kernels it fuses address with 64 bits)
+#if defined(SFA_WS_XCD) && SFA_WS_XCD
+    const unsigned tiles = (unsigned)((g.pitch + SM_X - 1) / SM_X) * (unsigned)((g.h + SM_Y - 1) / SM_Y) * (unsigned)g.nb;
+    hipLaunchKernelGGL(k_warp_smooth, dim3((tiles + 7) / 8 * 8), dim3(64, WS_ROWS), 0, c->stream, J, base, method, sh, sv, wx, wy, dpsis, g, alpha, reg);
+#else
+    hipLaunchKernelGGL(k_warp_smooth, dim3((g.pitch + SM_X - 1) / SM_X, (g.h + SM_Y - 1) / SM_Y, g.nb), dim3(64, WS_ROWS), 0, c->stream, J, base, method, sh, sv, wx, wy,
                        dpsis, g, alpha, reg);
+#endif
     return true;
 }
 
@@ -1575,12 +1638,20 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         if (r >= g.h || c >= g.w) continue;
         const size_t e = (size_t)b * a.op.ent + (size_t)(c + r + a.op.G) * a.op.RP + (r + a.op.G);
         if (SFA_X_AI & 64) continue;
-        a.op.sa[e] = tA[rl][cl];
-        a.op.sb[e] = tB[rl][cl];
         const float2 xv = tX[rl][cl];
         unsigned long long xu;
         __builtin_memcpy(&xu, &xv, 8);
+#if defined(SFA_ASM_NT) && SFA_ASM_NT      // what-if (round 6): the operand tile leaves as non-temporal stores
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        const float4 qa = tA[rl][cl], qb = tB[rl][cl];
+        __builtin_nontemporal_store((v4f_){qa.x, qa.y, qa.z, qa.w}, reinterpret_cast<v4f_ *>(a.op.sa + e));
+        __builtin_nontemporal_store((v4f_){qb.x, qb.y, qb.z, qb.w}, reinterpret_cast<v4f_ *>(a.op.sb + e));
+        __builtin_nontemporal_store(xu, a.op.x + e);
+#else
+        a.op.sa[e] = tA[rl][cl];
+        a.op.sb[e] = tB[rl][cl];
         a.op.x[e] = xu;
+#endif
     }
 #ifdef SFA_ASM_TIMING
     AT_MARK(12);
@@ -1748,7 +1819,11 @@ __global__ void __launch_bounds__(BX *BY) k_update_outer_x(float *__restrict__ u
                     sb += (double)fabsf(v - oy);
                     if (uu) { uu[o] = u; vv[o] = v; }                                     // (null: the caller reads wx, wy in their place -- one inner iteration)
                     if (dfa) { dfa[o] = fabsf(u - ox); dfb[o] = fabsf(v - oy); }         // the per-pixel terms of the norms, for k_exact_break
+#if defined(SFA_UPD_NT) && SFA_UPD_NT      // what-if (round 6): the new flow leaves as non-temporal stores
+                    __builtin_nontemporal_store(u, wx + o); __builtin_nontemporal_store(v, wy + o);
+#else
                     wx[o] = u; wy[o] = v;                                                 // :428-429
+#endif
                 }
         }
     }

@@ -155,7 +155,12 @@ inline int sw_int(Switches::Id i, int dflt) { return g_switches.given[i] ? g_swi
 
 inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 inline int host_stride(int w) { return ((w + 3) / 4) * 4; }     // image.c:25
-inline int dev_pitch(int w) { return round_up(w, 64); }         // device rows are 256-B aligned
+#ifndef SFA_PITCH_ODD
+#define SFA_PITCH_ODD 0
+#endif
+// device rows are 256-B aligned.  SFA_PITCH_ODD (what-if, round 6): an ODD number of 256-byte units per row, so that the rows of a tile and the planes of an image set
+// (a whole number of rows apart) do not all fall on addresses that agree modulo 4 KB (1024-column frames: rows 4 096 bytes apart)
+inline int dev_pitch(int w) { const int p = round_up(w, 64); return (SFA_PITCH_ODD && ((p / 64) & 1) == 0) ? p + 64 : p; }
 
 // RAII device allocation
 struct DevMem {
