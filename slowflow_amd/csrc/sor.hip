@@ -1065,7 +1065,13 @@ int SorWorkspace::configure(sfa_ctx *c, int w_, int h_, int K_, int nb_) {
         chain_shape(chain, K, &KG, &NW, &FMAX);
         const int CH = chain_ch(), AH = chain_ah(), LEAD = AH + 1;
         NG = K / KG;
-        G = K + 64;
+        // guard entries around the planes: at least K + 64; round 6: a multiple of 8, so that the TY = 8 consecutive entries of an anti-diagonal that a tile of
+        // k_assemble_images writes (rows 8 by .. 8 by + 7: entry (r + G) of its diagonal) are ONE aligned 128-byte line of the SA / SB planes instead of a 96 + 32-byte
+        // straddle of two lines that the tile below completes from another CU (-DSFA_GUARD_ALIGN=1: K + 64 as before)
+#ifndef SFA_GUARD_ALIGN
+#define SFA_GUARD_ALIGN 8
+#endif
+        G = round_up(K + 64, SFA_GUARD_ALIGN);
         RP = round_up(h + 2 * G, 16);
         NCH = round_up((w + 64 + KG - NW + 2 * CH + FMAX + CH - 1) / CH + chain_shift(chain), 4);     // + the chunks by which the groups start early
         NS = round_up(NCH + LEAD + NW + 2, AH);
