@@ -1160,8 +1160,13 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 // the same with a wave-uniform 64-bit base and a 32-bit byte offset per lane (no 64-bit address arithmetic in the vector unit)
+#if defined(SFA_ASM_DMA_NT) && SFA_ASM_DMA_NT      // what-if (round 6): the image quads as non-temporal loads (they stream through the L2 the solver's operands sit in)
+#define SFA_DMA_NT_ " nt"
+#else
+#define SFA_DMA_NT_ ""
+#endif
 __device__ __forceinline__ void dma16s(const float *sbase, unsigned voff, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" SFA_DMA_NT_ ::"v"(voff), "s"(sbase), "s"(lds_byte) : "memory", "m0");
 }
 __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte) : "memory", "m0");
