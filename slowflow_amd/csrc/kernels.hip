@@ -66,7 +66,7 @@ __global__ void k_warp(float *__restrict__ dst3, float *__restrict__ mask, const
     }
     const float xx = x + factor * wx[o];                             // :735
     const float yy = y + factor * wy[o];
-    const int xi = (int)floorf(xx), yi = (int)floorf(yy);
+    const int xi = floor_to_int_x86(xx), yi = floor_to_int_x86(yy);                // :737-738
     const float dx = xx - xi, dy = yy - yi;
     if (mask) mask[b * g.es + o] = (xx >= 0 && xx <= g.w - 1 && yy >= 0 && yy <= g.h - 1) ? 1.0f : 0.0f;   // :742
     const int x1 = clampi(xi, 0, g.w - 1), x2 = clampi(xi + 1, 0, g.w - 1);
@@ -94,7 +94,7 @@ __global__ void k_warp_jobs(WarpJobs J, float *__restrict__ base, const float *_
         float *dst3 = base + eb + J.job[j].dst_off;
         const float xx = x + factor * fx0;                              // :735
         const float yy = y + factor * fy0;
-        const int xi = (int)floorf(xx), yi = (int)floorf(yy);
+        const int xi = floor_to_int_x86(xx), yi = floor_to_int_x86(yy);                // :737-738
         const float dx = xx - xi, dy = yy - yi;
         if (J.job[j].mask_off >= 0) base[eb + J.job[j].mask_off + o] = (xx >= 0 && xx <= g.w - 1 && yy >= 0 && yy <= g.h - 1) ? 1.0f : 0.0f;   // :742
         const int x1 = clampi(xi, 0, g.w - 1), x2 = clampi(xi + 1, 0, g.w - 1);
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(64 * WS_ROWS) k_warp_smooth(WarpJobs J, float 
             const float *src3 = base + eb + J.job[j].src_off;
             const float xx = x + factor * fx0;                              // :735
             const float yy = y + factor * fy0;
-            const int xi = (int)floorf(xx), yi = (int)floorf(yy);
+            const int xi = floor_to_int_x86(xx), yi = floor_to_int_x86(yy);                // :737-738
             const float dx = xx - xi, dy = yy - yi;
             if (J.job[j].mask_off >= 0) st(base + eb + J.job[j].mask_off, o4, (xx >= 0 && xx <= g.w - 1 && yy >= 0 && yy <= g.h - 1) ? 1.0f : 0.0f);   // :742
             const int x1 = clampi(xi, 0, g.w - 1), x2 = clampi(xi + 1, 0, g.w - 1);

@@ -20,6 +20,15 @@ __device__ __forceinline__ bool elem_active(const WMask &active, const unsigned 
 }
 __device__ __forceinline__ bool elem_active(const Geo &g, int b) { return elem_active(g.active, g.amask, b); }
 __device__ __forceinline__ int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
+// `int x = floor(xx)` as the reference's x86 build evaluates it (variational_aux_mt.cpp:737-738: cvttsd2si): a value outside the int range -- a refinement that
+// diverges, e.g. under an ill-posed parameter set -- and NaN give INT_MIN, the instruction's "integer indefinite".  The GPU's own conversion saturates (+huge ->
+// INT_MAX), and `x + 1` then overflows: the compiler, entitled to assume it does not, had turned clamp(x + 1, 0, w - 1) into a select that let INT_MIN through as
+// a column index -- a memory access fault (found by tools/fuzz_parity.py, round 6; the form of rounds 1-5 had it too).  With this conversion x + 1 cannot overflow,
+// and a diverged window reads what the reference's would: column / row 0.
+__device__ __forceinline__ int floor_to_int_x86(float v) {
+    const float f = floorf(v);
+    return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (-2147483647 - 1);
+}
 
 // derivative filter taps as convolution_new builds them (image.c:363-366, variational_mt.cpp:570-573)
 #define C5_0 (1.0f / 12.0f)

@@ -87,6 +87,39 @@ def test_image_warp(ctx, oracle, factor):
         assert np.array_equal(valid(ma, w), valid(mb, w))
 
 
+def test_image_warp_with_flows_beyond_the_int_range(ctx, oracle):
+    """round 6 (found by tools/fuzz_parity.py as a GPU memory fault): a flow value whose target column leaves the int range -- a refinement that diverges -- or is not a
+    number.  The reference's x86 build converts such a coordinate to INT_MIN (`int x = floor(xx)`, variational_aux_mt.cpp:737: cvttsd2si's integer indefinite) and reads
+    column / row 0; the GPU's conversion saturates to INT_MAX, `x + 1` overflowed, and the compiler's clamp let INT_MIN through as an index.  Now the kernels convert like
+    the reference: every pixel, the poisoned ones included, equals the oracle's bit for bit (NaN == NaN), in the stage kernel and inside a level (k_warp_smooth, k_warp_jobs)"""
+    w, h = 130, 98
+    rng = np.random.default_rng(77)
+    src = smooth_noise_color(rng, w, h)
+    wx, wy = noise_plane(rng, w, h, -4, 4), noise_plane(rng, w, h, -4, 4)
+    bad = [3e9, -3e9, 1e30, -1e30, np.inf, -np.inf, np.nan, 2147483520.0, -2147483648.0, 2147483648.0]
+    for i, v in enumerate(bad):
+        wx[3 + i, 10 + 3 * i] = v
+        wy[40 + i, 20 + 5 * i] = v
+        wx[70, 5 + i] = v; wy[70, 5 + i] = bad[(i + 3) % len(bad)]
+    for factor in (-2, -1, 1, 2):
+        a, ma = oracle.image_warp(src, wx, wy, w, factor)
+        b, mb = ctx.image_warp(c_(src), c_(wx), c_(wy), w, factor)
+        assert np.array_equal(valid(a, w), valid(b, w), equal_nan=True), factor
+        assert np.array_equal(valid(ma, w), valid(mb, w)), factor
+    # the same field as the initial flow of a level (S = 3: four warps per get_derivatives through k_warp_smooth; niter_inner = 2: through k_warp_jobs): no fault, and
+    # the poison spreads over the same pixels as in the oracle
+    frames, af, sf = normalized_frames(oracle, w, h, 5, seed=9)
+    for inner in (1, 2):
+        po, ps = mk_params(oracle, S=3, rho=[1, 0.5], omega=[0.5, 2], norm_avg=af, norm_std=sf, niter_outer=2, niter_inner=inner, niter_solver=5)
+        o, g = run_both(ctx, oracle, po, ps, frames, w, h, init=(wx, wy))
+        for k in range(2):
+            fo, fg = valid(o[k], w), valid(g[k], w)
+            assert np.array_equal(np.isfinite(fo), np.isfinite(fg)), (inner, k)
+            fin = np.isfinite(fo)
+            assert fin.sum() < fin.size                                                                      # (the sweeps carry the poison nearly, or really, everywhere)
+            assert fin.sum() == 0 or np.abs(fo[fin] - fg[fin]).max() <= 1e-3 * max(1.0, np.abs(fo[fin]).max()), (inner, k)
+
+
 def test_image_warp_golden(ctx):
     w = 67
     for factor in (-2, -1, 1, 2):
