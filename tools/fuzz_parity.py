@@ -82,9 +82,104 @@ case_seed = seed0
 while time.time() < t_end:
     case_seed += 1
     rng = np.random.default_rng(case_seed)
-    kind = "sor" if rng.random() < 0.35 else "level"
+    r0 = rng.random()
+    kind = "sor" if r0 < 0.30 else "level" if r0 < 0.72 else "cut" if r0 < 0.82 else "2frame" if r0 < 0.90 else "rb" if r0 < 0.95 else "occ"
     try:
-        if kind == "sor":
+        if kind == "cut":
+            # the exact two-label minimum cut of optimizeOcc against the oracle's exact fp64 minimum: equal energy (the labelling need not be unique)
+            w, h = int(rng.integers(5, 331)), int(rng.integers(5, 261))
+            st = sfa.stride_of(w)
+            d0, d1 = np.zeros((h, st), np.float32), np.zeros((h, st), np.float32)
+            gen = int(rng.integers(0, 4))
+            if gen == 0:
+                d0[:, :w] = rng.uniform(0, 2, (h, w)); d1[:, :w] = rng.uniform(0, 2, (h, w))
+            elif gen == 1:
+                d0[:, :w] = rng.uniform(0, 0.2, (h, w)); d1[:, :w] = 1.0 + rng.uniform(0, 0.2, (h, w))
+                yy, xx = np.mgrid[0:h, 0:w]
+                for _ in range(int(rng.integers(1, 9))):
+                    cx, cy, r = rng.integers(0, w), rng.integers(0, h), rng.integers(1, 12)
+                    d0[:, :w][(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] += rng.uniform(1.0, 4.0)
+            elif gen == 2:
+                d0[:, :w] = 0.1; d1[:, :w] = 0.6
+                k7 = int(rng.integers(3, 12))
+                d0[::k7, :w] += 3.0; d1[k7 // 2::k7, :w] += 3.0
+                d0[:, :w] += rng.uniform(0, 0.05, (h, w))
+            else:                                                    # ties and zeros: equal costs, zero costs, one label free everywhere
+                d0[:, :w] = rng.integers(0, 3, (h, w)).astype(np.float32) * 0.5; d1[:, :w] = rng.integers(0, 3, (h, w)).astype(np.float32) * 0.5
+            alpha = float(rng.choice([0.0, 0.05, 0.1, 0.5, 2.0]))
+            a0 = orc.plane(h, st); a0[...] = d0
+            a1 = orc.plane(h, st); a1[...] = d1
+            _, e_o = o.grid_cut(a0, a1, alpha, w)
+            occ_g = ctx.grid_cut(c_(d0), c_(d1), alpha, w)
+            og = orc.plane(h, st); og[...] = occ_g
+            e_g = o.grid_cut_energy(og, a0, a1, alpha, w)
+            d = abs(e_g - e_o) / max(1.0, abs(e_o)); tol = 1e-5
+            ok = d <= tol and set(np.unique(occ_g[:, :w])) <= {-1.0, 0.0, 1.0}
+            desc = f"cut {w}x{h} costs {gen} alpha={alpha} energy {e_g:.6g} / {e_o:.6g}"
+        elif kind == "2frame":
+            # the original two-frame variational(): bit-identical to the oracle (which is bit-identical to the compiled reference)
+            w, h = int(rng.integers(8, 331)), int(rng.integers(8, 261))
+            big = smooth_noise_color(rng, w + 8, h + 8, float(rng.uniform(20, 60)))
+            a, b = orc.aligned_zeros((3, h, orc.stride_of(w))), orc.aligned_zeros((3, h, orc.stride_of(w)))
+            a[:, :, :w] = big[:, 4:4 + h, 4:4 + w]
+            sx, sy = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+            b[:, :, :w] = big[:, 4 - sy:4 - sy + h, 4 - sx:4 - sx + w]
+            kw = dict(niter_outer=int(rng.integers(1, 5)), niter_inner=int(rng.choice([1, 1, 2])), niter_solver=int(rng.choice([30, 7, 15])), sor_omega=float(rng.choice([1.9, 1.5])),
+                      alpha=float(rng.choice([1.0, 3.0])), gamma=float(rng.choice([0.71, 0.2])), delta=float(rng.choice([0.0, 0.5, 1.0])), sigma=float(rng.choice([0.0, 0.0, 0.8])))
+            wx0, wy0 = noise_plane(rng, w, h, -1, 3), noise_plane(rng, w, h, -1, 2)
+            wxo, wyo = orc.plane(*wx0.shape), orc.plane(*wx0.shape)
+            wxo[...] = wx0; wyo[...] = wy0
+            po = orc.params_2f(**kw)
+            o.variational_2frame(wxo, wyo, a, b, w, po)
+            pg = sfa.Params2f(po.alpha, po.gamma, po.delta, po.sigma, po.niter_outer, po.niter_inner, po.niter_solver, po.sor_omega)
+            wxg, wyg = c_(wx0).copy(), c_(wy0).copy()
+            ctx.variational_2frame(wxg, wyg, c_(a), c_(b), w, pg)
+            ok = np.array_equal(wxo[:, :w], wxg[:, :w], equal_nan=True) and np.array_equal(wyo[:, :w], wyg[:, :w], equal_nan=True)
+            d = tol = 0.0
+            desc = f"2frame {w}x{h} " + " ".join(f"{k}={v}" for k, v in kw.items())
+        elif kind == "rb":
+            # the labelled red-black mode against its CPU twin, bit for bit
+            w, h = int(rng.integers(2, 331)), int(rng.integers(2, 261))
+            K = int(rng.choice([1, 3, 5, 7, 11, 30]))
+            s0 = sor_system(rng, w, h)
+            s0["du"][:, :w] = rng.uniform(-.2, .2, (h, w)); s0["dv"][:, :w] = rng.uniform(-.2, .2, (h, w))
+            a = copy_sys(s0)
+            o.sor(a["du"], a["dv"], a["a11"], a["a12"], a["a22"], a["b1"], a["b2"], a["sh"], a["sv"], w, K, 1.9, red_black=True)
+            b = {k: c_(v).copy() for k, v in s0.items()}
+            ctx.sor_coupled(b["du"], b["dv"], b["a11"], b["a12"], b["a22"], b["b1"], b["b2"], b["sh"], b["sv"], w, K, 1.9, red_black=True)
+            ok = all(np.array_equal(a[k][:, :w], b[k][:, :w]) for k in ("du", "dv"))
+            d = tol = 0.0
+            desc = f"red-black {w}x{h} K={K}"
+        elif kind == "occ":
+            # alternations with the occlusion step (energies + cut) through a lockstep job: runs to the end, finite where the oracle is, and close to the oracle
+            # wherever the two cuts agree (a minimum cut need not be unique: not a bit test -- tests/test_gpu_parity.py::test_level_with_occlusion_reasoning is)
+            S = int(rng.choice([2, 3]))
+            w, h = int(rng.integers(16, 200)), int(rng.integers(16, 150))
+            kw = dict(S=S, niter_alter=int(rng.integers(2, 4)), niter_outer=int(rng.integers(1, 4)), niter_solver=int(rng.choice([30, 10])), occlusion_reasoning=1,
+                      thres_outer=float(rng.choice([0, 1e-3])), layers=1)
+            kw["rho"] = [1.0] if S == 2 else [1.0, 1.0]; kw["omega"] = [0.0] if S == 2 else [0.0, 2.0]
+            fr, af, sf = frames_for(rng, w, h, 2 * S - 1)
+            kw["norm_avg"] = af; kw["norm_std"] = sf
+            po, ps = set_params(kw)
+            for p_ in (po, ps):
+                p_.occlusion_reasoning = 1; p_.niter_alter = kw["niter_alter"]
+            stride = orc.stride_of(w)
+            wxo, wyo = orc.plane(h, stride), orc.plane(h, stride)
+            rc = o.compute_one_level(po, wxo, wyo, fr, w)[0]
+            nb = int(rng.choice([1, 3]))
+            job = sfa.Job(ctx, ps, w, h, nb)
+            for b in range(nb):
+                job.upload(b, [c_(f) for f in fr])
+            job.run()
+            outs = [job.download(b) for b in range(nb)]
+            occ = job.download_occlusions(0)
+            job.close()
+            same = all(np.array_equal(outs[0][0], x[0]) and np.array_equal(outs[0][1], x[1]) for x in outs[1:])
+            diff = np.maximum(np.abs(wxo[:, :w] - outs[0][0][:, :w]), np.abs(wyo[:, :w] - outs[0][1][:, :w]))
+            d = float(np.median(diff)); tol = 1e-3
+            ok = rc == 0 and same and np.isfinite(outs[0][0][:, :w]).all() == np.isfinite(wxo[:, :w]).all() and d <= tol and set(np.unique(occ[:, :w])) <= {-1.0, 0.0, 1.0}
+            desc = f"occlusion run {w}x{h} S={S} alter={kw['niter_alter']} outer={kw['niter_outer']} job={nb} share of pixels within 1e-4: {(diff <= 1e-4).mean():.3f}"
+        elif kind == "sor":
             w, h = int(rng.integers(2, 331)), int(rng.integers(2, 261))
             K = int(rng.choice([1, 2, 3, 5, 6, 7, 10, 15, 30, 30, 30, 31]))
             nb = int(rng.choice([1, 1, 2, 3, 5, 8, 9, 12, 17, 40]))
@@ -117,7 +212,7 @@ while time.time() < t_end:
                       one_direction=int(rng.random() < 0.2), delta=float(rng.choice([1.0, 0.0, 0.5])), gamma=float(rng.choice([6.0, 0.2])), alpha=float(rng.choice([4.0, 1.0])),
                       robust_color=pen(pid()), robust_grad=pen(pid()), robust_reg=pen(pid()),
                       thres_outer=float(rng.choice([0, 0, 2e-3])), thres_inner=float(rng.choice([0, 0, 1e-3])),
-                      layers=int(rng.integers(2, 5)) if whole else 1)
+                      layers=int(rng.integers(2, 5)) if whole else 1, presmooth_sigma=float(rng.choice([0, 0, 0, 0.5, 0.8, 1.7])) if whole else 0.0)
             if S == 2:
                 kw["rho"] = [1.0]; kw["omega"] = [float(rng.choice([0, 0, 1.0]))]
             else:
@@ -174,6 +269,9 @@ while time.time() < t_end:
             fails.append((case_seed, desc, d, tol))
     except sfa.SlowflowError as e:
         cases += 1
+        if "image too small for even one pyramid level" in str(e) and min(w, h) <= 5:        # a documented limit: the reference finds zero levels there
+            print(f"[{case_seed}] ok   refused {kind} {w}x{h}: {e}", flush=True)
+            continue
         print(f"[{case_seed}] ERROR {kind}: {e}", flush=True)
         fails.append((case_seed, "error: " + str(e)[:200], 0, 0))
 print(f"{cases} cases, {len(fails)} failures (seeds {seed0 + 1} .. {case_seed})")
