@@ -83,9 +83,50 @@ while time.time() < t_end:
     case_seed += 1
     rng = np.random.default_rng(case_seed)
     r0 = rng.random()
-    kind = "sor" if r0 < 0.30 else "level" if r0 < 0.72 else "cut" if r0 < 0.82 else "2frame" if r0 < 0.90 else "rb" if r0 < 0.95 else "occ"
+    kind = "sor" if r0 < 0.25 else "level" if r0 < 0.60 else "batch" if r0 < 0.75 else "cut" if r0 < 0.83 else "2frame" if r0 < 0.90 else "rb" if r0 < 0.95 else "occ"
     try:
-        if kind == "cut":
+        if kind == "batch":
+            # DIFFERENT windows in one lockstep job under break thresholds (passengers leaving at different iterations, the device-side mask, the fused / separate
+            # norm reductions on either side of four windows): every window bit for bit what it gives alone, change norms included
+            S = int(rng.choice([2, 2, 3]))
+            w, h = int(rng.integers(16, 260)), int(rng.integers(16, 200))
+            nb = int(rng.choice([2, 3, 4, 5, 6, 9, 17]))
+            layers = int(rng.integers(1, 4)) if min(w, h) >= 40 else 1
+            kw = dict(S=S, niter_outer=int(rng.integers(2, 9)), niter_inner=int(rng.choice([1, 1, 2])), niter_solver=int(rng.choice([30, 10, 15])), layers=layers,
+                      thres_outer=float(rng.choice([2e-3, 5e-3, 1e-4])), thres_inner=float(rng.choice([0, 1e-3])), one_direction=int(rng.random() < 0.15),
+                      occlusion_reasoning=int(rng.random() < 0.2), niter_alter=int(rng.choice([1, 2])))
+            kw["rho"] = [1.0] if S == 2 else [1.0, float(rng.choice([1.0, 0.5]))]; kw["omega"] = [0.0] if S == 2 else [0.0, float(rng.choice([2.0, 0.0]))]
+            kinds = []
+            for k in range(min(nb, 4)):
+                fr, af, sf = frames_for(rng, w, h, 2 * S - 1)
+                if rng.random() < 0.3:
+                    fr = [fr[S - 1]] * (2 * S - 1)                      # a still window: meets the threshold at once
+                kinds.append(fr)
+            kw["norm_avg"] = af; kw["norm_std"] = sf
+            _, ps = set_params(kw)
+            ps.niter_alter = kw["niter_alter"]; ps.occlusion_reasoning = kw["occlusion_reasoning"]
+            alone = []
+            for fr in kinds:
+                j1 = sfa.Job(ctx, ps, w, h, 1)
+                j1.upload(0, [c_(f) for f in fr]); j1.run(); alone.append(j1.download(0)); j1.close()
+            pick = [int(rng.integers(0, len(kinds))) for _ in range(nb)]
+            job = sfa.Job(ctx, ps, w, h, nb)
+            for b in range(nb):
+                job.upload(b, [c_(f) for f in kinds[pick[b]]])
+            job.run()
+            ok = True
+            for b in range(nb):
+                gx, gy, chg = job.download(b)
+                ref = alone[pick[b]]
+                same_chg = all((np.isnan(x) and np.isnan(y)) or x == y for x, y in zip(chg, ref[2]))
+                ok = ok and np.array_equal(gx, ref[0], equal_nan=True) and np.array_equal(gy, ref[1], equal_nan=True) and same_chg
+            job.run()                                                 # and once more on the same uploads
+            gx, gy, _ = job.download(nb - 1)
+            ok = ok and np.array_equal(gx, alone[pick[nb - 1]][0], equal_nan=True)
+            job.close()
+            d = tol = 0.0
+            desc = f"batch {w}x{h} nb={nb} windows {pick} " + " ".join(f"{k}={v}" for k, v in kw.items() if k not in ("norm_avg", "norm_std"))
+        elif kind == "cut":
             # the exact two-label minimum cut of optimizeOcc against the oracle's exact fp64 minimum: equal energy (the labelling need not be unique)
             w, h = int(rng.integers(5, 331)), int(rng.integers(5, 261))
             st = sfa.stride_of(w)
