@@ -337,6 +337,8 @@ while time.time() < t_end:
             desc = f"occlusion run {w}x{h} S={S} alter={kw['niter_alter']} outer={kw['niter_outer']} job={nb} share of pixels within 1e-4: {(diff <= 1e-4).mean():.3f}"
         elif kind == "sor":
             w, h = int(rng.integers(2, 331)), int(rng.integers(2, 261))
+            if os.environ.get("FUZZ_LARGE") and rng.random() < 0.15:          # now and then a frame of the metric's order (the band count picks the seven-stage shape for batches)
+                w, h = int(rng.integers(600, 1101)), int(rng.integers(300, 521))
             K = int(rng.choice([1, 2, 3, 5, 6, 7, 10, 15, 30, 30, 30, 31]))
             nb = int(rng.choice([1, 1, 2, 3, 5, 8, 9, 12, 17, 40]))
             omega = float(rng.choice([1.0, 1.5, 1.9]))
@@ -360,6 +362,8 @@ while time.time() < t_end:
         else:
             S = int(rng.choice([2, 2, 3]))
             w, h = int(rng.integers(5, 331)), int(rng.integers(5, 261))
+            if os.environ.get("FUZZ_LARGE") and rng.random() < 0.08:
+                w, h = int(rng.integers(600, 1101)), int(rng.integers(300, 521))
             whole = rng.random() < 0.4 and w >= 40 and h >= 40
             pid = lambda: int(rng.choice([1, 1, 1, 2, 3, 4, 0]))
             pen = lambda i: (i, 0.001 if i in (1, 3) else 0.05, 0.5)
