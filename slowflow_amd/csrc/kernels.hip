@@ -519,7 +519,12 @@ __global__ void __launch_bounds__(64 * WS_ROWS) k_warp_smooth(WarpJobs J, float 
             for (int ch = 0; ch < 3; ch++) {
                 const float *sp = src3 + ch * g.pl;
                 if (SFA_X_WS & 8) { out[ch] = ax * ay + dx * dy; continue; }
+#if defined(SFA_WS_LDNT) && SFA_WS_LDNT      // what-if (round 6): the gathers as non-temporal loads
+                auto ldn = [](const float *ubase, unsigned boff) { return __builtin_nontemporal_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + boff)); };
+                out[ch] = ldn(sp, o11) * ax * ay + ldn(sp, o12) * dx * ay + ldn(sp, o21) * ax * dy + ldn(sp, o22) * dx * dy;
+#else
                 out[ch] = ld(sp, o11) * ax * ay + ld(sp, o12) * dx * ay + ld(sp, o21) * ax * dy + ld(sp, o22) * dx * dy;               // :748-753
+#endif
             }
         };
         auto put = [&](int j, const float(&out)[3]) {
