@@ -1212,6 +1212,12 @@ __device__ __forceinline__ void dma16(const float *gsrc, unsigned lds_byte) {
 #ifndef SFA_ASM_TY
 #define SFA_ASM_TY 8
 #endif
+#ifndef SFA_ASM_STAGGER
+#define SFA_ASM_STAGGER 0
+#endif
+#ifndef SFA_ASM_STAGGER_MODE
+#define SFA_ASM_STAGGER_MODE 0
+#endif
 constexpr int kAsmPair = SFA_ASM_PAIR, kAsmMinWaves = SFA_ASM_PAIR ? 4 : 6, kAsmTY = SFA_ASM_TY, kAsmNT = 64 * SFA_ASM_TY;      // tile rows, threads (one row per wave)
 struct XcdTiles { int nx, ny, chunk; };      // tile columns, tile rows, ceil(tiles of the launch / 8)
 template <int TY, int NT, int MINB, bool ZUV, int FAST, bool XT>
@@ -1264,6 +1270,15 @@ __global__ void __launch_bounds__(NT, MINB) k_assemble_images(AssembleArgs a, co
         if (b == 0 && threadIdx.x == 0) a.op.flags[(size_t)a.op.nb * a.op.ntasks] = 0;
     }
     if (!elem_active(g, b)) return;
+#if SFA_ASM_STAGGER
+    // what-if (round 6): the blocks of the launch's FIRST residency round (three per CU) start a third of a block's life apart, so that one block of a CU stages
+    // while the others compute; every later block starts when an earlier one ends and inherits its phase.  SFA_ASM_STAGGER = units of ~6 400 cycles per slot
+    if (XT && blockIdx.x < 8u * 32u * 3u) {
+        const unsigned j = blockIdx.x >> 3;                                     // index inside the XCD
+        const unsigned slot = SFA_ASM_STAGGER_MODE ? j % 3u : (j >> 5) % 3u;
+        for (unsigned s_ = 0; s_ < slot * SFA_ASM_STAGGER; s_++) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
     const int x0 = bx * DT_X - DT_H, y0 = by * TY - DT_H;                       // origin of the halo-4 tile
     // The whole staged tile (halo 4) lies inside the image -- no replicated columns, no folded border rows, no skipped rows: 84 % of the tiles at 1024x436.
     // The conversion pass and stage 1 then run without the per-item index arithmetic and checks (the item -> plane / row / quad divisions were a fifth of

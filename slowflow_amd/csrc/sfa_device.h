@@ -42,7 +42,11 @@ __device__ __forceinline__ int floor_to_int_x86(float v) {
 
 // image.c:521
 __device__ __forceinline__ float tap5(float m2, float m1, float c, float p1, float p2) {
+#if defined(SFA_X_NO_CENTRE_TAP)
+    return C5_0 * m2 + C5_1 * m1 + C5_3 * p1 + C5_4 * p2;      // timing what-if only: the reference multiplies the centre by -0.0 and adds it
+#else
     return C5_0 * m2 + C5_1 * m1 + C5_2 * c + C5_3 * p1 + C5_4 * p2;
+#endif
 }
 
 // horizontal 5-tap at (x,y) of a plane accessor F(x,y); replicate border (image.c:501-516)
