@@ -2231,8 +2231,12 @@ void launch_resize_flow(sfa_ctx *c, float *dstx, float *dsty, int dw, int dh, in
 #define SFA_PYR_GROUP 4
 #endif
 constexpr int kPyrRB = 5;                                            // rows per item of the column pass
+#ifndef SFA_PYR_NT
+#define SFA_PYR_NT 256
+#endif
+constexpr int kPyrNT = SFA_PYR_NT, kPyrNY = kPyrNT / 64;          // threads per block (what-if, round 6: 512 = eight waves on a tile)
 template <int R>
-__global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int dw, int dh, int dpitch, long dpl, long des, const float *__restrict__ src, int sw, int sh,
+__global__ void __launch_bounds__(kPyrNT) k_pyr_down(float *__restrict__ dst, int dw, int dh, int dpitch, long dpl, long des, const float *__restrict__ src, int sw, int sh,
                                                   int spitch, long spl, long ses, int nplanes, double scale_x, double scale_y, Taps t, int CM, int RM, int td) {
     extern __shared__ __attribute__((aligned(16))) float pyr_lds[];
     constexpr int r = R;                                              // compile-time radius: the tap loops unroll, the row buffer stays in registers
@@ -2252,7 +2256,7 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
     {
         const int NQ = CS / 4;
         int j = tid / NQ, qa = tid % NQ;
-        const int dj = 256 / NQ, dq = 256 % NQ;
+        const int dj = kPyrNT / NQ, dq = kPyrNT % NQ;
         // a thread's items four at a time: every global load of the group is issued before the first value is stored (one item at a time -- load, wait,
         // LDS store the next load could not pass -- a thread's 4-5 items were as many memory round trips in a row)
         constexpr int G = SFA_PYR_GROUP;
@@ -2278,7 +2282,7 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
     }
     __syncthreads();
     // k_gauss_h on the rows of the footprint, four columns per item: the 4 + 2r inputs come as aligned float4 reads
-    const int CQ = CM / 4, djq = 256 / CQ, dcq = 256 % CQ;
+    const int CQ = CM / 4, djq = kPyrNT / CQ, dcq = kPyrNT % CQ;
     for (int j = tid / CQ, cq = tid % CQ; j < RS;) {
         const int c = 4 * cq;
         constexpr int nq = (4 + 2 * r + 3) / 4;
@@ -2302,7 +2306,7 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
     // k_gauss_v, four columns of kPyrRB consecutive rows per item: the rows' 2r + kPyrRB inputs are read once (one row per item: 2r + 1 reads per output row --
     // the column pass was 45 % of the kernel's LDS traffic)
     constexpr int RB = kPyrRB;
-    for (int item = tid; item < (RM + RB - 1) / RB * CQ; item += 256) {
+    for (int item = tid; item < (RM + RB - 1) / RB * CQ; item += kPyrNT) {
         const int jg = item / CQ, c = 4 * (item % CQ), j0 = RB * jg;
         float4 in[RB + 2 * r];
 #pragma unroll
@@ -2343,8 +2347,8 @@ __global__ void __launch_bounds__(256) k_pyr_down(float *__restrict__ dst, int d
     if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
     const int sx1 = sx + 1 < sw ? sx + 1 : sx;
     const float a0 = 1.f - fx, a1 = fx;
-    for (int k = 0; k < td / 4; k++) {
-        const int ry = threadIdx.y + 4 * k, dy = dy0 + ry;
+    for (int k = 0; k < td / kPyrNY; k++) {
+        const int ry = threadIdx.y + kPyrNY * k, dy = dy0 + ry;
         if (dy >= dh) break;
         const float *r0 = V + s_sy[ry] - mx0, *r1 = V + s_sy1[ry] - mx0;
         const float fy = s_fy[ry], b0 = 1.f - fy, b1 = fy;
@@ -2369,7 +2373,7 @@ bool launch_pyr_down(sfa_ctx *c, float *dst, int dw, int dh, int dpitch, long dp
     Taps t;
     t.r = radius;
     for (int i = 0; i < 2 * radius + 1; i++) t.k[i] = taps[i];
-    const dim3 grid((dw + 63) / 64, (dh + td - 1) / td, nb * nplanes), block(64, 4);
+    const dim3 grid((dw + 63) / 64, (dh + td - 1) / td, nb * nplanes), block(64, kPyrNY);
 #define SFA_PYR(RR) case RR: hipLaunchKernelGGL(k_pyr_down<RR>, grid, block, lds, c->stream, dst, dw, dh, dpitch, dpl, des, src, sw, sh, spitch, spl, ses, nplanes, scale_x, scale_y, t, CM, RM, td); break
     switch (radius) {
         SFA_PYR(1); SFA_PYR(2); SFA_PYR(3); SFA_PYR(4); SFA_PYR(5); SFA_PYR(6); SFA_PYR(7); SFA_PYR(8);
